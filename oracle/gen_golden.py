@@ -1,0 +1,258 @@
+"""Generate tests/golden/*.npz by running the REFERENCE modules.  CONTAINER-ONLY script.
+
+    python -m oracle.gen_golden            # needs /root/reference mounted
+
+The reference's swin_transformer.py / roberta.py / heads.py are executed unmodified (by path,
+under oracle/shim.py); weights and inputs come from oracle/detgen.py + oracle/cases.py, so the
+fixtures hold OUTPUTS only (strided samples + norms).  The fused sequencing driven here is a
+transcription of fiber_module.py:310-367 (the LightningModule itself needs pytorch_lightning,
+absent in this image).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import cases, detgen, shim
+from .fiber_ref import DEFAULT_CONFIG, SWIN_VARIANTS
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def save(name, d):
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print(f"  wrote {name}.npz ({len(d)} arrays)")
+
+
+def grads_into(out, prefix, module, extra=()):
+    for n, p in module.named_parameters():
+        if p.grad is not None:
+            cases.flatten_summary(f"{prefix}grad/{n}", p.grad, out)
+    for n, t in extra:
+        cases.flatten_summary(f"{prefix}grad_in/{n}", t.grad, out)
+
+
+def gen_blocks(sw):
+    for name, c in cases.BLOCK_CASES.items():
+        sw.DIM_TEXT = c["dim_text"] or 768
+        blk = sw.SwinTransformerBlock(c["dim"], c["res"], c["heads"], window_size=c["ws"], shift_size=c["shift"],
+                                      dim_text=c["dim_text"]).eval()
+        detgen.fill_(blk)
+        x, y, ext, g = cases.block_inputs(name)
+        x.requires_grad_(True)
+        if y is not None:
+            y.requires_grad_(True)
+        out = blk(x, y, ext)
+        (out * g).sum().backward()
+        d = {}
+        cases.flatten_summary("out", out, d)
+        grads_into(d, "", blk, [("x", x)] + ([("y", y)] if y is not None else []))
+        save(name, d)
+
+
+def gen_merge(sw):
+    for name, c in cases.MERGE_CASES.items():
+        m = sw.PatchMerging(c["res"], c["dim"]).eval()
+        detgen.fill_(m)
+        L = c["res"][0] * c["res"][1]
+        x = cases.randn(name + ".x", (c["B"], L, c["dim"])).requires_grad_(True)
+        g = cases.randn(name + ".g", (c["B"], L // 4, 2 * c["dim"]))
+        out = m(x)
+        (out * g).sum().backward()
+        d = {}
+        cases.flatten_summary("out", out, d)
+        grads_into(d, "", m, [("x", x)])
+        save(name, d)
+
+
+def gen_patch_embed():
+    from timm.models.layers import PatchEmbed
+    for name, c in cases.EMBED_CASES.items():
+        m = PatchEmbed(img_size=c["img"], patch_size=4, in_chans=3, embed_dim=c["dim"], norm_layer=nn.LayerNorm).eval()
+        detgen.fill_(m)
+        img = cases.randn(name + ".img", (c["B"], 3, c["img"], c["img"]))
+        out = m(img)
+        g = cases.randn(name + ".g", tuple(out.shape))
+        (out * g).sum().backward()
+        d = {}
+        cases.flatten_summary("out", out, d)
+        grads_into(d, "", m)
+        save(name, d)
+
+
+def gen_roberta(rb):
+    rb.NUM_FUSE_BLOCK, rb.DIM_IMG = 6, 1024
+    # embeddings: real vocab, padded rows
+    cfg = shim.roberta_config()
+    emb = rb.RobertaEmbeddings(cfg).eval()
+    detgen.fill_(emb)
+    b = detgen.synth_batch(3, image_size=8, seed=3)
+    out = emb(input_ids=b["text_ids"])
+    g = cases.randn("emb.g", tuple(out.shape))
+    (out * g).sum().backward()
+    d = {}
+    cases.flatten_summary("out", out, d)
+    rows = torch.unique(b["text_ids"])
+    cases.flatten_summary("grad/word_rows", emb.word_embeddings.weight.grad[rows], d)
+    cases.flatten_summary("grad/position_embeddings", emb.position_embeddings.weight.grad, d)
+    cases.flatten_summary("grad/token_type_embeddings", emb.token_type_embeddings.weight.grad, d)
+    cases.flatten_summary("grad/LayerNorm.weight", emb.LayerNorm.weight.grad, d)
+    cases.flatten_summary("grad/LayerNorm.bias", emb.LayerNorm.bias.grad, d)
+    save("roberta_emb", d)
+
+    for name, c in cases.ROBERTA_LAYER_CASES.items():
+        lyr = rb.RobertaLayer(cfg, layer_index=c["layer_index"]).eval()
+        detgen.fill_(lyr)
+        h, ext, img, g = cases.roberta_layer_inputs(name)
+        h.requires_grad_(True)
+        if img is not None:
+            img.requires_grad_(True)
+        out = lyr(h, ext, encoder_hidden_states=img, last_norm=c["last_norm"])[0]
+        (out * g).sum().backward()
+        d = {}
+        cases.flatten_summary("out", out, d)
+        grads_into(d, "", lyr, [("h", h)] + ([("img", img)] if img is not None else []))
+        save(name, d)
+
+
+class RefText(nn.Module):
+    def __init__(self, rb, cfg):
+        super().__init__()
+        self.embeddings = rb.RobertaEmbeddings(cfg)
+        self.encoder = rb.RobertaEncoder(cfg)
+        self.pooler = nn.Module()
+        self.pooler.dense = nn.Linear(cfg.hidden_size, cfg.hidden_size)
+
+
+class RefFused(nn.Module):
+    """Reference modules wired with FIBERTransformerSS's attribute names (fiber_module.py:27-117)."""
+
+    def __init__(self, sw, rb, heads, config):
+        super().__init__()
+        c = dict(DEFAULT_CONFIG)
+        c.update(config)
+        self.c = c
+        hs = c["hidden_size"]
+        sw.NUM_FUSE_BLOCK = rb.NUM_FUSE_BLOCK = c["num_fuse_block"]
+        rb.DIM_IMG = c["input_image_embed_size"]
+        sw.DIM_TEXT = c.get("swin_dim_text", 768)
+        self.cross_modal_text_transform = nn.Linear(c["input_text_embed_size"], hs)
+        self.cross_modal_image_transform = nn.Linear(c["input_image_embed_size"], hs)
+        self.cross_modal_text_transform_itc = nn.Linear(c["input_text_embed_size"], hs)
+        self.cross_modal_image_transform_itc = nn.Linear(c["input_image_embed_size"], hs)
+        dim, depths, nh = c.get("swin_arch") or SWIN_VARIANTS[c["vit"]]
+        self.vit_model = sw.SwinTransformer(img_size=c["image_size"], patch_size=4, embed_dim=dim, depths=depths,
+                                            num_heads=nh, drop_path_rate=c["drop_path_rate"])
+        tcfg = shim.roberta_config(
+            vocab_size=c["vocab_size"], hidden_size=c["input_text_embed_size"], num_hidden_layers=c["num_layers"],
+            num_attention_heads=c["num_heads"], intermediate_size=c["input_text_embed_size"] * c["mlp_ratio"],
+            max_position_embeddings=c["max_position_embeddings"], hidden_dropout_prob=c["text_dropout"],
+            attention_probs_dropout_prob=c["text_dropout"])
+        self.text_transformer = RefText(rb, tcfg)
+        self.cross_modal_image_pooler = heads.Pooler(hs)
+        self.cross_modal_text_pooler = heads.Pooler(hs)
+        self.cross_modal_image_pooler_itc = heads.Pooler(hs)
+        self.cross_modal_text_pooler_itc = heads.Pooler(hs)
+        hcfg = shim.roberta_config(vocab_size=c["vocab_size"], hidden_size=hs, layer_norm_eps=1e-12)
+        self.mlm_score = heads.MLMHead(hcfg)
+        self.itm_score = heads.ITMHead(hs * 2)
+        self.rank_output = nn.Linear(hs, 1)
+
+    def infer(self, batch, mask_text=False, img=None):
+        c = self.c
+        img = batch["image"][0] if img is None else img
+        sfx = "_mlm" if mask_text else ""
+        ids, masks = batch["text_ids" + sfx], batch["text_masks"]
+        x = self.vit_model.patch_embed(img)
+        for layer in self.vit_model.layers[:2]:
+            x = layer(x)
+        t = self.text_transformer.embeddings(input_ids=ids)
+        ext = (1.0 - masks[:, None, None, :].float()) * -10000.0
+        npt = c["num_layers"] - c["num_fuse_block"]
+        for layer in self.text_transformer.encoder.layer[:npt]:
+            t = layer(t, ext)[0]
+        for i, blk in enumerate(self.vit_model.layers[2].blocks):
+            if i < 8 + npt:
+                x = blk(x)
+            else:
+                fx = blk(x, t, ext)
+                t = self.text_transformer.encoder.layer[i - 8](t, ext, encoder_hidden_states=x)[0]
+                x = fx
+        x = self.vit_model.layers[2].downsample(x)
+        for i, blk in enumerate(self.vit_model.layers[3].blocks):
+            fx = blk(x, t, ext)
+            t = self.text_transformer.encoder.layer[i + 10](t, ext, encoder_hidden_states=x, last_norm=(i == 0))[0]
+            x = fx
+        t = self.cross_modal_text_transform(t)
+        x = self.cross_modal_image_transform(x)
+        ct = self.cross_modal_text_pooler(t)
+        ci = self.cross_modal_image_pooler(x.mean(1, keepdim=True))
+        return {"text_feats": t, "image_feats": x, "cls_feats": torch.cat([ct, ci], -1)}
+
+
+def gen_paths(sw, rb, heads):
+    for name, pc in cases.PATH_CASES.items():
+        torch.manual_seed(0)
+        m = RefFused(sw, rb, heads, pc["config"]).eval()
+        detgen.fill_(m)
+        c = m.c
+        b = detgen.synth_batch(pc["B"], c["image_size"], c["max_text_len"], c["vocab_size"], seed=1,
+                               min_len=min(8, c["max_text_len"] // 2))
+        d = {}
+        with torch.set_grad_enabled(pc["grads"]):
+            o = m.infer(b, mask_text=True)
+            for k in ("text_feats", "image_feats", "cls_feats"):
+                cases.flatten_summary("mlm/" + k, o[k], d)
+            logits = m.mlm_score(o["text_feats"])
+            mlm = F.cross_entropy(logits.view(-1, c["vocab_size"]), b["text_labels_mlm"].view(-1), ignore_index=-100)
+            lab = b["itm_labels"]
+            imgs = torch.where(lab.view(-1, 1, 1, 1) == 1, b["image"][0], b["false_image_0"][0])
+            o2 = m.infer(b, img=imgs)
+            for k in ("text_feats", "image_feats", "cls_feats"):
+                cases.flatten_summary("itm/" + k, o2[k], d)
+            itm_logits = m.itm_score(o2["cls_feats"])
+            itm = F.cross_entropy(itm_logits, lab.long())
+            d["mlm_loss"], d["itm_loss"] = np.float64(mlm.item()), np.float64(itm.item())
+            cases.flatten_summary("itm_logits", itm_logits, d)
+            if pc["grads"]:
+                (mlm + itm).backward()
+                unused = []
+                for n, p in m.named_parameters():
+                    if p.grad is None:
+                        unused.append(n)
+                    else:
+                        d[f"gradnorm/{n}"] = np.float64(p.grad.double().norm().item())
+                d["unused_params"] = np.array(unused)
+                for n in ("vit_model.patch_embed.proj.weight", "text_transformer.encoder.layer.11.alpha_t2i",
+                          "vit_model.layers.3.blocks.1.attn.alpha_i2t",
+                          "vit_model.layers.3.blocks.0.attn.relative_position_bias_table",
+                          "vit_model.layers.0.blocks.1.attn.relative_position_bias_table",
+                          "text_transformer.embeddings.position_embeddings.weight"):
+                    cases.flatten_summary("grad/" + n, dict(m.named_parameters())[n].grad, d)
+        print(f"  {name}: mlm {mlm.item():.6f} itm {itm.item():.6f}")
+        save(name, d)
+
+
+def main():
+    torch.set_num_threads(8)
+    sw, rb = shim.load_reference()
+    heads = shim._load("heads", os.path.join(shim.MODS, "heads.py"), "_fiber_reference_modules")
+    only = set(sys.argv[1:])
+    if not only or "blocks" in only:
+        gen_blocks(sw)
+    if not only or "merge" in only:
+        gen_merge(sw)
+    if not only or "embed" in only:
+        gen_patch_embed()
+    if not only or "roberta" in only:
+        gen_roberta(rb)
+    if not only or "paths" in only:
+        gen_paths(sw, rb, heads)
+
+
+if __name__ == "__main__":
+    main()
