@@ -1,0 +1,34 @@
+"""Default configuration dict of the coarse-grained path (values from the reference's sacred config,
+coarse_grained/fiber/config.py:21-92; sacred itself is not needed to build the dict)."""
+import copy
+
+
+def _loss_names(d):
+    ret = {"itm": 0, "itc": 0, "mlm": 0, "vqa": 0, "nlvr2": 0, "caption_mle": 0, "caption_gold": 0, "caption_cider": 0}
+    ret.update(d)
+    return ret
+
+
+DEFAULTS = dict(
+    exp_name="fiber", seed=0, loss_names=_loss_names({"itm": 1, "mlm": 1}), batch_size=4096,
+    image_size=384, vit="swin_base_patch4_window12_384_in22k", image_only=False, draw_false_image=1,
+    input_image_embed_size=1024, resolution_before=384, pretrained_vit=False,
+    vqav2_label_size=3129, max_text_len=40, tokenizer="roberta-base", vocab_size=50265, whole_word_masking=False,
+    mlm_prob=0.15, draw_false_text=0, input_text_embed_size=768,
+    hidden_size=768, num_heads=12, num_layers=12, mlp_ratio=4, drop_rate=0.1, num_fuse_block=6, itc_pooler=True,
+    optim_type="adamw", learning_rate=1e-5, weight_decay=0.01, decay_power=1, max_epoch=100, max_steps=100000,
+    warmup_steps=10000, end_lr=0, lr_mult_head=5, lr_mult_cross_modal=5,
+    get_recall_metric=False, get_recall_metric_itc=True, cider_path=None,
+    resume_from=None, fast_dev_run=False, val_check_interval=1.0, test_only=False,
+    data_root="", log_dir="result", per_gpu_batchsize=0, num_gpus=8, num_nodes=1, load_path="", num_workers=8, precision=32,
+)
+
+
+def make_config(**over):
+    c = copy.deepcopy(DEFAULTS)
+    for k, v in over.items():
+        if k == "loss_names":
+            c[k] = _loss_names(v)
+        else:
+            c[k] = v
+    return c

@@ -1,0 +1,689 @@
+// Fused multi-head attention for the FIBER fused-backbone path (gfx950 / CDNA4, wave64, MFMA 16x16x32 bf16).
+//
+// One kernel family serves all four attention sites of the reference hot path:
+//   WINDOW mode  Swin (shifted-)window self-attention, swin_transformer.py:195-224 + roll/partition/reverse
+//                (:99-126, 367-387): softmax(q.k^T * d^-1/2 + bias_table[rel_index] + shift_mask) . v
+//                Windows are never materialised: q/k/v/o live in IMAGE TOKEN ORDER ([B*H*W, 3C] / [B*H*W, C]) and the
+//                cyclic shift + window partition are folded into the row addressing; the relative-position bias is
+//                gathered from the (2ws-1)^2 x heads table (staged per head in LDS) and the {0,-100} shift mask is
+//                recomputed from region labels (swin_transformer.py:327-350) - no N x N tensors touch HBM.
+//   PLAIN mode   RoBERTa self-attention (roberta.py:256-326, additive key mask (1-m)*-10000, attention-prob dropout),
+//                image->text cross attention (swin_transformer.py:226-256: queries = image tokens in token order, keys =
+//                the sample's 40 text tokens, so repeat_interleave over windows disappears) and text->image cross
+//                attention (roberta.py:272-276: no mask).
+//
+// Structure (flash-style, no score tensor in HBM): a wave owns a strip of 16 queries; K and V^T of up to 160 keys are
+// staged in LDS per workgroup and shared by its waves; S^T = K.Q^T is computed with swapped MFMA operands so a lane
+// holds 4 consecutive keys of ONE query => row max / row sum are in-lane + two __shfl_xor (no LDS round trip), and the
+// fp32 probabilities convert in-register into the B operand of O^T = V^T.P^T (the key order inside a 32-key MFMA
+// k-slot is permuted identically on the V^T side, which is free).  Longer key ranges are walked in chunks with an
+// online softmax.  Backward recomputes P from the saved log-sum-exp (one fp32 per query/head) in two passes:
+//   pass A (wave = query strip):  dQ, and in WINDOW mode the relative-position-bias gradient accumulated in registers
+//                                 over the windows a workgroup visits (no atomics; partials folded by a scatter kernel)
+//   pass B (wave = key strip):    dK, dV
+#include "common.h"
+
+namespace {
+
+constexpr int NKT = 10;          // key (or query) tiles of 16 per LDS chunk  -> 160 rows
+constexpr int CH = NKT * 16;     // rows per chunk
+constexpr int CHP = CH + 8;      // padded row length of transposed LDS images (elements)
+
+struct AttnP {
+  const bf16* q; const bf16* k; const bf16* v; bf16* o;       // forward tensors (row-major, head h at column h*D)
+  const bf16* dout; bf16* dq; bf16* dk; bf16* dv;              // backward tensors
+  float* lse;            // [rows_q, H]  log-sum-exp of each query row (natural log), indexed by q token row
+  const float* delta;    // [rows_q, H]  rowsum(dO * O)
+  int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+  int H, Lq, Lk, G;      // heads, queries / keys per group, number of groups (windows or samples)
+  float scale;
+  const float* kmask;    // PLAIN: additive key mask [G, Lk] or null
+  // WINDOW mode geometry
+  int window, Hres, Wres, ws, shift, nWw, nW;
+  const float* bias_table;   // [(2ws-1)^2, H] fp32
+  float* dbias_part;         // [gridDim.z, H, N, N] fp32 partial bias gradients (pass A, WINDOW)
+  int groups_per_block;      // pass A: windows visited by one workgroup
+  // attention-probability dropout
+  float p_drop; uint64_t seed;
+};
+
+__device__ __forceinline__ int region_of(int x, int n, int ws, int shift) { return x < n - ws ? 0 : (x < n - shift ? 1 : 2); }
+
+// token row (in the [B*Hres*Wres] token-ordered tensors) and shift-mask region of window-local position i of window g
+__device__ __forceinline__ void window_tok(const AttnP& p, int g, int i, int& tok, int& reg) {
+  const int b = g / p.nW, w = g - b * p.nW;
+  const int wr = w / p.nWw, wc = w - wr * p.nWw;
+  const int pr = i / p.ws, pc = i - pr * p.ws;
+  const int R = wr * p.ws + pr, C = wc * p.ws + pc;
+  int r = R + p.shift, c = C + p.shift;
+  r = r >= p.Hres ? r - p.Hres : r;
+  c = c >= p.Wres ? c - p.Wres : c;
+  tok = (b * p.Hres + r) * p.Wres + c;
+  reg = p.shift > 0 ? region_of(R, p.Hres, p.ws, p.shift) * 3 + region_of(C, p.Wres, p.ws, p.shift) : 0;
+}
+
+__device__ __forceinline__ float group4_max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
+__device__ __forceinline__ float group4_sum(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
+
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { o[e] = f2bf(a[e]); o[4 + e] = f2bf(b[e]); }
+  return o;
+}
+
+// Stage `nrows` rows (row r of the chunk <-> global row rowmap[r]) of a [*, ld] bf16 matrix (head slice D wide) into LDS,
+// row-major (stride D+8) and/or transposed ([D][CHP]).  Rows >= valid are zero filled.
+template <int D, bool RM, bool TR>
+__device__ __forceinline__ void stage(const bf16* __restrict__ src, int ld, int hcol, const int* rowmap, int nrows,
+                                      int valid, bf16* rm, bf16* tr) {
+  constexpr int CPR = D / 8;
+  for (int idx = threadIdx.x; idx < nrows * CPR; idx += blockDim.x) {
+    const int r = idx / CPR, c = idx - r * CPR;
+    bf16x8 v;
+    if (r < valid) {
+      v = *reinterpret_cast<const bf16x8*>(src + (size_t)rowmap[r] * ld + hcol + c * 8);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = f2bf(0.f);
+    }
+    if (RM) *reinterpret_cast<bf16x8*>(rm + r * (D + 8) + c * 8) = v;
+    if (TR) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) tr[(c * 8 + e) * CHP + r] = v[e];
+    }
+  }
+}
+
+// fragment of a transposed LDS image for MFMA operand A: row d, k-slots = keys {t0*16+g*4..+3} U {t0*16+16+g*4..+3}
+__device__ __forceinline__ bf16x8 tr_frag(const bf16* tr, int d, int t0, int g) {
+  const bf16x4 lo = *reinterpret_cast<const bf16x4*>(tr + d * CHP + t0 * 16 + g * 4);
+  const bf16x4 hi = *reinterpret_cast<const bf16x4*>(tr + d * CHP + t0 * 16 + 16 + g * 4);
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi[e]; }
+  return o;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Shared LDS layout (dynamic): [rowmap int CH][reg int CH][addmask float CH][aux float CH][btab float nb] then bf16 images
+struct Lds {
+  int* rowmap; int* reg; float* addmask; float* aux; float* btab;
+  bf16* rm0; bf16* rm1; bf16* tr0; bf16* tr1;
+};
+template <int D>
+__device__ __forceinline__ Lds carve(char* base, int nbias, int n_rm, int n_tr) {
+  Lds L;
+  L.rowmap = reinterpret_cast<int*>(base);
+  L.reg = L.rowmap + CH;
+  L.addmask = reinterpret_cast<float*>(L.reg + CH);
+  L.aux = L.addmask + CH;
+  L.btab = L.aux + CH;
+  size_t off = (size_t)(4 * CH + ((nbias + 3) & ~3)) * 4;
+  bf16* img = reinterpret_cast<bf16*>(base + off);
+  L.rm0 = img; img += (n_rm > 0) * CH * (D + 8);
+  L.rm1 = img; img += (n_rm > 1) * CH * (D + 8);
+  L.tr0 = img; img += (n_tr > 0) * D * CHP;
+  L.tr1 = img;
+  return L;
+}
+template <int D>
+size_t lds_bytes(int nbias, int n_rm, int n_tr) {
+  return (size_t)(4 * CH + ((nbias + 3) & ~3)) * 4 + (size_t)n_rm * CH * (D + 8) * 2 + (size_t)n_tr * D * CHP * 2;
+}
+
+// rows of chunk `c0..c0+n` of the KEY (or query) axis -> LDS rowmap/reg/addmask
+__device__ __forceinline__ void fill_rowmeta(const AttnP& p, const Lds& L, int g, int base, int n, int len, bool keys) {
+  for (int r = threadIdx.x; r < n; r += blockDim.x) {
+    const int j = base + r;
+    int tok = 0, reg = 0;
+    float am = 0.f;
+    if (j < len) {
+      if (p.window) window_tok(p, g, j, tok, reg);
+      else { tok = g * len + j; if (keys && p.kmask) am = p.kmask[(size_t)g * len + j]; }
+    } else {
+      am = -INFINITY;
+    }
+    L.rowmap[r] = tok; L.reg[r] = reg; L.addmask[r] = am;
+  }
+}
+
+// score bias for (query i, key j) in WINDOW mode
+__device__ __forceinline__ float win_bias(const AttnP& p, const float* btab, int i, int j) {
+  const int pri = i / p.ws, pci = i - pri * p.ws, prj = j / p.ws, pcj = j - prj * p.ws;
+  return btab[(pri - prj + p.ws - 1) * (2 * p.ws - 1) + (pci - pcj + p.ws - 1)];
+}
+
+// ===================================================== forward =================================================
+template <int D>
+__global__ __launch_bounds__(768) void attn_fwd_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KS = D / 32, DT = D / 16;
+  const int nb = p.window ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
+  Lds L = carve<D>(smem, nb, 1, 1);
+  bf16* Ks = L.rm0; bf16* Vt = L.tr0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int gq = lane >> 4, lq = lane & 15;
+  const int h = blockIdx.y, g = blockIdx.z;
+  const int strip = blockIdx.x * nw + wave;
+  const int i = strip * 16 + lq;                      // this lane's query (window-local / sample-local)
+  const bool qvalid = i < p.Lq;
+  int qtok = 0, qreg = 0;
+  {
+    const int ic = qvalid ? i : p.Lq - 1;
+    if (p.window) window_tok(p, g, ic, qtok, qreg); else qtok = g * p.Lq + ic;
+  }
+  for (int t = threadIdx.x; t < nb; t += blockDim.x) L.btab[t] = p.bias_table[(size_t)t * p.H + h];
+
+  bf16x8 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+    qf[ks] = *reinterpret_cast<const bf16x8*>(p.q + (size_t)qtok * p.ldq + h * D + ks * 32 + gq * 8);
+
+  const int ntiles = (p.Lk + 15) / 16, nchunk = (ntiles + NKT - 1) / NKT, tpc = (ntiles + nchunk - 1) / nchunk;
+  float m = -INFINITY, lsum = 0.f;
+  f32x4 oacc[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint32_t thresh = (uint32_t)((double)p.p_drop * 4294967296.0);
+  const float inv_keep = 1.f / (1.f - p.p_drop);
+
+  for (int c = 0; c < nchunk; ++c) {
+    const int kbase = c * tpc * 16;
+    __syncthreads();                                   // previous chunk fully consumed
+    fill_rowmeta(p, L, g, kbase, tpc * 16, p.Lk, true);
+    __syncthreads();
+    const int valid = min(tpc * 16, p.Lk - kbase);
+    stage<D, true, false>(p.k, p.ldk, h * D, L.rowmap, tpc * 16, valid, Ks, nullptr);
+    stage<D, false, true>(p.v, p.ldv, h * D, L.rowmap, (tpc * 16 + 31) & ~31, valid, nullptr, Vt);
+    __syncthreads();
+
+    f32x4 s[NKT];
+    float cmax = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      s[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      if (kt < tpc) {
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 16 + lq) * (D + 8) + ks * 32 + gq * 8);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], a, 0, 0, 0);   // S^T[key][query]
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int jl = kt * 16 + gq * 4 + r;
+          float v = a[r] * p.scale + L.addmask[jl];
+          if (p.window) {
+            v += win_bias(p, L.btab, qvalid ? i : 0, min(kbase + jl, p.Lk - 1));
+            if (L.reg[jl] != qreg) v += -100.f;
+          }
+          s[kt][r] = v;
+          cmax = fmaxf(cmax, v);
+        }
+      }
+    }
+    cmax = group4_max(cmax);
+    const float mnew = fmaxf(m, cmax);
+    const float alpha = __expf(m - mnew);             // m = -inf on the first chunk -> 0
+    m = mnew;
+    float psum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float e = kt < tpc ? __expf(s[kt][r] - mnew) : 0.f;
+        psum += e;
+        if (p.p_drop > 0.f) {
+          const uint64_t idx = (((uint64_t)g * p.H + h) * p.Lq + (qvalid ? i : 0)) * p.Lk + kbase + kt * 16 + gq * 4 + r;
+          e = drop_keep(p.seed, idx, thresh) ? e * inv_keep : 0.f;
+        }
+        s[kt][r] = e;
+      }
+    }
+    lsum = lsum * alpha + psum;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
+#pragma unroll
+    for (int t2 = 0; t2 < NKT / 2; ++t2) {
+      if (t2 * 2 < tpc) {
+        const bf16x8 pf = pack8(s[2 * t2], s[2 * t2 + 1]);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const bf16x8 vf = tr_frag(Vt, dt * 16 + lq, 2 * t2, gq);
+          oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);   // O^T[d][query]
+        }
+      }
+    }
+  }
+  lsum = group4_sum(lsum);
+  if (qvalid) {
+    const float inv = 1.f / lsum;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      bf16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = f2bf(oacc[dt][r] * inv);
+      *reinterpret_cast<bf16x4*>(p.o + (size_t)qtok * p.ldo + h * D + dt * 16 + gq * 4) = o;
+    }
+    if (gq == 0 && p.lse) p.lse[(size_t)qtok * p.H + h] = m + __logf(lsum);
+  }
+}
+
+// ===================================================== delta ===================================================
+// delta[row, h] = sum_d dO[row, h*D+d] * O[row, h*D+d]
+template <int D>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ o, const bf16* __restrict__ dout,
+                                                         float* __restrict__ delta, int rows, int H, int ldo, int lddo) {
+  constexpr int LPH = D / 8;                         // lanes per head
+  const int vecs = H * LPH;
+  for (size_t idx = blockIdx.x * (size_t)256 + threadIdx.x; idx < (size_t)rows * vecs; idx += (size_t)gridDim.x * 256) {
+    const int row = idx / vecs, v = idx - (size_t)row * vecs;
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(o + (size_t)row * ldo + v * 8);
+    const bf16x8 b = *reinterpret_cast<const bf16x8*>(dout + (size_t)row * lddo + v * 8);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += bf2f(a[e]) * bf2f(b[e]);
+#pragma unroll
+    for (int off = 1; off < LPH; off <<= 1) s += __shfl_xor(s, off);
+    if ((v & (LPH - 1)) == 0) delta[(size_t)row * H + v / LPH] = s;
+  }
+}
+
+// ===================================================== backward, pass A: dQ (+ dbias) ==========================
+template <int D>
+__global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KS = D / 32, DT = D / 16;
+  const int nb = p.window ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
+  Lds L = carve<D>(smem, nb, 2, 1);
+  bf16* Ks = L.rm0; bf16* Vs = L.rm1; bf16* Kt = L.tr0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int gq = lane >> 4, lq = lane & 15;
+  const int h = blockIdx.y;
+  const int strip = blockIdx.x * nw + wave;
+  const int i = strip * 16 + lq;
+  const bool qvalid = i < p.Lq;
+  for (int t = threadIdx.x; t < nb; t += blockDim.x) L.btab[t] = p.bias_table[(size_t)t * p.H + h];
+  const int ntiles = (p.Lk + 15) / 16, nchunk = (ntiles + NKT - 1) / NKT, tpc = (ntiles + nchunk - 1) / nchunk;
+  const uint32_t thresh = (uint32_t)((double)p.p_drop * 4294967296.0);
+  const float inv_keep = 1.f / (1.f - p.p_drop);
+
+  f32x4 dbacc[NKT];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) dbacc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int g0 = blockIdx.z * p.groups_per_block, g1 = min(p.G, g0 + p.groups_per_block);
+  for (int g = g0; g < g1; ++g) {
+    int qtok = 0, qreg = 0;
+    {
+      const int ic = qvalid ? i : p.Lq - 1;
+      if (p.window) window_tok(p, g, ic, qtok, qreg); else qtok = g * p.Lq + ic;
+    }
+    bf16x8 qf[KS], dof[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      qf[ks] = *reinterpret_cast<const bf16x8*>(p.q + (size_t)qtok * p.ldq + h * D + ks * 32 + gq * 8);
+      dof[ks] = *reinterpret_cast<const bf16x8*>(p.dout + (size_t)qtok * p.lddo + h * D + ks * 32 + gq * 8);
+    }
+    const float lse = p.lse[(size_t)qtok * p.H + h], dlt = p.delta[(size_t)qtok * p.H + h];
+    f32x4 dqacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) dqacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int c = 0; c < nchunk; ++c) {
+      const int kbase = c * tpc * 16;
+      __syncthreads();
+      fill_rowmeta(p, L, g, kbase, tpc * 16, p.Lk, true);
+      __syncthreads();
+      const int valid = min(tpc * 16, p.Lk - kbase);
+      stage<D, true, true>(p.k, p.ldk, h * D, L.rowmap, (tpc * 16 + 31) & ~31, valid, Ks, Kt);
+      stage<D, true, false>(p.v, p.ldv, h * D, L.rowmap, tpc * 16, valid, Vs, nullptr);
+      __syncthreads();
+#pragma unroll
+      for (int t2 = 0; t2 < NKT / 2; ++t2) {
+        if (t2 * 2 < tpc) {
+          f32x4 ds[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int kt = 2 * t2 + u;
+            ds[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kt < tpc) {
+              f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 16 + lq) * (D + 8) + ks * 32 + gq * 8);
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + (kt * 16 + lq) * (D + 8) + ks * 32 + gq * 8);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], a, 0, 0, 0);     // S^T
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[ks], dp, 0, 0, 0);  // dP^T
+              }
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int jl = kt * 16 + gq * 4 + r;
+                float sv = a[r] * p.scale + L.addmask[jl];
+                if (p.window) {
+                  sv += win_bias(p, L.btab, qvalid ? i : 0, min(kbase + jl, p.Lk - 1));
+                  if (L.reg[jl] != qreg) sv += -100.f;
+                }
+                const float pr = __expf(sv - lse);
+                float dpe = dp[r];
+                if (p.p_drop > 0.f) {
+                  const uint64_t idx = (((uint64_t)g * p.H + h) * p.Lq + (qvalid ? i : 0)) * p.Lk + kbase + jl;
+                  dpe = drop_keep(p.seed, idx, thresh) ? dpe * inv_keep : 0.f;
+                }
+                const float d = qvalid ? pr * (dpe - dlt) : 0.f;
+                ds[u][r] = d;
+              }
+              if (p.window) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dbacc[kt][r] += ds[u][r];
+              }
+            }
+          }
+          const bf16x8 dsf = pack8(ds[0], ds[1]);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const bf16x8 ktf = tr_frag(Kt, dt * 16 + lq, 2 * t2, gq);
+            dqacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf, dqacc[dt], 0, 0, 0);   // dQ^T[d][query]
+          }
+        }
+      }
+    }
+    if (qvalid) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = f2bf(dqacc[dt][r] * p.scale);
+        *reinterpret_cast<bf16x4*>(p.dq + (size_t)qtok * p.lddq + h * D + dt * 16 + gq * 4) = o;
+      }
+    }
+  }
+  if (p.window && p.dbias_part && qvalid) {           // single key chunk guaranteed by the host for WINDOW mode
+    float* dst = p.dbias_part + (((size_t)blockIdx.z * p.H + h) * p.Lq + i) * p.Lk;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (kt < tpc) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = kt * 16 + gq * 4 + r;
+          if (j < p.Lk) dst[j] = dbacc[kt][r];
+        }
+      }
+    }
+  }
+}
+
+// ===================================================== backward, pass B: dK, dV ================================
+template <int D>
+__global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KS = D / 32, DT = D / 16;
+  const int nb = p.window ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
+  Lds L = carve<D>(smem, nb, 2, 2);
+  bf16* Qs = L.rm0; bf16* dOs = L.rm1; bf16* Qt = L.tr0; bf16* dOt = L.tr1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int gq = lane >> 4, lq = lane & 15;
+  const int h = blockIdx.y, g = blockIdx.z;
+  const int strip = blockIdx.x * nw + wave;
+  const int j = strip * 16 + lq;                      // this lane's key
+  const bool kvalid = j < p.Lk;
+  int ktok = 0, kreg = 0;
+  float kadd = 0.f;
+  {
+    const int jc = kvalid ? j : p.Lk - 1;
+    if (p.window) window_tok(p, g, jc, ktok, kreg);
+    else { ktok = g * p.Lk + jc; if (p.kmask) kadd = p.kmask[(size_t)g * p.Lk + jc]; }
+  }
+  for (int t = threadIdx.x; t < nb; t += blockDim.x) L.btab[t] = p.bias_table[(size_t)t * p.H + h];
+  bf16x8 kf[KS], vf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    kf[ks] = *reinterpret_cast<const bf16x8*>(p.k + (size_t)ktok * p.ldk + h * D + ks * 32 + gq * 8);
+    vf[ks] = *reinterpret_cast<const bf16x8*>(p.v + (size_t)ktok * p.ldv + h * D + ks * 32 + gq * 8);
+  }
+  const int ntiles = (p.Lq + 15) / 16, nchunk = (ntiles + NKT - 1) / NKT, tpc = (ntiles + nchunk - 1) / nchunk;
+  const uint32_t thresh = (uint32_t)((double)p.p_drop * 4294967296.0);
+  const float inv_keep = 1.f / (1.f - p.p_drop);
+  f32x4 dkacc[DT], dvacc[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) { dkacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  for (int c = 0; c < nchunk; ++c) {
+    const int qbase = c * tpc * 16;
+    __syncthreads();
+    fill_rowmeta(p, L, g, qbase, tpc * 16, p.Lq, false);
+    __syncthreads();
+    const int valid = min(tpc * 16, p.Lq - qbase);
+    const int nst = (tpc * 16 + 31) & ~31;
+    stage<D, true, true>(p.q, p.ldq, h * D, L.rowmap, nst, valid, Qs, Qt);
+    stage<D, true, true>(p.dout, p.lddo, h * D, L.rowmap, nst, valid, dOs, dOt);
+    for (int r = threadIdx.x; r < tpc * 16; r += blockDim.x) {   // per-query lse (addmask slot) and delta (aux slot)
+      const bool ok = r < valid;
+      L.addmask[r] = ok ? p.lse[(size_t)L.rowmap[r] * p.H + h] : INFINITY;   // +inf -> p = exp(-inf) = 0 for padded queries
+      L.aux[r] = ok ? p.delta[(size_t)L.rowmap[r] * p.H + h] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t2 = 0; t2 < NKT / 2; ++t2) {
+      if (t2 * 2 < tpc) {
+        f32x4 ds[2], pd[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int qt = 2 * t2 + u;
+          ds[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          pd[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (qt < tpc) {
+            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+              const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + (qt * 16 + lq) * (D + 8) + ks * 32 + gq * 8);
+              const bf16x8 df = *reinterpret_cast<const bf16x8*>(dOs + (qt * 16 + lq) * (D + 8) + ks * 32 + gq * 8);
+              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[ks], a, 0, 0, 0);    // S[query][key]
+              dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf[ks], dp, 0, 0, 0);  // dP[query][key]
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int il = qt * 16 + gq * 4 + r;      // chunk-local query
+              const int ig = min(qbase + il, p.Lq - 1);
+              float sv = a[r] * p.scale + kadd;
+              if (p.window) {
+                sv += win_bias(p, L.btab, ig, kvalid ? j : 0);
+                if (L.reg[il] != kreg) sv += -100.f;
+              }
+              float pr = kvalid ? __expf(sv - L.addmask[il]) : 0.f;
+              float dpe = dp[r], prd = pr;
+              if (p.p_drop > 0.f) {
+                const uint64_t idx = (((uint64_t)g * p.H + h) * p.Lq + ig) * p.Lk + (kvalid ? j : 0);
+                const bool keep = drop_keep(p.seed, idx, thresh);
+                dpe = keep ? dpe * inv_keep : 0.f;
+                prd = keep ? pr * inv_keep : 0.f;
+              }
+              ds[u][r] = pr * (dpe - L.aux[il]);
+              pd[u][r] = prd;
+            }
+          }
+        }
+        const bf16x8 dsf = pack8(ds[0], ds[1]), pf = pack8(pd[0], pd[1]);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const bf16x8 qtf = tr_frag(Qt, dt * 16 + lq, 2 * t2, gq);
+          const bf16x8 dotf = tr_frag(dOt, dt * 16 + lq, 2 * t2, gq);
+          dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf, dkacc[dt], 0, 0, 0);   // dK^T[d][key]
+          dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotf, pf, dvacc[dt], 0, 0, 0);   // dV^T[d][key]
+        }
+      }
+    }
+  }
+  if (kvalid) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      bf16x4 ok, ov;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ok[r] = f2bf(dkacc[dt][r] * p.scale); ov[r] = f2bf(dvacc[dt][r]); }
+      *reinterpret_cast<bf16x4*>(p.dk + (size_t)ktok * p.lddk + h * D + dt * 16 + gq * 4) = ok;
+      *reinterpret_cast<bf16x4*>(p.dv + (size_t)ktok * p.lddv + h * D + dt * 16 + gq * 4) = ov;
+    }
+  }
+}
+
+// dtable[t, h] = sum_z sum_{(i,j): rel_index(i,j)=t} part[z, h, i, j]     (swin_transformer.py:166-176 index)
+__global__ __launch_bounds__(64) void dbias_scatter_kernel(const float* __restrict__ part, float* __restrict__ dtable,
+                                                           int nz, int H, int ws) {
+  const int t = blockIdx.x, h = blockIdx.y, N = ws * ws, W2 = 2 * ws - 1;
+  const int dr = t / W2 - (ws - 1), dc = t % W2 - (ws - 1);     // (pri - prj, pci - pcj)
+  float s = 0.f;
+  for (int idx = threadIdx.x; idx < nz * N; idx += 64) {
+    const int z = idx / N, i = idx - z * N;
+    const int pri = i / ws, pci = i - pri * ws, prj = pri - dr, pcj = pci - dc;
+    if (prj >= 0 && prj < ws && pcj >= 0 && pcj < ws)
+      s += part[(((size_t)z * H + h) * N + i) * N + prj * ws + pcj];
+  }
+  s = wave_sum(s);
+  if (threadIdx.x == 0) dtable[(size_t)t * H + h] = s;
+}
+
+int pick_waves(int nstrips) { return nstrips <= 12 ? nstrips : (nstrips % 9 == 0 ? 9 : 8); }
+
+template <int D>
+int launch_fwd(AttnP& p, hipStream_t st) {
+  const int nstrips = cdiv(p.Lq, 16), nw = pick_waves(nstrips);
+  const int nb = p.window ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
+  const size_t sh = lds_bytes<D>(nb, 1, 1);
+  hipLaunchKernelGGL((attn_fwd_kernel<D>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), sh, st, p);
+  FIBER_CHECK_LAUNCH();
+  return FIBER_OK;
+}
+
+template <int D>
+int launch_bwd(AttnP& p, float* delta, float* dbias_table, float* dbias_ws, int nz, hipStream_t st) {
+  const int rows_q = p.G * p.Lq;
+  {
+    const size_t total = (size_t)rows_q * p.H * (D / 8);
+    int grid = (int)((total + 255) / 256);
+    grid = grid > 2048 ? 2048 : grid;
+    hipLaunchKernelGGL((attn_delta_kernel<D>), dim3(grid), dim3(256), 0, st, (const bf16*)p.o, p.dout, delta, rows_q, p.H, p.ldo, p.lddo);
+    FIBER_CHECK_LAUNCH();
+  }
+  p.delta = delta;
+  const int nb = p.window ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
+  {
+    const int nstrips = cdiv(p.Lq, 16), nw = pick_waves(nstrips);
+    int gz = p.G;
+    p.groups_per_block = 1;
+    p.dbias_part = nullptr;
+    if (p.window) {
+      if (p.Lk > CH) return FIBER_EINVAL;             // bias-gradient accumulation needs a single key chunk
+      gz = nz;
+      p.groups_per_block = cdiv(p.G, nz);
+      gz = cdiv(p.G, p.groups_per_block);
+      p.dbias_part = dbias_ws;
+    }
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<D>), dim3(cdiv(nstrips, nw), p.H, gz), dim3(64 * nw), lds_bytes<D>(nb, 2, 1), st, p);
+    FIBER_CHECK_LAUNCH();
+    if (p.window) {
+      hipLaunchKernelGGL(dbias_scatter_kernel, dim3(nb, p.H), dim3(64), 0, st, dbias_ws, dbias_table, gz, p.H, p.ws);
+      FIBER_CHECK_LAUNCH();
+    }
+  }
+  {
+    const int nstrips = cdiv(p.Lk, 16), nw = pick_waves(nstrips);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<D>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), lds_bytes<D>(nb, 2, 2), st, p);
+    FIBER_CHECK_LAUNCH();
+  }
+  return FIBER_OK;
+}
+
+bool attr_done = false;
+void ensure_attrs() {
+  if (attr_done) return;
+  const int big = 160 * 1024;
+  hipFuncSetAttribute((const void*)attn_fwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)attn_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  attr_done = true;
+}
+
+}  // namespace
+
+// --------------------------------------------------------------------------------------------------- C ABI
+// Window attention in image-token order.  qkv: [B*Hres*Wres, 3C] bf16 with channel layout [3][heads][32]
+// (swin_transformer.py:202); o: [B*Hres*Wres, C]; bias_table fp32 [(2ws-1)^2, heads]; lse fp32 [B*Hres*Wres, heads].
+// shift = 0 disables the cyclic shift and the region mask.  head_dim must be 32.
+extern "C" int fiber_window_attn_fwd_bf16(const void* qkv, const float* bias_table, void* o, float* lse, int B, int Hres,
+                                          int Wres, int C, int heads, int ws, int shift, hipStream_t stream) {
+  if (C != heads * 32 || Hres % ws || Wres % ws || shift < 0 || shift >= ws) return FIBER_EINVAL;
+  ensure_attrs();
+  AttnP p{};
+  const bf16* base = (const bf16*)qkv;
+  p.q = base; p.k = base + C; p.v = base + 2 * C; p.o = (bf16*)o; p.lse = lse;
+  p.ldq = p.ldk = p.ldv = 3 * C; p.ldo = C;
+  p.H = heads; p.Lq = p.Lk = ws * ws; p.nWw = Wres / ws; p.nW = (Hres / ws) * p.nWw; p.G = B * p.nW;
+  p.scale = 0.17677669529663687f;  // 32^-0.5
+  p.window = 1; p.Hres = Hres; p.Wres = Wres; p.ws = ws; p.shift = shift; p.bias_table = bias_table;
+  return launch_fwd<32>(p, stream);
+}
+
+// Number of partial-gradient slices pass A uses for B*nW windows; workspace = slices * heads * N * N floats.
+extern "C" int fiber_window_attn_bwd_slices(int n_windows, int heads) {
+  int nz = cdiv(512, heads);
+  return nz > n_windows ? n_windows : nz;
+}
+
+// Backward of the above.  dqkv: [B*Hres*Wres, 3C] (fully written); dbias_table fp32 [(2ws-1)^2, heads] (overwritten);
+// delta_ws: fp32 [B*Hres*Wres*heads]; dbias_ws: fp32 [slices*heads*N*N].
+extern "C" int fiber_window_attn_bwd_bf16(const void* qkv, const float* bias_table, const void* o, const void* dout,
+                                          const float* lse, void* dqkv, float* dbias_table, float* delta_ws,
+                                          float* dbias_ws, int B, int Hres, int Wres, int C, int heads, int ws, int shift,
+                                          hipStream_t stream) {
+  if (C != heads * 32 || Hres % ws || Wres % ws || shift < 0 || shift >= ws) return FIBER_EINVAL;
+  ensure_attrs();
+  AttnP p{};
+  const bf16* base = (const bf16*)qkv;
+  bf16* dbase = (bf16*)dqkv;
+  p.q = base; p.k = base + C; p.v = base + 2 * C; p.o = (bf16*)o; p.lse = (float*)lse; p.dout = (const bf16*)dout;
+  p.dq = dbase; p.dk = dbase + C; p.dv = dbase + 2 * C;
+  p.ldq = p.ldk = p.ldv = p.lddq = p.lddk = p.lddv = 3 * C; p.ldo = p.lddo = C;
+  p.H = heads; p.Lq = p.Lk = ws * ws; p.nWw = Wres / ws; p.nW = (Hres / ws) * p.nWw; p.G = B * p.nW;
+  p.scale = 0.17677669529663687f;
+  p.window = 1; p.Hres = Hres; p.Wres = Wres; p.ws = ws; p.shift = shift; p.bias_table = bias_table;
+  return launch_bwd<32>(p, delta_ws, dbias_table, dbias_ws, fiber_window_attn_bwd_slices(p.G, heads), stream);
+}
+
+// Generic multi-head attention: q [B*Lq, ldq], k/v [B*Lk, ldk/ldv], o [B*Lq, ldo]; head h occupies columns
+// [h*D, (h+1)*D) of each; kmask: additive fp32 [B, Lk] or NULL; scale applied to q.k^T; p_drop/seed: attention-prob
+// dropout (0 disables).  D in {32, 64}.  lse fp32 [B*Lq, heads].
+extern "C" int fiber_mha_fwd_bf16(const void* q, const void* k, const void* v, const float* kmask, void* o, float* lse,
+                                  int B, int heads, int Lq, int Lk, int D, int ldq, int ldk, int ldv, int ldo,
+                                  float scale, float p_drop, uint64_t seed, hipStream_t stream) {
+  if ((D != 32 && D != 64) || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) || Lq <= 0 || Lk <= 0) return FIBER_EINVAL;
+  ensure_attrs();
+  AttnP p{};
+  p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.o = (bf16*)o; p.lse = lse;
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+  p.H = heads; p.Lq = Lq; p.Lk = Lk; p.G = B; p.scale = scale; p.kmask = kmask; p.p_drop = p_drop; p.seed = seed;
+  return D == 32 ? launch_fwd<32>(p, stream) : launch_fwd<64>(p, stream);
+}
+
+// Backward: dq/dk/dv have the same row layout as q/k/v with leading dims lddq/lddk/lddv; delta_ws fp32 [B*Lq*heads].
+extern "C" int fiber_mha_bwd_bf16(const void* q, const void* k, const void* v, const float* kmask, const void* o,
+                                  const void* dout, const float* lse, void* dq, void* dk, void* dv, float* delta_ws,
+                                  int B, int heads, int Lq, int Lk, int D, int ldq, int ldk, int ldv, int ldo, int lddo,
+                                  int lddq, int lddk, int lddv, float scale, float p_drop, uint64_t seed,
+                                  hipStream_t stream) {
+  if ((D != 32 && D != 64) || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 7) || (lddo & 7) || (lddq & 3) || (lddk & 3) ||
+      (lddv & 3) || Lq <= 0 || Lk <= 0)
+    return FIBER_EINVAL;
+  ensure_attrs();
+  AttnP p{};
+  p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.o = (bf16*)o; p.lse = (float*)lse;
+  p.dout = (const bf16*)dout; p.dq = (bf16*)dq; p.dk = (bf16*)dk; p.dv = (bf16*)dv;
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
+  p.H = heads; p.Lq = Lq; p.Lk = Lk; p.G = B; p.scale = scale; p.kmask = kmask; p.p_drop = p_drop; p.seed = seed;
+  return D == 32 ? launch_bwd<32>(p, delta_ws, nullptr, nullptr, 1, stream) : launch_bwd<64>(p, delta_ws, nullptr, nullptr, 1, stream);
+}

@@ -1,0 +1,59 @@
+// Shared device helpers for the fiber_hip kernels (gfx950 / CDNA4 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define FIBER_OK 0
+#define FIBER_EINVAL 1
+#define FIBER_ELAUNCH 2
+
+#define FIBER_CHECK_LAUNCH()                          \
+  do {                                                \
+    hipError_t e__ = hipGetLastError();               \
+    if (e__ != hipSuccess) return FIBER_ELAUNCH;      \
+  } while (0)
+
+__device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
+__device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// d/dx of exact (erf) GELU
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// Counter-based RNG for dropout: one 32-bit hash per (seed, element index).  Forward and backward
+// recompute the same keep-mask from (seed, index), so no mask tensor is ever stored.
+__device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+// keep with probability (1-p):  thresh = p * 2^32
+__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
+  return hash_u32(seed, idx) >= thresh;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,184 @@
+// Memory-bound helper kernels of the FIBER fused path (gfx950): everything is 16-byte vectorised bf16 with
+// fp32 math, grid-stride, ~2048 workgroups (HBM roofline work; nothing here is GEMM shaped).
+//
+//   gelu_bwd          dH = dG * gelu'(H)                    (timm Mlp / RobertaIntermediate exact-erf GELU backward)
+//   scale_add         out = a + alpha * b                   (x + alpha_i2t*y swin_transformer.py:259; alpha_t2i roberta.py:483)
+//   dot_scaled        *out += sum(a*b)                      (d alpha = <dOut, branch>)
+//   colsum            db[n] = sum_m dY[m,n]                 (bias gradients of every nn.Linear)
+//   dropout           y = keep ? x/(1-p) : 0                (RoBERTa hidden dropout, roberta.py:198,339,420)
+//   rowscale_add      out = r + s[row/rows_per_sample] * x  (timm DropPath on the residual branch, swin_transformer.py:390-391)
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16* __restrict__ dg, const bf16* __restrict__ h,
+                                                       bf16* __restrict__ dh, size_t nvec) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    const bf16x8 a = reinterpret_cast<const bf16x8*>(dg)[i], b = reinterpret_cast<const bf16x8*>(h)[i];
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(a[e]) * gelu_erf_grad(bf2f(b[e])));
+    reinterpret_cast<bf16x8*>(dh)[i] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void scale_add_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b,
+                                                        const float* __restrict__ alpha, float mult,
+                                                        bf16* __restrict__ out, size_t nvec) {
+  const float s = (alpha ? alpha[0] : 1.f) * mult;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    const bf16x8 y = reinterpret_cast<const bf16x8*>(b)[i];
+    bf16x8 o;
+    if (a) {
+      const bf16x8 x = reinterpret_cast<const bf16x8*>(a)[i];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(x[e]) + s * bf2f(y[e]));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(s * bf2f(y[e]));
+    }
+    reinterpret_cast<bf16x8*>(out)[i] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void dot_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b,
+                                                  float* __restrict__ out, size_t nvec) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    const bf16x8 x = reinterpret_cast<const bf16x8*>(a)[i], y = reinterpret_cast<const bf16x8*>(b)[i];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += bf2f(x[e]) * bf2f(y[e]);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// column sums of a [M, N] bf16 matrix -> fp32 [N]; block = 32 column-vectors x 8 row lanes, partials via atomics
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, float* __restrict__ out, int M, int N,
+                                                     int ld, int rows_per_block) {
+  __shared__ float red[8][32 * 8 + 1];
+  const int cv = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int col = (blockIdx.x * 32 + cv) * 8;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (col < N) {
+    for (int r = r0 + rl; r < r1; r += 8) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (size_t)r * ld + col);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += bf2f(v[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rl][cv * 8 + e] = s[e];
+  __syncthreads();
+  const int c = threadIdx.x;  // 256 columns handled by this block
+  float t = 0.f;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) t += red[r][c];
+  const int gc = blockIdx.x * 256 + c;
+  if (gc < N) atomicAdd(out + gc, t);
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, size_t nvec,
+                                                      uint64_t seed, uint32_t thresh, float inv_keep) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    const bf16x8 v = reinterpret_cast<const bf16x8*>(x)[i];
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = drop_keep(seed, i * 8 + e, thresh) ? f2bf(bf2f(v[e]) * inv_keep) : f2bf(0.f);
+    reinterpret_cast<bf16x8*>(y)[i] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void rowscale_add_kernel(const bf16* __restrict__ r, const bf16* __restrict__ x,
+                                                           const float* __restrict__ scale, bf16* __restrict__ out,
+                                                           size_t nvec, size_t vec_per_sample) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    const float s = scale[i / vec_per_sample];
+    const bf16x8 b = reinterpret_cast<const bf16x8*>(x)[i];
+    bf16x8 o;
+    if (r) {
+      const bf16x8 a = reinterpret_cast<const bf16x8*>(r)[i];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(a[e]) + s * bf2f(b[e]));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(s * bf2f(b[e]));
+    }
+    reinterpret_cast<bf16x8*>(out)[i] = o;
+  }
+}
+
+inline int ew_grid(size_t nvec) {
+  size_t g = (nvec + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace
+
+extern "C" int fiber_gelu_bwd_bf16(const void* dgelu, const void* h_pre, void* dh, long n, hipStream_t stream) {
+  if (n <= 0) return FIBER_OK;
+  if (n & 7) return FIBER_EINVAL;
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, stream, (const bf16*)dgelu, (const bf16*)h_pre, (bf16*)dh, (size_t)n / 8);
+  FIBER_CHECK_LAUNCH();
+  return FIBER_OK;
+}
+
+// out = a + alpha[0]*mult*b   (a may be NULL -> out = alpha*mult*b; alpha may be NULL -> 1)
+extern "C" int fiber_scale_add_bf16(const void* a, const void* b, const float* alpha, float mult, void* out, long n,
+                                    hipStream_t stream) {
+  if (n <= 0) return FIBER_OK;
+  if (n & 7) return FIBER_EINVAL;
+  hipLaunchKernelGGL(scale_add_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, stream, (const bf16*)a, (const bf16*)b, alpha, mult, (bf16*)out, (size_t)n / 8);
+  FIBER_CHECK_LAUNCH();
+  return FIBER_OK;
+}
+
+// out[0] += sum(a*b)   (out must be zero-initialised by the caller for a plain dot product)
+extern "C" int fiber_dot_bf16(const void* a, const void* b, float* out, long n, hipStream_t stream) {
+  if (n <= 0) return FIBER_OK;
+  if (n & 7) return FIBER_EINVAL;
+  size_t nvec = n / 8;
+  int grid = (int)((nvec + 255) / 256);
+  grid = grid > 512 ? 512 : grid;
+  hipLaunchKernelGGL(dot_kernel, dim3(grid), dim3(256), 0, stream, (const bf16*)a, (const bf16*)b, out, nvec);
+  FIBER_CHECK_LAUNCH();
+  return FIBER_OK;
+}
+
+// out[n] += sum_m x[m,n]   (out fp32[N], zero-initialised by the caller); N % 8 == 0
+extern "C" int fiber_colsum_bf16(const void* x, float* out, int M, int N, int ld, hipStream_t stream) {
+  if (M <= 0 || N <= 0) return FIBER_OK;
+  if ((N & 7) || (ld & 7)) return FIBER_EINVAL;
+  const int gx = cdiv(N, 256);
+  int gy = cdiv(M, 256);
+  const int cap = cdiv(2048, gx);
+  gy = gy > cap ? cap : gy;
+  const int rpb = cdiv(M, gy);
+  hipLaunchKernelGGL(colsum_kernel, dim3(gx, cdiv(M, rpb)), dim3(256), 0, stream, (const bf16*)x, out, M, N, ld, rpb);
+  FIBER_CHECK_LAUNCH();
+  return FIBER_OK;
+}
+
+// y = keep(seed, i) ? x / (1-p) : 0 ; the same call with dy as x gives the backward.
+extern "C" int fiber_dropout_bf16(const void* x, void* y, long n, float p, uint64_t seed, hipStream_t stream) {
+  if (n <= 0) return FIBER_OK;
+  if ((n & 7) || p < 0.f || p >= 1.f) return FIBER_EINVAL;
+  const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+  hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, (size_t)n / 8, seed, thresh, 1.f / (1.f - p));
+  FIBER_CHECK_LAUNCH();
+  return FIBER_OK;
+}
+
+// out = r + scale[sample] * x  with `per_sample` contiguous elements per sample (r may be NULL)
+extern "C" int fiber_rowscale_add_bf16(const void* r, const void* x, const float* scale, void* out, long n,
+                                       long per_sample, hipStream_t stream) {
+  if (n <= 0) return FIBER_OK;
+  if ((n & 7) || (per_sample & 7)) return FIBER_EINVAL;
+  hipLaunchKernelGGL(rowscale_add_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, stream, (const bf16*)r, (const bf16*)x, scale, (bf16*)out, (size_t)n / 8, (size_t)per_sample / 8);
+  FIBER_CHECK_LAUNCH();
+  return FIBER_OK;
+}

@@ -1,0 +1,183 @@
+// bf16 MFMA GEMM with fused epilogues for the FIBER fused-backbone path (gfx950 / CDNA4).
+//
+//   Y[M,N] = epilogue( X[M,K] . W[N,K]^T )         X, W, Y row-major bf16, fp32 accumulate
+//
+// Replaces the separate ATen addmm + bias + GELU + residual-add kernels behind every nn.Linear on the
+// reference hot path (swin_transformer.py:197,221,233,238,257 qkv/proj/i2t projections; timm Mlp fc1/fc2 at
+// swin_transformer.py:325; roberta.py:231-241,337,398,415 query/key/value/dense layers; PatchMerging.reduction
+// swin_transformer.py:431; fiber_module.py:349-350 cross-modal transforms).
+//
+// Design (CDNA4): 256-thread workgroups (4 waves, 2x2), block tile BMxBNx64, per-wave (BM/2)x(BN/2) built from
+// v_mfma_f32_32x32x16_bf16 tiles.  Operands are staged global -> VGPR (16 B/lane, coalesced 128-B rows) -> LDS with a
+// 16-byte-chunk XOR swizzle (chunk ^= (row>>1)&7) that makes both the ds_write_b128 staging stores and the
+// ds_read_b128 fragment loads bank-conflict free (LDS bank row = 256 B = two 128-B tile rows).  LDS is double
+// buffered: loads for tile t+1 are issued before the MFMAs of tile t and written after them, one barrier per K tile.
+// The MFMA is issued with swapped operands (D^T = W.X^T) so each lane owns 4 consecutive output columns and the
+// epilogue (bias, exact-erf GELU, residual, optional pre-activation copy) reads/writes 8-byte vectors.
+// Workgroup ids are remapped so that consecutive tiles of one X row-panel land on the same XCD (shared L2).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 64;
+
+struct GemmArgs {
+  const bf16* X; const bf16* W; const float* bias; const bf16* R; bf16* Y; bf16* Ypre;
+  int M, N, K, ldx, ldw, ldy, ldr, act;
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return (row * 8 + (chunk ^ ((row >> 1) & 7))) * 8; }  // element offset
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
+  constexpr int WTM = BM / 2, WTN = BN / 2;      // per-wave tile
+  constexpr int TM = WTM / 32, TN = WTN / 32;    // 32x32 MFMA tiles per wave
+  constexpr int PA = BM / 32, PB = BN / 32;      // staging passes (32 rows x 8 chunks per pass)
+  __shared__ __attribute__((aligned(16))) bf16 As[2][BM * BK];
+  __shared__ __attribute__((aligned(16))) bf16 Bs[2][BN * BK];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tilesN = (a.N + BN - 1) / BN, tilesM = (a.M + BM - 1) / BM;
+  const int nblk = tilesM * tilesN;
+  // XCD-aware bijective remap: hardware places block b on XCD b%8; give each XCD a contiguous run of tiles.
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm0 = (bid / tilesN) * BM, tn0 = (bid % tilesN) * BN;
+
+  const int srow = tid >> 3, schunk = tid & 7;
+  const bf16* xrow[PA];
+  const bf16* wrow[PB];
+#pragma unroll
+  for (int p = 0; p < PA; ++p) {
+    int r = tm0 + srow + p * 32;
+    r = r < a.M ? r : a.M - 1;
+    xrow[p] = a.X + (size_t)r * a.ldx + schunk * 8;
+  }
+#pragma unroll
+  for (int p = 0; p < PB; ++p) {
+    int r = tn0 + srow + p * 32;
+    r = r < a.N ? r : a.N - 1;
+    wrow[p] = a.W + (size_t)r * a.ldw + schunk * 8;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  uint4 ra[PA], rb[PB];
+  const int nk = (a.K + BK - 1) / BK;
+  auto gload = [&](int kt) {
+    const int k = kt * BK + schunk * 8;
+    const bool ok = k < a.K;   // K % 8 == 0 is required, so a chunk is entirely in or out
+#pragma unroll
+    for (int p = 0; p < PA; ++p) ra[p] = ok ? *reinterpret_cast<const uint4*>(xrow[p] + kt * BK) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int p = 0; p < PB; ++p) rb[p] = ok ? *reinterpret_cast<const uint4*>(wrow[p] + kt * BK) : make_uint4(0, 0, 0, 0);
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < PA; ++p) *reinterpret_cast<uint4*>(&As[buf][swz(srow + p * 32, schunk)]) = ra[p];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) *reinterpret_cast<uint4*>(&Bs[buf][swz(srow + p * 32, schunk)]) = rb[p];
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  const int frow = lane & 31, fk = lane >> 5;   // fragment row within a 32-row tile, k-chunk selector (0/1)
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[i] = *reinterpret_cast<const bf16x8*>(&As[cur][swz(wm * WTM + i * 32 + frow, ks * 2 + fk)]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fb[j] = *reinterpret_cast<const bf16x8*>(&Bs[cur][swz(wn * WTN + j * 32 + frow, ks * 2 + fk)]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D^T[n][m]
+    }
+    if (kt + 1 < nk) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: lane holds, for output row m = ..+(lane&31), columns n = ..+8*q+4*(lane>>5)+{0..3}, q = 0..3
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = tm0 + wm * WTM + i * 32 + (lane & 31);
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = tn0 + wn * WTN + j * 32 + q * 8 + (lane >> 5) * 4;
+        if (n >= a.N) continue;   // N % 4 == 0 required
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
+        if (a.bias) {
+          const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+        if (a.act == 1) {
+          if (a.Ypre) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+            *reinterpret_cast<bf16x4*>(a.Ypre + (size_t)m * a.ldy + n) = o;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        }
+        if (a.R) {
+          const bf16x4 r = *reinterpret_cast<const bf16x4*>(a.R + (size_t)m * a.ldr + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bf2f(r[e]);
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+        *reinterpret_cast<bf16x4*>(a.Y + (size_t)m * a.ldy + n) = o;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// C ABI ---------------------------------------------------------------------------------------------------------
+// Y = act(X.W^T + bias) + residual.  bias: fp32[N] or NULL; residual: bf16[M,ldr] or NULL; act: 0 none, 1 exact GELU
+// (Ypre, if non-NULL with act=1, receives the pre-activation for the backward pass).  K % 8 == 0, N % 4 == 0,
+// all leading dimensions multiples of 8 elements (16-byte rows).
+extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bias, const void* residual, void* Y,
+                                  void* Ypre, int M, int N, int K, int ldx, int ldw, int ldy, int ldr, int act,
+                                  hipStream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return FIBER_OK;
+  if ((K & 7) || (N & 3) || (ldx & 7) || (ldw & 7) || (ldy & 3) || (residual && (ldr & 3))) return FIBER_EINVAL;
+  GemmArgs a{(const bf16*)X, (const bf16*)W, bias, (const bf16*)residual, (bf16*)Y, (bf16*)Ypre,
+             M, N, K, ldx, ldw, ldy, ldr, act};
+  const long big = (long)cdiv(M, 128) * cdiv(N, 128);
+  if (big >= 192) {
+    hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), dim3((unsigned)big), dim3(256), 0, stream, a);
+  } else {
+    const long small = (long)cdiv(M, 64) * cdiv(N, 64);
+    hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), dim3((unsigned)small), dim3(256), 0, stream, a);
+  }
+  FIBER_CHECK_LAUNCH();
+  return FIBER_OK;
+}

@@ -1,0 +1,90 @@
+"""ctypes binding of libfiber_hip.so (the C ABI declared in include/fiber_hip.h).
+
+PyTorch is plumbing only: tensors provide device memory (``data_ptr()``) and the current HIP stream.  There is no
+CPU or eager fallback -- if the shared library is missing or a tensor is not on a HIP device the call raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfiber_hip.so")
+
+P, I, F, L, U64 = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_uint64
+
+# name -> argtypes (stream appended automatically)
+SIGNATURES = {
+    "fiber_gemm_nt_bf16": [P, P, P, P, P, P, I, I, I, I, I, I, I, I],
+    "fiber_layernorm_fwd_bf16": [P, P, P, P, P, P, I, I, F],
+    "fiber_layernorm_bwd_bf16": [P, P, P, P, P, P, P, P, P, I, I],
+    "fiber_patch_merge_ln_fwd_bf16": [P, P, P, P, P, P, I, I, I, I, F],
+    "fiber_patch_merge_ln_bwd_bf16": [P, P, P, P, P, P, P, P, P, I, I, I, I],
+    "fiber_window_attn_fwd_bf16": [P, P, P, P, I, I, I, I, I, I, I],
+    "fiber_window_attn_bwd_bf16": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I],
+    "fiber_mha_fwd_bf16": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, F, U64],
+    "fiber_mha_bwd_bf16": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, F, F, U64],
+    "fiber_roberta_embed_fwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, U64],
+    "fiber_roberta_embed_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, U64],
+    "fiber_im2col_patch4": [P, P, I, I, I],
+    "fiber_gelu_bwd_bf16": [P, P, P, L],
+    "fiber_scale_add_bf16": [P, P, P, F, P, L],
+    "fiber_dot_bf16": [P, P, P, L],
+    "fiber_colsum_bf16": [P, P, I, I, I],
+    "fiber_dropout_bf16": [P, P, L, F, U64],
+    "fiber_rowscale_add_bf16": [P, P, P, P, L, L],
+}
+# host-side helpers without a stream argument
+PLAIN = {"fiber_layernorm_bwd_grid": [I], "fiber_window_attn_bwd_slices": [I, I]}
+
+_lib = None
+
+
+class FiberHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libfiber_hip.so and declare every prototype.  Raises if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise FiberHipError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "or `make -C fiber_amd/csrc` (there is no fallback path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args + [P]
+        fn.restype = I
+    for name, args in PLAIN.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = I
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return list(SIGNATURES) + list(PLAIN)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses anything that is not contiguous HIP memory."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise FiberHipError("fiber_amd ops need HIP device tensors (no CPU fallback)")
+    return t.data_ptr()
+
+
+def call(name, *args):
+    lib = load()
+    stream = torch.cuda.current_stream().cuda_stream
+    rc = getattr(lib, name)(*args, stream)
+    if rc != 0:
+        raise FiberHipError(f"{name} failed with code {rc} ({ {1: 'invalid argument', 2: 'launch failure'}.get(rc, '?')})")
+
+
+def plain(name, *args):
+    return getattr(load(), name)(*args)

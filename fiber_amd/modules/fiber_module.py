@@ -1,0 +1,220 @@
+"""FIBERTransformerSS -- the drop-in boundary of the coarse-grained path, MI355X-native.
+
+Mirrors coarse_grained/fiber/modules/fiber_module.py: constructor wiring (:27-179), infer() (:224-367, fused branch
+:310-367, image-only :279-308, text-only :247-277), forward() (:431-471), training_step (:473-478),
+configure_optimizers (:522).  Parameter names / shapes equal the reference's so a `fiber_pretrain.ckpt` state dict loads
+(`load_path`, ITC queue keys dropped as at :141-146).  Captioning / ITC-queue / VQA-test code is out of scope (SURVEY.md
+section 2) and raises if requested.
+"""
+import types
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..lightning import LightningModule
+from . import fiber_utils, heads, objectives, roberta, swin_transformer
+from .roberta import RobertaModel
+
+
+class FIBERTransformerSS(LightningModule):
+    def __init__(self, config):
+        super().__init__()
+        self.save_hyperparameters()
+        self.config = config
+        ln = config["loss_names"]
+        for k in ("itc", "caption_mle", "caption_gold", "caption_cider", "nlvr2"):
+            if ln.get(k, 0) > 0:
+                raise NotImplementedError(f"loss '{k}' is outside the fused-backbone hot path built here")
+
+        bert_config = types.SimpleNamespace(        # RobertaConfig defaults: layer_norm_eps = 1e-12
+            vocab_size=config["vocab_size"], hidden_size=config["hidden_size"], layer_norm_eps=1e-12)
+
+        self.num_fuse_block = config["num_fuse_block"]
+        self.num_text_layer = config["num_layers"]
+        roberta.NUM_FUSE_BLOCK = swin_transformer.NUM_FUSE_BLOCK = self.num_fuse_block
+        roberta.DIM_IMG = config["input_image_embed_size"]
+        swin_transformer.DIM_TXT = config["input_text_embed_size"]      # reference typo kept: DIM_TEXT stays at its default
+        swin_transformer.DIM_TEXT = config.get("swin_dim_text", 768)   # test-only knob for shrunken configs
+
+        hs = config["hidden_size"]
+        self.cross_modal_text_transform = nn.Linear(config["input_text_embed_size"], hs)
+        self.cross_modal_image_transform = nn.Linear(config["input_image_embed_size"], hs)
+        self.cross_modal_text_transform_itc = nn.Linear(config["input_text_embed_size"], hs)
+        self.cross_modal_image_transform_itc = nn.Linear(config["input_image_embed_size"], hs)
+        for m in (self.cross_modal_text_transform, self.cross_modal_image_transform,
+                  self.cross_modal_text_transform_itc, self.cross_modal_image_transform_itc):
+            m.apply(objectives.init_weights)
+
+        if "swin_arch" in config:                                        # test-only: explicit (embed_dim, depths, heads)
+            dim, depths, nh = config["swin_arch"]
+            self.vit_model = swin_transformer.SwinTransformer(img_size=config["image_size"], embed_dim=dim, depths=depths,
+                                                              num_heads=nh, drop_path_rate=config.get("drop_path_rate", 0.1))
+        else:
+            kw = {"drop_path_rate": config["drop_path_rate"]} if "drop_path_rate" in config else {}
+            self.vit_model = getattr(swin_transformer, config["vit"])(pretrained=config["pretrained_vit"], config=config, **kw)
+        self.avgpool = nn.AdaptiveAvgPool1d(1)
+        tover = {}
+        if config["input_text_embed_size"] != 768 or config["num_layers"] != 12 or config["vocab_size"] != 50265:
+            tover = dict(hidden_size=config["input_text_embed_size"], num_hidden_layers=config["num_layers"],
+                         num_attention_heads=config["num_heads"], vocab_size=config["vocab_size"],
+                         intermediate_size=config["input_text_embed_size"] * config["mlp_ratio"])
+        if "max_position_embeddings" in config:
+            tover["max_position_embeddings"] = config["max_position_embeddings"]
+        if "text_dropout" in config:
+            tover.update(hidden_dropout_prob=config["text_dropout"], attention_probs_dropout_prob=config["text_dropout"])
+        self.text_transformer = RobertaModel.from_pretrained(config["tokenizer"], **tover)
+
+        self.cross_modal_image_pooler = heads.Pooler(hs)
+        self.cross_modal_text_pooler = heads.Pooler(hs)
+        self.cross_modal_image_pooler.apply(objectives.init_weights)
+        self.cross_modal_text_pooler.apply(objectives.init_weights)
+        self.itc_pooler = config["itc_pooler"]
+        if self.itc_pooler:
+            self.cross_modal_image_pooler_itc = heads.Pooler(hs)
+            self.cross_modal_text_pooler_itc = heads.Pooler(hs)
+            self.cross_modal_image_pooler_itc.apply(objectives.init_weights)
+            self.cross_modal_text_pooler_itc.apply(objectives.init_weights)
+
+        if ln.get("mlm", 0) > 0:
+            self.mlm_score = heads.MLMHead(bert_config)
+            self.mlm_score.apply(objectives.init_weights)
+        if ln.get("itm", 0) > 0:
+            self.itm_score = heads.ITMHead(hs * 2)
+            self.itm_score.apply(objectives.init_weights)
+            self.rank_output = nn.Linear(hs, 1)
+            self.rank_output.weight.data = self.itm_score.fc.weight.data[1:, :]
+            self.rank_output.bias.data = self.itm_score.fc.bias.data[1:]
+
+        if config["load_path"] != "":
+            ckpt = torch.load(config["load_path"], map_location="cpu")
+            state_dict = ckpt["state_dict"]
+            for key in ["image_queue", "text_queue", "queue_ptr", "queue_total", "image_input_queue", "text_input_queue",
+                        "text_input_mask_queue"]:
+                state_dict.pop(key, None)
+            self.load_state_dict(state_dict, strict=False)
+
+        if ln.get("vqa", 0) > 0:
+            vs = config["vqav2_label_size"]
+            self.vqa_classifier = nn.Sequential(nn.Linear(hs * 2, hs * 2), nn.LayerNorm(hs * 2), nn.GELU(), nn.Linear(hs * 2, vs))
+            self.vqa_classifier.apply(objectives.init_weights)
+
+        fiber_utils.set_metrics(self)
+        self.current_tasks = list()
+
+    # parameters that never receive a gradient on the fused MLM+ITM path (SURVEY.md section 7 "DDP unused parameters")
+    def unused_parameter_names(self):
+        names = []
+        for n, _ in self.named_parameters():
+            if (n.startswith("vit_model.norm.") or n.startswith("text_transformer.pooler.") or "_itc." in n
+                    or n.startswith("rank_output.") or ("crossattention_t2i.output.LayerNorm" in n)):
+                names.append(n)
+        stage2 = self.vit_model.layers[2].blocks
+        if len(stage2) < 8 + self.num_text_layer - self.num_fuse_block + 1:      # Swin-T quirk: text layers 6..9 never run
+            for i in range(self.num_text_layer - self.num_fuse_block, 10):
+                names += [n for n, _ in self.named_parameters() if n.startswith(f"text_transformer.encoder.layer.{i}.")]
+            names += [n for n, _ in self.named_parameters()
+                      if n.startswith("vit_model.layers.2.") and ("i2t" in n)]
+        # alpha_t2i of layers without cross-attention is created but unused
+        for i in range(self.num_text_layer):
+            lyr = self.text_transformer.encoder.layer[i]
+            if not hasattr(lyr, "crossattention_t2i") or f"text_transformer.encoder.layer.{i}.alpha_t2i" in names:
+                names.append(f"text_transformer.encoder.layer.{i}.alpha_t2i")
+        return sorted(set(names))
+
+    def infer(self, batch, mask_text=False, mask_image=False, image_token_type_idx=1, img=None, text_only=False,
+              image_only=False):
+        if not text_only and img is None:
+            imgkey = f"image_{image_token_type_idx - 1}" if f"image_{image_token_type_idx - 1}" in batch else "image"
+            img = batch[imgkey][0]
+        if not image_only:
+            do_mlm = "_mlm" if mask_text else ""
+            text_ids, text_labels, text_masks = batch[f"text_ids{do_mlm}"], batch[f"text_labels{do_mlm}"], batch["text_masks"]
+        vit, txt = self.vit_model, self.text_transformer
+
+        if text_only:
+            text_embeds = txt.embeddings(input_ids=text_ids)
+            ext = txt.get_extended_attention_mask(text_masks, text_masks.size(), text_embeds.device)
+            for layer in txt.encoder.layer:
+                text_embeds = layer(text_embeds, ext)[0]
+            text_embeds = ops.linear(text_embeds, self.cross_modal_text_transform_itc.weight, self.cross_modal_text_transform_itc.bias)
+            cls = self.cross_modal_text_pooler_itc(text_embeds) if self.itc_pooler else text_embeds[:, 0]
+            cls = cls / cls.norm(dim=-1, keepdim=True)
+            return {"text_feats": text_embeds, "image_feats": None, "cls_feats": cls, "text_labels": text_labels,
+                    "text_ids": text_ids, "text_masks": text_masks, "image": None}
+
+        if image_only:
+            x = vit.patch_embed(img)
+            for layer in vit.layers:
+                x = layer(x)
+            x = ops.layernorm(x, vit.norm.weight, vit.norm.bias, vit.norm.eps)
+            x = ops.linear(x, self.cross_modal_image_transform_itc.weight, self.cross_modal_image_transform_itc.bias)
+            avg = x.float().mean(1, keepdim=True)
+            cls = self.cross_modal_image_pooler_itc(avg) if self.itc_pooler else avg[:, 0]
+            cls = cls / cls.norm(dim=-1, keepdim=True)
+            return {"text_feats": None, "image_feats": x, "cls_feats": cls, "text_labels": None, "text_ids": None,
+                    "text_masks": None, "image": None}
+
+        # ---- fused branch (fiber_module.py:310-367) ------------------------------------------------------------
+        image_embeds = vit.patch_embed(img)
+        for layer in vit.layers[:2]:
+            image_embeds = layer(image_embeds)
+
+        text_embeds = txt.embeddings(input_ids=text_ids)
+        ext = txt.get_extended_attention_mask(text_masks, text_masks.size(), text_embeds.device)
+        num_pre_text = self.num_text_layer - self.num_fuse_block
+        for layer in txt.encoder.layer[:num_pre_text]:
+            text_embeds = layer(text_embeds, ext)[0]
+
+        num_pre_block = 8 + num_pre_text
+        for blk_cnt, blk in enumerate(vit.layers[2].blocks):
+            if blk_cnt < num_pre_block:
+                image_embeds = blk(image_embeds)
+            else:
+                fuse_image_embeds = blk(image_embeds, text_embeds, ext)
+                text_embeds = txt.encoder.layer[blk_cnt - 8](text_embeds, ext, encoder_hidden_states=image_embeds)[0]
+                image_embeds = fuse_image_embeds
+        if vit.layers[2].downsample is not None:
+            image_embeds = vit.layers[2].downsample(image_embeds)
+
+        for blk_cnt, blk in enumerate(vit.layers[3].blocks):
+            fuse_image_embeds = blk(image_embeds, text_embeds, ext)
+            text_embeds = txt.encoder.layer[blk_cnt + 10](text_embeds, ext, encoder_hidden_states=image_embeds,
+                                                          last_norm=(blk_cnt == 0))[0]
+            image_embeds = fuse_image_embeds
+        if vit.layers[3].downsample is not None:
+            image_embeds = vit.layers[3].downsample(image_embeds)
+
+        text_embeds = ops.linear(text_embeds, self.cross_modal_text_transform.weight, self.cross_modal_text_transform.bias)
+        image_embeds = ops.linear(image_embeds, self.cross_modal_image_transform.weight, self.cross_modal_image_transform.bias)
+        cls_feats_text = self.cross_modal_text_pooler(text_embeds)
+        avg_image_feats = image_embeds.float().mean(1, keepdim=True)
+        cls_feats_image = self.cross_modal_image_pooler(avg_image_feats)
+        cls_feats = torch.cat([cls_feats_text, cls_feats_image], dim=-1)
+        return {"text_feats": text_embeds, "image_feats": image_embeds, "cls_feats": cls_feats, "text_labels": text_labels,
+                "text_ids": text_ids, "text_masks": text_masks, "image": img}
+
+    def forward(self, batch):
+        ret = dict()
+        if len(self.current_tasks) == 0:
+            ret.update(self.infer(batch))
+            return ret
+        if "mlm" in self.current_tasks:
+            ret.update(objectives.compute_mlm(self, batch))
+        if "itm" in self.current_tasks:
+            ret.update(objectives.compute_itm(self, batch, batch.get("itm_labels_override")))
+        if "vqa" in self.current_tasks:
+            raise NotImplementedError("VQA fine-tune head is SURVEY.md section 8(f) 'next'")
+        return ret
+
+    def training_step(self, batch, batch_idx):
+        fiber_utils.set_task(self)
+        output = self(batch)
+        return sum([v for k, v in output.items() if "loss" in k])
+
+    def validation_step(self, batch, batch_idx):
+        fiber_utils.set_task(self)
+        return self(batch)
+
+    def configure_optimizers(self):
+        return fiber_utils.set_schedule(self)

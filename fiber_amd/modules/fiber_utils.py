@@ -1,0 +1,113 @@
+"""set_metrics / set_task / set_schedule for the metric path (reference coarse_grained/fiber/modules/fiber_utils.py:14-41,
+151-287; coarse_grained/fiber/gadgets/my_metrics.py).  AdamW and the polynomial-decay-with-warmup schedule restate
+transformers==4.6.0 (`AdamW(correct_bias=True)`: decoupled weight decay, eps 1e-8, betas (0.9, 0.98);
+`get_polynomial_decay_schedule_with_warmup`)."""
+import math
+
+import torch
+
+
+class _Running:
+    """Stand-in for pytorch_lightning.metrics.Metric (my_metrics.py): running value, callable, compute()/reset()."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.num, self.den = 0.0, 0.0
+
+    def compute(self):
+        return torch.tensor(self.num / max(self.den, 1e-12))
+
+
+class Scalar(_Running):
+    def __call__(self, scalar):
+        self.last = scalar.detach() if isinstance(scalar, torch.Tensor) else torch.tensor(float(scalar))
+        return self.last                      # accumulated lazily: no host sync on the hot path
+
+    def compute(self):
+        return self.last
+
+
+class Accuracy(_Running):
+    def __call__(self, logits, target):
+        with torch.no_grad():
+            preds = logits.detach().argmax(dim=-1)
+            tgt = target.detach().to(preds.device)
+            valid = tgt != -100
+            correct = ((preds == tgt) & valid).sum().float()
+            self.last = correct / valid.sum().clamp(min=1).float()
+        return self.last
+
+    def compute(self):
+        return self.last
+
+
+def set_metrics(pl_module):
+    for split in ["train", "val"]:
+        for k, v in pl_module.hparams.config["loss_names"].items():
+            if v <= 0:
+                continue
+            setattr(pl_module, f"{split}_{k}_accuracy", Accuracy())
+            setattr(pl_module, f"{split}_{k}_loss", Scalar())
+
+
+def set_task(pl_module):
+    pl_module.current_tasks = [k for k, v in pl_module.hparams.config["loss_names"].items() if v > 0]
+
+
+NO_DECAY = ["bias", "LayerNorm.bias", "LayerNorm.weight", "norm.bias", "norm.weight", "norm1.bias", "norm1.weight",
+            "norm2.bias", "norm2.weight"]
+HEAD_NAMES = ["vqa_classifier", "nlvr2_classifier", "mlm_score", "itm_score", "snli_classifier"]
+CROSS_MODAL_NAMES = ["cross_modal", "i2t", "t2i"]
+
+
+def param_group_index(name):
+    """0..5: (plain|head|cross_modal) x (decay|no_decay) in the reference's order (fiber_utils.py:179-245)."""
+    nd = any(s in name for s in NO_DECAY)
+    head = any(s in name for s in HEAD_NAMES)
+    cross = any(s in name for s in CROSS_MODAL_NAMES)
+    if head and cross:
+        return None                           # matches no reference group -> not optimised (as in the reference)
+    return (4 if cross else (2 if head else 0)) + (1 if nd else 0)
+
+
+def poly_decay_lambda(step, warmup, total, lr_init, lr_end, power):
+    if step < warmup:
+        return float(step) / float(max(1, warmup))
+    if step > total:
+        return lr_end / lr_init
+    rem = 1 - (step - warmup) / (total - warmup)
+    return ((lr_init - lr_end) * rem ** power + lr_end) / lr_init
+
+
+def set_schedule(pl_module):
+    cfg = pl_module.hparams.config
+    lr, wd = cfg["learning_rate"], cfg["weight_decay"]
+    mult = [1, 1, cfg["lr_mult_head"], cfg["lr_mult_head"], cfg["lr_mult_cross_modal"], cfg["lr_mult_cross_modal"]]
+    groups = [{"params": [], "weight_decay": wd if i % 2 == 0 else 0.0, "lr": lr * mult[i]} for i in range(6)]
+    for n, p in pl_module.named_parameters():
+        gi = param_group_index(n)
+        if gi is not None and p.requires_grad:
+            groups[gi]["params"].append(p)
+    if cfg["optim_type"] == "adamw":
+        optimizer = torch.optim.AdamW(groups, lr=lr, eps=1e-8, betas=(0.9, 0.98))
+    elif cfg["optim_type"] == "adam":
+        optimizer = torch.optim.Adam(groups, lr=lr)
+    else:
+        optimizer = torch.optim.SGD(groups, lr=lr, momentum=0.9)
+    tr = getattr(pl_module, "trainer", None)
+    max_steps = getattr(tr, "max_steps", None) if tr is not None else None
+    if max_steps is None:
+        max_steps = cfg["max_steps"]
+    warmup = cfg["warmup_steps"]
+    if isinstance(warmup, float):
+        warmup = int(max_steps * warmup)
+    if cfg["decay_power"] == "cosine":
+        lam = lambda s: s / max(1, warmup) if s < warmup else max(0.0, 0.5 * (1 + math.cos(math.pi * (s - warmup) / max(1, max_steps - warmup))))
+        scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lam)
+    else:
+        # HF uses optimizer.defaults["lr"] (the base lr) as lr_init for every group
+        lam = lambda s: poly_decay_lambda(s, warmup, max_steps, lr, cfg["end_lr"], cfg["decay_power"])
+        scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lam)
+    return [optimizer], [{"scheduler": scheduler, "interval": "step"}]

@@ -1,0 +1,57 @@
+"""Pooler / ITMHead / MLMHead with the reference's parameter names (coarse_grained/fiber/modules/heads.py:8-43).
+
+Small caller-side GEMMs: the 768x768 dense layers use the HIP GEMM; the 2-way ITM classifier and the 50265-way
+vocabulary decoder are plain library GEMMs ("keep on library GEMM").
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+
+class Pooler(nn.Module):
+    def __init__(self, hidden_size):
+        super().__init__()
+        self.dense = nn.Linear(hidden_size, hidden_size)
+        self.activation = nn.Tanh()
+
+    def forward(self, hidden_states):
+        first = hidden_states[:, 0].contiguous()
+        return torch.tanh(ops.linear(first.to(torch.bfloat16), self.dense.weight, self.dense.bias))
+
+
+class ITMHead(nn.Module):
+    def __init__(self, hidden_size):
+        super().__init__()
+        self.fc = nn.Linear(hidden_size, 2)
+
+    def forward(self, x):
+        return F.linear(x.float(), self.fc.weight, self.fc.bias)
+
+
+class BertPredictionHeadTransform(nn.Module):
+    """transformers==4.6.0 BertPredictionHeadTransform: dense -> gelu(erf) -> LayerNorm(eps from config)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+
+    def forward(self, x):
+        h = ops.linear(x, self.dense.weight, self.dense.bias, act="gelu")
+        return ops.layernorm(h, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
+
+
+class MLMHead(nn.Module):
+    def __init__(self, config, weight=None):
+        super().__init__()
+        self.transform = BertPredictionHeadTransform(config)
+        self.decoder = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+        self.bias = nn.Parameter(torch.zeros(config.vocab_size))
+        if weight is not None:
+            self.decoder.weight = weight
+
+    def forward(self, x):
+        h = self.transform(x)
+        return F.linear(h, ops.cast_bf16(self.decoder.weight), ops.cast_bf16(self.bias))

@@ -1,0 +1,56 @@
+"""Loss functions on the metric path: compute_mlm / compute_itm / init_weights
+(reference coarse_grained/fiber/modules/objectives.py:17-75, 502-510).  Same call signatures and return keys."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def compute_mlm(pl_module, batch):
+    infer = pl_module.infer(batch, mask_text=True, mask_image=False)
+    mlm_logits = pl_module.mlm_score(infer["text_feats"])
+    mlm_labels = infer["text_labels"]
+    mlm_loss = F.cross_entropy(
+        mlm_logits.view(-1, pl_module.hparams.config["vocab_size"]).float(), mlm_labels.view(-1), ignore_index=-100)
+    ret = {"mlm_loss": mlm_loss, "mlm_logits": mlm_logits, "mlm_labels": mlm_labels, "mlm_ids": infer["text_ids"]}
+    phase = "train" if pl_module.training else "val"
+    loss = getattr(pl_module, f"{phase}_mlm_loss")(ret["mlm_loss"])
+    acc = getattr(pl_module, f"{phase}_mlm_accuracy")(ret["mlm_logits"], ret["mlm_labels"])
+    pl_module.log(f"mlm/{phase}/loss", loss)
+    pl_module.log(f"mlm/{phase}/accuracy", acc)
+    return ret
+
+
+def compute_itm(pl_module, batch, itm_labels=None):
+    """`itm_labels` (optional) pins the true/false permutation for parity tests; by default it is drawn with
+    torch.randperm exactly as the reference does (objectives.py:47-48)."""
+    pos_len = len(batch["text"]) // 2
+    neg_len = len(batch["text"]) - pos_len
+    if itm_labels is None:
+        itm_labels = torch.cat([torch.ones(pos_len), torch.zeros(neg_len)]).to(pl_module.device)
+        itm_labels = itm_labels[torch.randperm(itm_labels.size(0))]
+    else:
+        itm_labels = itm_labels.to(pl_module.device).float()
+    sel = itm_labels.view(-1, 1, 1, 1) == 1
+    itm_images = [torch.where(sel, bti, bfi) for bti, bfi in zip(batch["image"], batch["false_image_0"])]
+    batch = {k: v for k, v in batch.items()}
+    batch["image"] = itm_images
+    infer = pl_module.infer(batch, mask_text=False, mask_image=False)
+    itm_logits = pl_module.itm_score(infer["cls_feats"])
+    itm_loss = F.cross_entropy(itm_logits, itm_labels.long())
+    ret = {"itm_loss": itm_loss, "itm_logits": itm_logits, "itm_labels": itm_labels}
+    phase = "train" if pl_module.training else "val"
+    loss = getattr(pl_module, f"{phase}_itm_loss")(ret["itm_loss"])
+    acc = getattr(pl_module, f"{phase}_itm_accuracy")(ret["itm_logits"], ret["itm_labels"])
+    pl_module.log(f"itm/{phase}/loss", loss)
+    pl_module.log(f"itm/{phase}/accuracy", acc)
+    return ret
+
+
+def init_weights(module):
+    if isinstance(module, (nn.Linear, nn.Embedding)):
+        module.weight.data.normal_(mean=0.0, std=0.02)
+    elif isinstance(module, nn.LayerNorm):
+        module.bias.data.zero_()
+        module.weight.data.fill_(1.0)
+    if isinstance(module, nn.Linear) and module.bias is not None:
+        module.bias.data.zero_()

@@ -1,0 +1,426 @@
+"""Autograd wrappers around the fiber_hip C ABI (fiber_amd/lib.py).
+
+Activations are bf16, parameters stay fp32 masters (state-dict compatible with the reference); each op casts the
+weights it needs to bf16 once per parameter version.  Forward GEMMs with fused epilogues, LayerNorm, all attention
+cores, embeddings and the element-wise glue are hand-written HIP kernels.  The plain backward GEMMs (dX = dY.W,
+dW = dY^T.X -- no epilogue to fuse) go through torch.matmul, i.e. hipBLASLt/rocBLAS on the same device and stream.
+Nothing here runs on the CPU: tensors must live on a HIP device.
+"""
+import math
+
+import torch
+
+from . import lib
+
+BF16 = torch.bfloat16
+_wcache = {}
+
+
+def bf16_weight(w):
+    """bf16 copy of an fp32 parameter, refreshed when the parameter's version counter changes."""
+    key = id(w)
+    hit = _wcache.get(key)
+    if hit is not None and hit[0] == w._version and hit[2] is w:
+        return hit[1]
+    wb = w.detach().to(BF16).contiguous()
+    _wcache[key] = (w._version, wb, w)
+    return wb
+
+
+def cast_bf16(w):
+    """Autograd-visible bf16 view of an fp32 parameter for library GEMMs (gradient flows back in fp32)."""
+    return w.to(BF16)
+
+
+def clear_weight_cache():
+    _wcache.clear()
+
+
+def _rows(x):
+    return x.numel() // x.shape[-1]
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def gemm_nt(x2, wb, bias=None, residual=None, act=0, want_pre=False):
+    """y = act(x2 @ wb^T + bias) + residual  on the HIP kernel.  x2 [M,K] bf16 (row stride may exceed K)."""
+    M, K = x2.shape
+    N = wb.shape[0]
+    assert x2.dtype == BF16 and wb.dtype == BF16 and x2.stride(1) == 1 and wb.stride(1) == 1
+    y = torch.empty((M, N), dtype=BF16, device=x2.device)
+    pre = torch.empty((M, N), dtype=BF16, device=x2.device) if (want_pre and act) else None
+    lib.call("fiber_gemm_nt_bf16", lib.ptr(x2), lib.ptr(wb), lib.ptr(bias), lib.ptr(residual), lib.ptr(y), lib.ptr(pre),
+             M, N, K, x2.stride(0), wb.stride(0), N, residual.stride(0) if residual is not None else 0, act)
+    return y, pre
+
+
+def colsum(x2):
+    out = torch.zeros(x2.shape[1], dtype=torch.float32, device=x2.device)
+    lib.call("fiber_colsum_bf16", lib.ptr(x2), lib.ptr(out), x2.shape[0], x2.shape[1], x2.stride(0))
+    return out
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, act):
+        shp = x.shape
+        x2 = _c(x).view(-1, shp[-1])
+        wb = bf16_weight(weight)
+        r2 = _c(residual).view(-1, weight.shape[0]) if residual is not None else None
+        need_pre = bool(act) and any(ctx.needs_input_grad[:3])
+        y, pre = gemm_nt(x2, wb, bias, r2, act, need_pre)
+        ctx.save_for_backward(x2, weight, pre)
+        ctx.act, ctx.has_bias, ctx.has_res, ctx.shp = act, bias is not None, residual is not None, shp
+        return y.view(*shp[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, pre = ctx.saved_tensors
+        dy2 = _c(dy).view(-1, weight.shape[0])
+        dres = dy if ctx.has_res else None
+        if ctx.act:
+            dh = torch.empty_like(dy2)
+            lib.call("fiber_gelu_bwd_bf16", lib.ptr(dy2), lib.ptr(pre), lib.ptr(dh), dy2.numel())
+        else:
+            dh = dy2
+        wb = bf16_weight(weight)
+        dx = torch.matmul(dh, wb).view(ctx.shp) if ctx.needs_input_grad[0] else None
+        dw = torch.matmul(dh.t(), x2).float() if ctx.needs_input_grad[1] else None
+        db = colsum(dh) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, dres, None
+
+
+def linear(x, weight, bias=None, residual=None, act=None):
+    """nn.Linear with fused bias / exact GELU / residual.  Falls back to a library GEMM only for shapes the tile
+    kernel does not cover (N % 4 != 0, e.g. the 2-way ITM head, or K % 8 != 0)."""
+    N, K = weight.shape
+    if (N % 4) or (K % 8):
+        y = torch.nn.functional.linear(x, weight.to(BF16), bias.to(BF16) if bias is not None else None)
+        if act:
+            y = torch.nn.functional.gelu(y)
+        return y + residual if residual is not None else y
+    return _Linear.apply(x, weight, bias, residual, 1 if act else 0)
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        C = x.shape[-1]
+        x2 = _c(x).view(-1, C)
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        lib.call("fiber_layernorm_fwd_bf16", lib.ptr(x2), lib.ptr(gamma), lib.ptr(beta), lib.ptr(y), lib.ptr(mean), lib.ptr(rstd), rows, C, eps)
+        ctx.save_for_backward(x2, gamma, mean, rstd)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, gamma, mean, rstd = ctx.saved_tensors
+        rows, C = x2.shape
+        dy2 = _c(dy).view(rows, C)
+        dx = torch.empty_like(x2)
+        dg = torch.empty(C, dtype=torch.float32, device=dy.device)
+        db = torch.empty_like(dg)
+        ws = torch.empty(lib.plain("fiber_layernorm_bwd_grid", rows) * 8 * C, dtype=torch.float32, device=dy.device)
+        lib.call("fiber_layernorm_bwd_bf16", lib.ptr(dy2), lib.ptr(x2), lib.ptr(gamma), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dx),
+                 lib.ptr(dg), lib.ptr(db), lib.ptr(ws), rows, C)
+        return dx.view(dy.shape), dg, db, None
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    return _LayerNorm.apply(x, gamma, beta, eps)
+
+
+class _PatchMergeLN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, H, W, eps):
+        B, L, C = x.shape
+        x = _c(x)
+        rows = B * (H // 2) * (W // 2)
+        y = torch.empty((B, rows // B, 4 * C), dtype=BF16, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        lib.call("fiber_patch_merge_ln_fwd_bf16", lib.ptr(x), lib.ptr(gamma), lib.ptr(beta), lib.ptr(y), lib.ptr(mean), lib.ptr(rstd), B, H, W, C, eps)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.dims = (B, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        B, H, W, C = ctx.dims
+        rows = B * (H // 2) * (W // 2)
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        dg = torch.empty(4 * C, dtype=torch.float32, device=dy.device)
+        db = torch.empty_like(dg)
+        ws = torch.empty(lib.plain("fiber_layernorm_bwd_grid", rows) * 8 * 4 * C, dtype=torch.float32, device=dy.device)
+        lib.call("fiber_patch_merge_ln_bwd_bf16", lib.ptr(dy), lib.ptr(x), lib.ptr(gamma), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dx),
+                 lib.ptr(dg), lib.ptr(db), lib.ptr(ws), B, H, W, C)
+        return dx, dg, db, None, None, None
+
+
+def patch_merge_ln(x, gamma, beta, H, W, eps=1e-5):
+    return _PatchMergeLN.apply(x, gamma, beta, H, W, eps)
+
+
+class _WindowAttn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, bias_table, B, H, W, heads, ws, shift):
+        C = qkv.shape[-1] // 3
+        qkv = _c(qkv)
+        rows = B * H * W
+        o = torch.empty((rows, C), dtype=BF16, device=qkv.device)
+        lse = torch.empty((rows, heads), dtype=torch.float32, device=qkv.device)
+        lib.call("fiber_window_attn_fwd_bf16", lib.ptr(qkv), lib.ptr(bias_table), lib.ptr(o), lib.ptr(lse), B, H, W, C, heads, ws, shift)
+        ctx.save_for_backward(qkv, bias_table, o, lse)
+        ctx.dims = (B, H, W, C, heads, ws, shift)
+        return o.view(B, H * W, C)
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, bias_table, o, lse = ctx.saved_tensors
+        B, H, W, C, heads, ws, shift = ctx.dims
+        do = _c(do)
+        rows, N = B * H * W, ws * ws
+        dqkv = torch.empty_like(qkv)
+        dtab = torch.empty_like(bias_table)
+        delta = torch.empty((rows, heads), dtype=torch.float32, device=do.device)
+        nz = lib.plain("fiber_window_attn_bwd_slices", rows // N, heads)
+        part = torch.empty(nz * heads * N * N, dtype=torch.float32, device=do.device)
+        lib.call("fiber_window_attn_bwd_bf16", lib.ptr(qkv), lib.ptr(bias_table), lib.ptr(o), lib.ptr(do), lib.ptr(lse), lib.ptr(dqkv),
+                 lib.ptr(dtab), lib.ptr(delta), lib.ptr(part), B, H, W, C, heads, ws, shift)
+        return dqkv, dtab, None, None, None, None, None, None
+
+
+def window_attention(qkv, bias_table, B, H, W, heads, ws, shift):
+    """qkv [B, H*W, 3C] in image-token order -> attention output [B, H*W, C] (shift/partition/reverse folded in)."""
+    return _WindowAttn.apply(qkv, bias_table, B, H, W, heads, ws, shift)
+
+
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1
+    return t.stride(0)
+
+
+class _MHA(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, kmask, B, heads, scale, p_drop, seed):
+        # q [B*Lq, heads*D], k/v [B*Lk, heads*D] (possibly column views of a packed projection)
+        D = q.shape[1] // heads
+        Lq, Lk = q.shape[0] // B, k.shape[0] // B
+        o = torch.empty((q.shape[0], heads * D), dtype=BF16, device=q.device)
+        lse = torch.empty((q.shape[0], heads), dtype=torch.float32, device=q.device)
+        lib.call("fiber_mha_fwd_bf16", lib.ptr(q), lib.ptr(k), lib.ptr(v), lib.ptr(kmask), lib.ptr(o), lib.ptr(lse), B, heads, Lq, Lk, D,
+                 _ld(q), _ld(k), _ld(v), _ld(o), scale, p_drop, seed)
+        ctx.save_for_backward(q, k, v, kmask, o, lse)
+        ctx.cfg = (B, heads, Lq, Lk, D, scale, p_drop, seed)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, kmask, o, lse = ctx.saved_tensors
+        B, heads, Lq, Lk, D, scale, p_drop, seed = ctx.cfg
+        do = _c(do)
+        dq = torch.empty((q.shape[0], heads * D), dtype=BF16, device=q.device)
+        dk = torch.empty((k.shape[0], heads * D), dtype=BF16, device=q.device)
+        dv = torch.empty_like(dk)
+        delta = torch.empty((q.shape[0], heads), dtype=torch.float32, device=q.device)
+        lib.call("fiber_mha_bwd_bf16", lib.ptr(q), lib.ptr(k), lib.ptr(v), lib.ptr(kmask), lib.ptr(o), lib.ptr(do), lib.ptr(lse),
+                 lib.ptr(dq), lib.ptr(dk), lib.ptr(dv), lib.ptr(delta), B, heads, Lq, Lk, D, _ld(q), _ld(k), _ld(v), _ld(o), _ld(do),
+                 _ld(dq), _ld(dk), _ld(dv), scale, p_drop, seed)
+        return dq, dk, dv, None, None, None, None, None, None
+
+
+def mha(q, k, v, kmask, B, heads, scale, p_drop=0.0, seed=0):
+    """softmax(q.k^T*scale + kmask).v per (sample, head); q/k/v are 2-D [B*L, heads*D] bf16, kmask fp32 [B, Lk] or None."""
+    if kmask is not None:
+        kmask = _c(kmask.view(B, -1).float())
+    return _MHA.apply(q, k, v, kmask, B, heads, float(scale), float(p_drop), int(seed))
+
+
+class _ScaleAdd(torch.autograd.Function):
+    """out = a + alpha * b with a learnable scalar alpha (alpha_i2t / alpha_t2i)."""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        a, b = _c(a), _c(b)
+        out = torch.empty_like(a)
+        lib.call("fiber_scale_add_bf16", lib.ptr(a), lib.ptr(b), lib.ptr(alpha), 1.0, lib.ptr(out), a.numel())
+        ctx.save_for_backward(b, alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        b, alpha = ctx.saved_tensors
+        dout = _c(dout)
+        db = torch.empty_like(b)
+        lib.call("fiber_scale_add_bf16", None, lib.ptr(dout), lib.ptr(alpha), 1.0, lib.ptr(db), dout.numel())
+        dalpha = torch.zeros(1, dtype=torch.float32, device=dout.device)
+        lib.call("fiber_dot_bf16", lib.ptr(dout), lib.ptr(b), lib.ptr(dalpha), dout.numel())
+        return dout, db, dalpha
+
+
+def scale_add(a, b, alpha):
+    return _ScaleAdd.apply(a, b, alpha)
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        out = torch.empty_like(a)
+        lib.call("fiber_scale_add_bf16", lib.ptr(a), lib.ptr(b), None, 1.0, lib.ptr(out), a.numel())
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        return dout, dout
+
+
+def add(a, b):
+    """Residual add of two same-shape bf16 tensors."""
+    return _Add.apply(a, b)
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = _c(x)
+        y = torch.empty_like(x)
+        lib.call("fiber_dropout_bf16", lib.ptr(x), lib.ptr(y), x.numel(), p, seed)
+        ctx.cfg = (p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        lib.call("fiber_dropout_bf16", lib.ptr(dy), lib.ptr(dx), dy.numel(), *ctx.cfg)
+        return dx, None, None
+
+
+_seed_state = {"seed": 0x5EED, "ctr": 0}
+
+
+def manual_seed(seed):
+    _seed_state["seed"], _seed_state["ctr"] = int(seed) & 0xFFFFFFFF, 0
+
+
+def next_seed():
+    """A fresh 64-bit dropout key per call site (counter-based: forward and backward share it through ctx)."""
+    _seed_state["ctr"] += 1
+    return (_seed_state["seed"] << 32) | (_seed_state["ctr"] & 0xFFFFFFFF)
+
+
+def dropout(x, p, training):
+    if not training or p <= 0.0:
+        return x
+    return _Dropout.apply(x, float(p), next_seed())
+
+
+class _RowScaleAdd(torch.autograd.Function):
+    """out = resid + scale[b] * x  (per-sample DropPath on a residual branch)."""
+
+    @staticmethod
+    def forward(ctx, resid, x, scale):
+        resid, x = _c(resid), _c(x)
+        out = torch.empty_like(x)
+        per = x.numel() // x.shape[0]
+        lib.call("fiber_rowscale_add_bf16", lib.ptr(resid), lib.ptr(x), lib.ptr(scale), lib.ptr(out), x.numel(), per)
+        ctx.save_for_backward(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (scale,) = ctx.saved_tensors
+        dout = _c(dout)
+        dx = torch.empty_like(dout)
+        per = dout.numel() // dout.shape[0]
+        lib.call("fiber_rowscale_add_bf16", None, lib.ptr(dout), lib.ptr(scale), lib.ptr(dx), dout.numel(), per)
+        return dout, dx, None
+
+
+def drop_path_add(resid, x, p, training):
+    """resid + DropPath_p(x): timm 0.4.12 per-sample mask floor(keep + U[0,1)) scaled by 1/keep."""
+    if not training or p <= 0.0:
+        return resid + x
+    keep = 1.0 - p
+    g = torch.Generator(device=x.device)
+    g.manual_seed(next_seed() & 0x7FFFFFFFFFFFFFFF)
+    scale = torch.floor(keep + torch.rand(x.shape[0], device=x.device, generator=g)) / keep
+    return _RowScaleAdd.apply(resid, x, scale.float())
+
+
+class _RobertaEmbed(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, word, pos_tab, type_tab, gamma, beta, pad, eps, p_drop, seed):
+        B, S = ids.shape
+        C = word.shape[1]
+        ids = _c(ids)
+        y = torch.empty((B, S, C), dtype=BF16, device=ids.device)
+        pos = torch.empty((B, S), dtype=torch.int32, device=ids.device)
+        mean = torch.empty(B * S, dtype=torch.float32, device=ids.device)
+        rstd = torch.empty_like(mean)
+        lib.call("fiber_roberta_embed_fwd", lib.ptr(ids), lib.ptr(word), lib.ptr(pos_tab), lib.ptr(type_tab), lib.ptr(gamma), lib.ptr(beta),
+                 lib.ptr(y), lib.ptr(pos), lib.ptr(mean), lib.ptr(rstd), B, S, C, pad, eps, p_drop, seed)
+        ctx.save_for_backward(ids, pos, word, pos_tab, type_tab, gamma, mean, rstd)
+        ctx.cfg = (B, S, C, p_drop, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ids, pos, word, pos_tab, type_tab, gamma, mean, rstd = ctx.saved_tensors
+        B, S, C, p_drop, seed = ctx.cfg
+        dy = _c(dy)
+        dword, dpos, dtype = torch.zeros_like(word), torch.zeros_like(pos_tab), torch.zeros_like(type_tab)
+        dg = torch.zeros(C, dtype=torch.float32, device=dy.device)
+        db = torch.zeros_like(dg)
+        lib.call("fiber_roberta_embed_bwd", lib.ptr(dy), lib.ptr(ids), lib.ptr(pos), lib.ptr(word), lib.ptr(pos_tab), lib.ptr(type_tab),
+                 lib.ptr(gamma), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dword), lib.ptr(dpos), lib.ptr(dtype), lib.ptr(dg), lib.ptr(db),
+                 B, S, C, p_drop, seed)
+        return None, dword, dpos, dtype, dg, db, None, None, None, None
+
+
+def roberta_embed(ids, word, pos_tab, type_tab, gamma, beta, pad=1, eps=1e-5, p_drop=0.0, training=False):
+    p = float(p_drop) if training else 0.0
+    return _RobertaEmbed.apply(ids, word, pos_tab, type_tab, gamma, beta, pad, eps, p, next_seed() if p > 0 else 0)
+
+
+class _PatchEmbedProj(torch.autograd.Function):
+    """Conv2d(3->C, k=4, s=4) + bias as im2col + MFMA GEMM (no input gradient: the image is data)."""
+
+    @staticmethod
+    def forward(ctx, img, weight, bias):
+        B, _, H, W = img.shape
+        Cout = weight.shape[0]
+        img = _c(img.float())
+        rows = B * (H // 4) * (W // 4)
+        cols = torch.empty((rows, 64), dtype=BF16, device=img.device)
+        lib.call("fiber_im2col_patch4", lib.ptr(img), lib.ptr(cols), B, H, W)
+        key = ("pe", id(weight))
+        hit = _wcache.get(key)
+        if hit is None or hit[0] != weight._version or hit[2] is not weight:
+            wp = torch.zeros((Cout, 64), dtype=BF16, device=img.device)
+            wp[:, :48] = weight.detach().reshape(Cout, 48).to(BF16)
+            _wcache[key] = (weight._version, wp, weight)
+        wp = _wcache[key][1]
+        y, _ = gemm_nt(cols, wp, bias)
+        ctx.save_for_backward(cols)
+        ctx.wshape = weight.shape
+        return y.view(B, rows // B, Cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (cols,) = ctx.saved_tensors
+        dy2 = _c(dy).view(-1, dy.shape[-1])
+        dw = torch.matmul(dy2.t(), cols)[:, :48].float().reshape(ctx.wshape)
+        return None, dw, colsum(dy2)
+
+
+def patch_embed_proj(img, weight, bias):
+    return _PatchEmbedProj.apply(img, weight, bias)

@@ -1,0 +1,86 @@
+/* fiber_hip.h -- C ABI of libfiber_hip.so, the MI355X (gfx950) kernels behind the FIBER coarse-grained
+ * fused-backbone forward/backward path.
+ *
+ * The reference has no FFI: its hot path is Python calling ATen.  Each entry point below replaces the ATen call
+ * sequence of one reference function (file:line relative to /root/reference/coarse_grained/fiber/modules/).
+ * A maintainer binds them with ctypes (fiber_amd/lib.py is that binding).
+ *
+ * Conventions: every pointer is a DEVICE pointer; "bf16" buffers are passed as void* (uint16 storage, row-major);
+ * fp32 is used for parameters of normalisation/bias, statistics and gradient accumulators; `stream` is a hipStream_t
+ * (the caller's current stream -- kernels are stream-ordered, re-entrant, and never synchronise the host);
+ * return value 0 = ok, 1 = invalid argument (shape/alignment contract violated), 2 = launch failure.
+ * Inputs are borrowed and never mutated; outputs and workspaces are caller-allocated.
+ */
+#ifndef FIBER_HIP_H
+#define FIBER_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct ihipStream_t* fiber_stream_t;
+
+/* nn.Linear (+bias, +exact-erf GELU, +residual) : Y = act(X.W^T + bias) + R
+ * replaces: swin_transformer.py:197,221,233,238,257 (qkv/proj/i2t linears), timm Mlp fc1/fc2 (:325), PatchMerging.reduction
+ * (:431), roberta.py:231-241,337,398,415, fiber_module.py:349-350.  act: 0 none, 1 GELU (Ypre, if non-NULL, gets the
+ * pre-activation).  Requires K%8==0, N%4==0, ldx/ldw%8==0, ldy/ldr%4==0. */
+int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bias, const void* residual, void* Y, void* Ypre, int M,
+                       int N, int K, int ldx, int ldw, int ldy, int ldr, int act, fiber_stream_t stream);
+
+/* nn.LayerNorm over the last dim (C%8==0, C<=4096); saves mean/rstd.  replaces swin_transformer.py:362,391,244; roberta.py:485,422 */
+int fiber_layernorm_fwd_bf16(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int rows,
+                             int C, float eps, fiber_stream_t stream);
+int fiber_layernorm_bwd_grid(int rows); /* workspace = grid*8*C floats */
+int fiber_layernorm_bwd_bf16(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
+                             float* dgamma, float* dbeta, float* workspace, int rows, int C, fiber_stream_t stream);
+
+/* PatchMerging gather+concat+LayerNorm (swin_transformer.py:411-430): x [B,H*W,C] -> y [B,H*W/4,4C] */
+int fiber_patch_merge_ln_fwd_bf16(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int B,
+                                  int H, int W, int C, float eps, fiber_stream_t stream);
+int fiber_patch_merge_ln_bwd_bf16(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                  void* dx, float* dgamma, float* dbeta, float* workspace, int B, int H, int W, int C,
+                                  fiber_stream_t stream);
+
+/* Swin (shifted) window attention in image-token order: roll + window_partition + WindowAttention self-attn core +
+ * window_reverse + roll (swin_transformer.py:99-126, 195-219, 364-387, mask 327-350).  qkv [B*H*W,3C] -> o [B*H*W,C]. */
+int fiber_window_attn_fwd_bf16(const void* qkv, const float* bias_table, void* o, float* lse, int B, int Hres, int Wres, int C,
+                               int heads, int ws, int shift, fiber_stream_t stream);
+int fiber_window_attn_bwd_slices(int n_windows, int heads);
+int fiber_window_attn_bwd_bf16(const void* qkv, const float* bias_table, const void* o, const void* dout, const float* lse,
+                               void* dqkv, float* dbias_table, float* delta_ws, float* dbias_ws, int B, int Hres, int Wres,
+                               int C, int heads, int ws, int shift, fiber_stream_t stream);
+
+/* Generic MHA core softmax(q.k^T*scale + kmask).v with optional attention-prob dropout: RoBERTa self-attention
+ * (roberta.py:256-326), image->text cross-attention (swin_transformer.py:226-256) and text->image cross-attention
+ * (roberta.py:272-276).  D in {32,64}. */
+int fiber_mha_fwd_bf16(const void* q, const void* k, const void* v, const float* kmask, void* o, float* lse, int B, int heads,
+                       int Lq, int Lk, int D, int ldq, int ldk, int ldv, int ldo, float scale, float p_drop, uint64_t seed,
+                       fiber_stream_t stream);
+int fiber_mha_bwd_bf16(const void* q, const void* k, const void* v, const float* kmask, const void* o, const void* dout,
+                       const float* lse, void* dq, void* dk, void* dv, float* delta_ws, int B, int heads, int Lq, int Lk, int D,
+                       int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, float scale, float p_drop,
+                       uint64_t seed, fiber_stream_t stream);
+
+/* RobertaEmbeddings.forward (roberta.py:169-199, 877-888) and its backward (scatter-add into fp32 gradient tables) */
+int fiber_roberta_embed_fwd(const int64_t* ids, const float* word, const float* pos_tab, const float* type_tab,
+                            const float* gamma, const float* beta, void* y, int* pos_out, float* mean, float* rstd, int B, int S,
+                            int C, int pad, float eps, float p_drop, uint64_t seed, fiber_stream_t stream);
+int fiber_roberta_embed_bwd(const void* dy, const int64_t* ids, const int* pos, const float* word, const float* pos_tab,
+                            const float* type_tab, const float* gamma, const float* mean, const float* rstd, float* dword,
+                            float* dpos, float* dtype, float* dgamma, float* dbeta, int B, int S, int C, float p_drop,
+                            uint64_t seed, fiber_stream_t stream);
+
+/* timm PatchEmbed Conv2d(3->C,k=4,s=4) as im2col (K=48 ordered [c][kh][kw], zero padded to 64) feeding fiber_gemm_nt_bf16 */
+int fiber_im2col_patch4(const float* img, void* cols, int B, int H, int W, fiber_stream_t stream);
+
+/* element-wise / reduction helpers (n % 8 == 0) */
+int fiber_gelu_bwd_bf16(const void* dgelu, const void* h_pre, void* dh, long n, fiber_stream_t stream);
+int fiber_scale_add_bf16(const void* a, const void* b, const float* alpha, float mult, void* out, long n, fiber_stream_t stream);
+int fiber_dot_bf16(const void* a, const void* b, float* out, long n, fiber_stream_t stream);
+int fiber_colsum_bf16(const void* x, float* out, int M, int N, int ld, fiber_stream_t stream);
+int fiber_dropout_bf16(const void* x, void* y, long n, float p, uint64_t seed, fiber_stream_t stream);
+int fiber_rowscale_add_bf16(const void* r, const void* x, const float* scale, void* out, long n, long per_sample,
+                            fiber_stream_t stream);
+#ifdef __cplusplus
+}
+#endif
+#endif
