@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void roberta_embed_bwd_kernel(const bf16* __re
                                                                 const float* __restrict__ rstd, float* __restrict__ dword,
                                                                 float* __restrict__ dpos, float* __restrict__ dtype,
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
-                                                                int C, float p_drop, uint64_t seed) {
+                                                                int C, int pad, float p_drop, uint64_t seed) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = C >> 2;
   const uint32_t thresh = (uint32_t)((double)p_drop * 4294967296.0);
@@ -137,8 +137,9 @@ __global__ __launch_bounds__(256) void roberta_embed_bwd_kernel(const bf16* __re
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float de = rs * (dg[i][e] - s1 - xh[i][e] * s2);
-          atomicAdd(dword + (size_t)id * C + vi * 4 + e, de);
-          atomicAdd(dpos + (size_t)ps * C + vi * 4 + e, de);
+          // nn.Embedding(padding_idx=pad): the pad row of both tables never receives a gradient (roberta.py:146,163)
+          if (id != pad) atomicAdd(dword + (size_t)id * C + vi * 4 + e, de);
+          if (ps != pad) atomicAdd(dpos + (size_t)ps * C + vi * 4 + e, de);
           at[i][e] += de;
         }
     }
@@ -196,13 +197,13 @@ extern "C" int fiber_roberta_embed_fwd(const int64_t* ids, const float* word, co
 extern "C" int fiber_roberta_embed_bwd(const void* dy, const int64_t* ids, const int* pos, const float* word, const float* pos_tab,
                                        const float* type_tab, const float* gamma, const float* mean, const float* rstd,
                                        float* dword, float* dpos, float* dtype, float* dgamma, float* dbeta, int B, int S, int C,
-                                       float p_drop, uint64_t seed, hipStream_t stream) {
+                                       int pad, float p_drop, uint64_t seed, hipStream_t stream) {
   if (B <= 0) return FIBER_OK;
   if ((C & 3) || C > 2048) return FIBER_EINVAL;
   const int rows = B * S, nv = cdiv(C >> 2, 64);
   int grid = cdiv(rows, 4 * 4);
   grid = grid < 1 ? 1 : (grid > 256 ? 256 : grid);
-#define L(NV) hipLaunchKernelGGL((roberta_embed_bwd_kernel<NV>), dim3(grid), dim3(256), 0, stream, (const bf16*)dy, ids, pos, word, pos_tab, type_tab, gamma, mean, rstd, dword, dpos, dtype, dgamma, dbeta, rows, C, p_drop, seed)
+#define L(NV) hipLaunchKernelGGL((roberta_embed_bwd_kernel<NV>), dim3(grid), dim3(256), 0, stream, (const bf16*)dy, ids, pos, word, pos_tab, type_tab, gamma, mean, rstd, dword, dpos, dtype, dgamma, dbeta, rows, C, pad, p_drop, seed)
   if (nv <= 1) L(1); else if (nv <= 2) L(2); else if (nv <= 4) L(4); else L(8);
 #undef L
   FIBER_CHECK_LAUNCH();

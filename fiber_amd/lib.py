@@ -25,7 +25,7 @@ SIGNATURES = {
     "fiber_mha_fwd_bf16": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, F, U64],
     "fiber_mha_bwd_bf16": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, F, F, U64],
     "fiber_roberta_embed_fwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, U64],
-    "fiber_roberta_embed_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, U64],
+    "fiber_roberta_embed_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, U64],
     "fiber_im2col_patch4": [P, P, I, I, I],
     "fiber_gelu_bwd_bf16": [P, P, P, L],
     "fiber_scale_add_bf16": [P, P, P, F, P, L],

@@ -369,20 +369,20 @@ class _RobertaEmbed(torch.autograd.Function):
         lib.call("fiber_roberta_embed_fwd", lib.ptr(ids), lib.ptr(word), lib.ptr(pos_tab), lib.ptr(type_tab), lib.ptr(gamma), lib.ptr(beta),
                  lib.ptr(y), lib.ptr(pos), lib.ptr(mean), lib.ptr(rstd), B, S, C, pad, eps, p_drop, seed)
         ctx.save_for_backward(ids, pos, word, pos_tab, type_tab, gamma, mean, rstd)
-        ctx.cfg = (B, S, C, p_drop, seed)
+        ctx.cfg = (B, S, C, pad, p_drop, seed)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         ids, pos, word, pos_tab, type_tab, gamma, mean, rstd = ctx.saved_tensors
-        B, S, C, p_drop, seed = ctx.cfg
+        B, S, C, pad, p_drop, seed = ctx.cfg
         dy = _c(dy)
         dword, dpos, dtype = torch.zeros_like(word), torch.zeros_like(pos_tab), torch.zeros_like(type_tab)
         dg = torch.zeros(C, dtype=torch.float32, device=dy.device)
         db = torch.zeros_like(dg)
         lib.call("fiber_roberta_embed_bwd", lib.ptr(dy), lib.ptr(ids), lib.ptr(pos), lib.ptr(word), lib.ptr(pos_tab), lib.ptr(type_tab),
                  lib.ptr(gamma), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dword), lib.ptr(dpos), lib.ptr(dtype), lib.ptr(dg), lib.ptr(db),
-                 B, S, C, p_drop, seed)
+                 B, S, C, pad, p_drop, seed)
         return None, dword, dpos, dtype, dg, db, None, None, None, None
 
 

@@ -66,7 +66,7 @@ int fiber_roberta_embed_fwd(const int64_t* ids, const float* word, const float* 
                             int C, int pad, float eps, float p_drop, uint64_t seed, fiber_stream_t stream);
 int fiber_roberta_embed_bwd(const void* dy, const int64_t* ids, const int* pos, const float* word, const float* pos_tab,
                             const float* type_tab, const float* gamma, const float* mean, const float* rstd, float* dword,
-                            float* dpos, float* dtype, float* dgamma, float* dbeta, int B, int S, int C, float p_drop,
+                            float* dpos, float* dtype, float* dgamma, float* dbeta, int B, int S, int C, int pad, float p_drop,
                             uint64_t seed, fiber_stream_t stream);
 
 /* timm PatchEmbed Conv2d(3->C,k=4,s=4) as im2col (K=48 ordered [c][kh][kw], zero padded to 64) feeding fiber_gemm_nt_bf16 */

@@ -96,7 +96,7 @@ def roberta_layer_inputs(name, B=2, S=40, hidden=768):
 
 def summarize(t, cap=4096):
     """Compact fingerprint of a tensor: strided sample + l2 norm + sum (keeps fixtures small)."""
-    t = t.detach().float().reshape(-1)
+    t = t.detach().float().cpu().reshape(-1)
     n = t.numel()
     stride = max(1, n // cap)
     return {"sub": t[::stride][:cap].numpy().copy(), "norm": np.float64(t.double().norm().item()),
