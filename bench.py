@@ -170,6 +170,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     ms = dt / args.steps * 1e3
+    if rank == 0:
+        print(f"[bench] {ms:.2f} ms/step, {args.batch * world * args.steps / dt:.1f} images/s", file=sys.stderr, flush=True)
     ips = args.batch * world * args.steps / dt
     lossv = loss.item()
 

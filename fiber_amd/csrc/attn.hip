@@ -529,20 +529,18 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnP p) {
   }
 }
 
-// dtable[t, h] = sum_z sum_{(i,j): rel_index(i,j)=t} part[z, h, i, j]     (swin_transformer.py:166-176 index)
-__global__ __launch_bounds__(64) void dbias_scatter_kernel(const float* __restrict__ part, float* __restrict__ dtable,
-                                                           int nz, int H, int ws) {
-  const int t = blockIdx.x, h = blockIdx.y, N = ws * ws, W2 = 2 * ws - 1;
-  const int dr = t / W2 - (ws - 1), dc = t % W2 - (ws - 1);     // (pri - prj, pci - pcj)
-  float s = 0.f;
-  for (int idx = threadIdx.x; idx < nz * N; idx += 64) {
-    const int z = idx / N, i = idx - z * N;
-    const int pri = i / ws, pci = i - pri * ws, prj = pri - dr, pcj = pci - dc;
-    if (prj >= 0 && prj < ws && pcj >= 0 && pcj < ws)
-      s += part[(((size_t)z * H + h) * N + i) * N + prj * ws + pcj];
+// dtable[rel_index(i,j), h] += sum_z part[z, h, i, j]   (swin_transformer.py:166-176 index; dtable pre-zeroed)
+// block = (query i, head h): threads stride over keys j, the z-sum reads are coalesced along j.
+__global__ __launch_bounds__(256) void dbias_scatter_kernel(const float* __restrict__ part, float* __restrict__ dtable,
+                                                            int nz, int H, int ws) {
+  const int i = blockIdx.x, h = blockIdx.y, N = ws * ws, W2 = 2 * ws - 1;
+  const int pri = i / ws, pci = i - pri * ws;
+  for (int j = threadIdx.x; j < N; j += 256) {
+    float s = 0.f;
+    for (int z = 0; z < nz; ++z) s += part[(((size_t)z * H + h) * N + i) * N + j];
+    const int prj = j / ws, pcj = j - prj * ws;
+    atomicAdd(dtable + (size_t)((pri - prj + ws - 1) * W2 + (pci - pcj + ws - 1)) * H + h, s);
   }
-  s = wave_sum(s);
-  if (threadIdx.x == 0) dtable[(size_t)t * H + h] = s;
 }
 
 int pick_waves(int nstrips) { return nstrips <= 12 ? nstrips : (nstrips % 9 == 0 ? 9 : 8); }
@@ -584,7 +582,8 @@ int launch_bwd(AttnP& p, float* delta, float* dbias_table, float* dbias_ws, int 
     hipLaunchKernelGGL((attn_bwd_dq_kernel<D>), dim3(cdiv(nstrips, nw), p.H, gz), dim3(64 * nw), lds_bytes<D>(nb, 2, 1), st, p);
     FIBER_CHECK_LAUNCH();
     if (p.window) {
-      hipLaunchKernelGGL(dbias_scatter_kernel, dim3(nb, p.H), dim3(64), 0, st, dbias_ws, dbias_table, gz, p.H, p.ws);
+      if (hipMemsetAsync(dbias_table, 0, (size_t)nb * p.H * sizeof(float), st) != hipSuccess) return FIBER_ELAUNCH;
+      hipLaunchKernelGGL(dbias_scatter_kernel, dim3(p.Lq, p.H), dim3(256), 0, st, dbias_ws, dbias_table, gz, p.H, p.ws);
       FIBER_CHECK_LAUNCH();
     }
   }

@@ -22,20 +22,41 @@ struct MergeMap {  // PatchMerging gather: output row (b,i,j) of width 4C reads 
   }
 };
 
-template <int NV, bool MERGE>
+// sum over the LPR lanes that share a row (LPR = 64 -> whole wave)
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// LPR lanes cooperate on one row (64/LPR rows per wave, so narrow rows such as C=128 still use all 64 lanes);
+// NV 16-byte vectors per lane (NV > 1 only when LPR == 64).
+template <int LPR, int NV, bool MERGE>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows,
                                                      int C, float eps, MergeMap mm) {
+  constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, gl = lane % LPR;
   const int nvec = C >> 3;
-  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+  float g[NV][8], b[NV][8];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int vi = gl + i * LPR;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { g[i][e] = vi < nvec ? gamma[vi * 8 + e] : 0.f; b[i][e] = vi < nvec ? beta[vi * 8 + e] : 0.f; }
+  }
+  for (int row0 = (blockIdx.x * 4 + wave) * RPW; row0 < rows; row0 += gridDim.x * 4 * RPW) {
+    const int row = row0 + sub;
+    const bool rok = row < rows;
     float v[NV][8];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int vi = lane + i * 64;
-      if (vi < nvec) {
+      const int vi = gl + i * LPR;
+      if (rok && vi < nvec) {
         const size_t off = MERGE ? mm.src(row, vi * 8) : (size_t)row * C + vi * 8;
         const bf16x8 t = *reinterpret_cast<const bf16x8*>(x + off);
 #pragma unroll
@@ -45,56 +66,56 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
         for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
       }
     }
-    const float mu = wave_sum(s) / C;
+    const float mu = group_sum<LPR>(s) / C;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i)
-      if (lane + i * 64 < nvec)
+      if (gl + i * LPR < nvec)
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mu; q += d * d; }
-    const float rs = rsqrtf(wave_sum(q) / C + eps);
-    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    const float rs = rsqrtf(group_sum<LPR>(q) / C + eps);
+    if (rok && gl == 0) { mean[row] = mu; rstd[row] = rs; }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int vi = lane + i * 64;
-      if (vi < nvec) {
-        const float4 g0 = *reinterpret_cast<const float4*>(gamma + vi * 8), g1 = *reinterpret_cast<const float4*>(gamma + vi * 8 + 4);
-        const float4 b0 = *reinterpret_cast<const float4*>(beta + vi * 8), b1 = *reinterpret_cast<const float4*>(beta + vi * 8 + 4);
-        const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-        const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      const int vi = gl + i * LPR;
+      if (rok && vi < nvec) {
         bf16x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f2bf((v[i][e] - mu) * rs * g[e] + b[e]);
+        for (int e = 0; e < 8; ++e) o[e] = f2bf((v[i][e] - mu) * rs * g[i][e] + b[i][e]);
         *reinterpret_cast<bf16x8*>(y + (size_t)row * C + vi * 8) = o;
       }
     }
   }
 }
 
-// dx = rstd * (dy*g - mean_c(dy*g) - xhat * mean_c(dy*g*xhat)); partial dgamma/dbeta per workgroup.
-template <int NV, bool MERGE>
+// dx = rstd * (dy*g - mean_c(dy*g) - xhat * mean_c(dy*g*xhat)); one fp32 partial row of dgamma/dbeta per wave.
+template <int LPR, int NV, bool MERGE>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, bf16* __restrict__ dx,
                                                      float* __restrict__ part /*[grid*4 waves][2][C]*/, int rows, int C,
                                                      MergeMap mm) {
+  constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, gl = lane % LPR;
   const int nvec = C >> 3;
   float ag[NV][8], ab[NV][8], g[NV][8];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int vi = lane + i * 64;
+    const int vi = gl + i * LPR;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ag[i][e] = 0.f; ab[i][e] = 0.f; g[i][e] = vi < nvec ? gamma[vi * 8 + e] : 0.f; }
   }
-  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-    const float mu = mean[row], rs = rstd[row];
+  for (int row0 = (blockIdx.x * 4 + wave) * RPW; row0 < rows; row0 += gridDim.x * 4 * RPW) {
+    const int row = row0 + sub;
+    const bool rok = row < rows;
+    const float mu = rok ? mean[row] : 0.f, rs = rok ? rstd[row] : 0.f;
     float xh[NV][8], dg[NV][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int vi = lane + i * 64;
-      if (vi < nvec) {
+      const int vi = gl + i * LPR;
+      if (rok && vi < nvec) {
         const size_t off = MERGE ? mm.src(row, vi * 8) : (size_t)row * C + vi * 8;
         const bf16x8 tx = *reinterpret_cast<const bf16x8*>(x + off);
         const bf16x8 td = *reinterpret_cast<const bf16x8*>(dy + (size_t)row * C + vi * 8);
@@ -113,12 +134,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
         for (int e = 0; e < 8; ++e) { xh[i][e] = 0.f; dg[i][e] = 0.f; }
       }
     }
-    s1 = wave_sum(s1) / C;
-    s2 = wave_sum(s2) / C;
+    s1 = group_sum<LPR>(s1) / C;
+    s2 = group_sum<LPR>(s2) / C;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int vi = lane + i * 64;
-      if (vi < nvec) {
+      const int vi = gl + i * LPR;
+      if (rok && vi < nvec) {
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = f2bf(rs * (dg[i][e] - s1 - xh[i][e] * s2));
@@ -127,38 +148,68 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
       }
     }
   }
-  // one fp32 partial row per wave; folded by ln_bwd_reduce_kernel
+  // combine the RPW row-groups of this wave, then one fp32 partial row per wave
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int o = 32; o >= LPR; o >>= 1) { ag[i][e] += __shfl_xor(ag[i][e], o); ab[i][e] += __shfl_xor(ab[i][e], o); }
   float* my = part + (size_t)(blockIdx.x * 4 + wave) * 2 * C;
+  if (sub == 0) {
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int vi = lane + i * 64;
-    if (vi < nvec)
+    for (int i = 0; i < NV; ++i) {
+      const int vi = gl + i * LPR;
+      if (vi < nvec)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        my[vi * 8 + e] = ag[i][e];
-        my[C + vi * 8 + e] = ab[i][e];
-      }
+        for (int e = 0; e < 8; ++e) {
+          my[vi * 8 + e] = ag[i][e];
+          my[C + vi * 8 + e] = ab[i][e];
+        }
+    }
   }
 }
 
-__global__ void ln_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta, int nblk, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= 2 * C) return;
-  const int which = c / C, col = c - which * C;
+// fold the per-wave partial rows: block = 64 columns x 4 row lanes (coalesced along columns), LDS combine
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int nrows, int C) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;            // column in the [2][C] partial row
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += part[((size_t)b * 2 + which) * C + col];
-  (which ? dbeta : dgamma)[col] = s;
+  if (col < 2 * C)
+    for (int r = rl; r < nrows; r += 4) s += part[(size_t)r * 2 * C + col];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && col < 2 * C) {
+    s = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    if (col < C) dgamma[col] = s; else dbeta[col - C] = s;
+  }
 }
+
+#define LN_DISPATCH(KERNEL, ...)                                                             \
+  do {                                                                                      \
+    const int nvec = C >> 3;                                                                \
+    if (nvec <= 8) KERNEL(8, 1, __VA_ARGS__);                                               \
+    else if (nvec <= 16) KERNEL(16, 1, __VA_ARGS__);                                        \
+    else if (nvec <= 32) KERNEL(32, 1, __VA_ARGS__);                                        \
+    else if (nvec <= 64) KERNEL(64, 1, __VA_ARGS__);                                        \
+    else if (nvec <= 128) KERNEL(64, 2, __VA_ARGS__);                                       \
+    else if (nvec <= 256) KERNEL(64, 4, __VA_ARGS__);                                       \
+    else if (nvec <= 512) KERNEL(64, 8, __VA_ARGS__);                                       \
+    else return FIBER_EINVAL;                                                               \
+  } while (0)
+
+inline int rows_per_wave(int C) { const int nvec = C >> 3; return nvec <= 8 ? 8 : nvec <= 16 ? 4 : nvec <= 32 ? 2 : 1; }
 
 template <bool MERGE>
 int launch_fwd(const bf16* x, const float* g, const float* b, bf16* y, float* mean, float* rstd, int rows, int C,
                float eps, MergeMap mm, hipStream_t st) {
-  const int grid = rows < 4 * 2048 ? cdiv(rows, 4) : 2048;
-  const int nv = cdiv(C >> 3, 64);
-#define L(NV) hipLaunchKernelGGL((ln_fwd_kernel<NV, MERGE>), dim3(grid), dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps, mm)
-  if (nv <= 1) L(1); else if (nv <= 2) L(2); else if (nv <= 4) L(4); else if (nv <= 8) L(8); else return FIBER_EINVAL;
-#undef L
+  const int need = cdiv(rows, 4 * rows_per_wave(C));
+  const int grid = need < 4096 ? need : 4096;
+#define FWD(LPR, NV, ...) hipLaunchKernelGGL((ln_fwd_kernel<LPR, NV, MERGE>), dim3(grid), dim3(256), 0, st, __VA_ARGS__)
+  LN_DISPATCH(FWD, x, g, b, y, mean, rstd, rows, C, eps, mm);
+#undef FWD
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }
@@ -166,12 +217,11 @@ int launch_fwd(const bf16* x, const float* g, const float* b, bf16* y, float* me
 template <bool MERGE>
 int launch_bwd(const bf16* dy, const bf16* x, const float* g, const float* mean, const float* rstd, bf16* dx,
                float* dgamma, float* dbeta, float* ws, int grid, int rows, int C, MergeMap mm, hipStream_t st) {
-  const int nv = cdiv(C >> 3, 64);
-#define L(NV) hipLaunchKernelGGL((ln_bwd_kernel<NV, MERGE>), dim3(grid), dim3(256), 0, st, dy, x, g, mean, rstd, dx, ws, rows, C, mm)
-  if (nv <= 1) L(1); else if (nv <= 2) L(2); else if (nv <= 4) L(4); else if (nv <= 8) L(8); else return FIBER_EINVAL;
-#undef L
+#define BWD(LPR, NV, ...) hipLaunchKernelGGL((ln_bwd_kernel<LPR, NV, MERGE>), dim3(grid), dim3(256), 0, st, __VA_ARGS__)
+  LN_DISPATCH(BWD, dy, x, g, mean, rstd, dx, ws, rows, C, mm);
+#undef BWD
   FIBER_CHECK_LAUNCH();
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, st, ws, dgamma, dbeta, grid * 4, C);
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * C, 64)), dim3(256), 0, st, ws, dgamma, dbeta, grid * 4, C);
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }
@@ -180,8 +230,8 @@ int launch_bwd(const bf16* dy, const bf16* x, const float* g, const float* mean,
 
 // Number of workgroups the backward uses for `rows` rows: the caller sizes the fp32 workspace as grid*8*C floats.
 extern "C" int fiber_layernorm_bwd_grid(int rows) {
-  int g = cdiv(rows, 4 * 8);
-  return g < 1 ? 1 : (g > 256 ? 256 : g);
+  int g = cdiv(rows, 4 * 16);
+  return g < 1 ? 1 : (g > 1024 ? 1024 : g);
 }
 
 // y = LN(x) * gamma + beta over the last dim C (C % 8 == 0, C <= 4096); saves per-row mean / rstd (fp32).

@@ -109,6 +109,9 @@ class FIBERTransformerSS(LightningModule):
             if (n.startswith("vit_model.norm.") or n.startswith("text_transformer.pooler.") or "_itc." in n
                     or n.startswith("rank_output.") or ("crossattention_t2i.output.LayerNorm" in n)):
                 names.append(n)
+        last = self.num_text_layer - 1                  # layer 11 runs with last_norm=False on the fused path (:342)
+        names += [f"text_transformer.encoder.layer.{last}.output.LayerNorm.weight",
+                  f"text_transformer.encoder.layer.{last}.output.LayerNorm.bias"]
         stage2 = self.vit_model.layers[2].blocks
         if len(stage2) < 8 + self.num_text_layer - self.num_fuse_block + 1:      # Swin-T quirk: text layers 6..9 never run
             for i in range(self.num_text_layer - self.num_fuse_block, 10):

@@ -62,6 +62,34 @@ def colsum(x2):
     return out
 
 
+_bmm_fp32 = [None]
+
+
+def wgrad(dh, x2):
+    """dW[N,K] = dh[M,N]^T . x2[M,K] in fp32.  The library TN GEMM does not split the (huge) M reduction, so for
+    small N*K it runs on a handful of CUs (49 TFLOP/s at M=295k, N=384, K=128); expressing the reduction as a batch of
+    S independent chunk GEMMs + one fp32 sum restores parallelism."""
+    M, N = dh.shape
+    K = x2.shape[1]
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    S = 1
+    while S < 64 and tiles * S < 512 and M % (2 * S) == 0 and M // (2 * S) >= 1024:
+        S *= 2
+    if S == 1:
+        return torch.matmul(dh.t(), x2).float()
+    a = dh.view(S, M // S, N).transpose(1, 2)
+    b = x2.view(S, M // S, K)
+    if _bmm_fp32[0] is None:
+        try:
+            torch.bmm(a[:1], b[:1], out_dtype=torch.float32)
+            _bmm_fp32[0] = True
+        except Exception:  # noqa: BLE001
+            _bmm_fp32[0] = False
+    if _bmm_fp32[0]:
+        return torch.bmm(a, b, out_dtype=torch.float32).sum(0)
+    return torch.bmm(a, b).float().sum(0)
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, act):
@@ -87,7 +115,7 @@ class _Linear(torch.autograd.Function):
             dh = dy2
         wb = bf16_weight(weight)
         dx = torch.matmul(dh, wb).view(ctx.shp) if ctx.needs_input_grad[0] else None
-        dw = torch.matmul(dh.t(), x2).float() if ctx.needs_input_grad[1] else None
+        dw = wgrad(dh, x2) if ctx.needs_input_grad[1] else None
         db = colsum(dh) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db, dres, None
 
@@ -418,7 +446,7 @@ class _PatchEmbedProj(torch.autograd.Function):
     def backward(ctx, dy):
         (cols,) = ctx.saved_tensors
         dy2 = _c(dy).view(-1, dy.shape[-1])
-        dw = torch.matmul(dy2.t(), cols)[:, :48].float().reshape(ctx.wshape)
+        dw = wgrad(dy2, cols)[:, :48].reshape(ctx.wshape)
         return None, dw, colsum(dy2)
 
 

