@@ -610,6 +610,14 @@ void ensure_attrs() {
 
 }  // namespace
 
+// specialised persistent window kernels (win_attn.hip)
+int fiber_win_fwd_launch(const void* qkv, const float* bias_table, void* o, float* lse, int B, int Hres, int Wres, int C,
+                         int heads, int ws, int shift, hipStream_t st);
+int fiber_win_bwd_slices(int n_windows, int heads);
+int fiber_win_bwd_launch(const void* qkv, const float* bias_table, const void* o, const void* dout, const float* lse,
+                         void* dqkv, float* dbias_table, float* delta_ws, float* dbias_ws, int B, int Hres, int Wres, int C,
+                         int heads, int ws, int shift, hipStream_t st);
+
 // --------------------------------------------------------------------------------------------------- C ABI
 // Window attention in image-token order.  qkv: [B*Hres*Wres, 3C] bf16 with channel layout [3][heads][32]
 // (swin_transformer.py:202); o: [B*Hres*Wres, C]; bias_table fp32 [(2ws-1)^2, heads]; lse fp32 [B*Hres*Wres, heads].
@@ -617,6 +625,7 @@ void ensure_attrs() {
 extern "C" int fiber_window_attn_fwd_bf16(const void* qkv, const float* bias_table, void* o, float* lse, int B, int Hres,
                                           int Wres, int C, int heads, int ws, int shift, hipStream_t stream) {
   if (C != heads * 32 || Hres % ws || Wres % ws || shift < 0 || shift >= ws) return FIBER_EINVAL;
+  if (ws * ws <= 160) return fiber_win_fwd_launch(qkv, bias_table, o, lse, B, Hres, Wres, C, heads, ws, shift, stream);
   ensure_attrs();
   AttnP p{};
   const bf16* base = (const bf16*)qkv;
@@ -629,10 +638,7 @@ extern "C" int fiber_window_attn_fwd_bf16(const void* qkv, const float* bias_tab
 }
 
 // Number of partial-gradient slices pass A uses for B*nW windows; workspace = slices * heads * N * N floats.
-extern "C" int fiber_window_attn_bwd_slices(int n_windows, int heads) {
-  int nz = cdiv(512, heads);
-  return nz > n_windows ? n_windows : nz;
-}
+extern "C" int fiber_window_attn_bwd_slices(int n_windows, int heads) { return fiber_win_bwd_slices(n_windows, heads); }
 
 // Backward of the above.  dqkv: [B*Hres*Wres, 3C] (fully written); dbias_table fp32 [(2ws-1)^2, heads] (overwritten);
 // delta_ws: fp32 [B*Hres*Wres*heads]; dbias_ws: fp32 [slices*heads*N*N].
@@ -641,6 +647,9 @@ extern "C" int fiber_window_attn_bwd_bf16(const void* qkv, const float* bias_tab
                                           float* dbias_ws, int B, int Hres, int Wres, int C, int heads, int ws, int shift,
                                           hipStream_t stream) {
   if (C != heads * 32 || Hres % ws || Wres % ws || shift < 0 || shift >= ws) return FIBER_EINVAL;
+  if (ws * ws <= 160)
+    return fiber_win_bwd_launch(qkv, bias_table, o, dout, lse, dqkv, dbias_table, delta_ws, dbias_ws, B, Hres, Wres, C, heads,
+                                ws, shift, stream);
   ensure_attrs();
   AttnP p{};
   const bf16* base = (const bf16*)qkv;

@@ -170,20 +170,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
   }
 }
 
-// fold the per-wave partial rows: block = 64 columns x 4 row lanes (coalesced along columns), LDS combine
+// fold the per-wave partial rows: block = 64 columns x 4 row lanes (coalesced along columns); the row range is split
+// over blockIdx.y and combined with one fp32 atomic per column (outputs pre-zeroed by the launcher)
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, int nrows, int C) {
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cl;            // column in the [2][C] partial row
+  const int per = (nrows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per, r1 = min(nrows, r0 + per);
   float s = 0.f;
   if (col < 2 * C)
-    for (int r = rl; r < nrows; r += 4) s += part[(size_t)r * 2 * C + col];
+    for (int r = r0 + rl; r < r1; r += 4) s += part[(size_t)r * 2 * C + col];
   red[rl][cl] = s;
   __syncthreads();
   if (rl == 0 && col < 2 * C) {
     s = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
-    if (col < C) dgamma[col] = s; else dbeta[col - C] = s;
+    atomicAdd(col < C ? dgamma + col : dbeta + (col - C), s);
   }
 }
 
@@ -221,7 +224,10 @@ int launch_bwd(const bf16* dy, const bf16* x, const float* g, const float* mean,
   LN_DISPATCH(BWD, dy, x, g, mean, rstd, dx, ws, rows, C, mm);
 #undef BWD
   FIBER_CHECK_LAUNCH();
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * C, 64)), dim3(256), 0, st, ws, dgamma, dbeta, grid * 4, C);
+  if (hipMemsetAsync(dgamma, 0, C * sizeof(float), st) != hipSuccess || hipMemsetAsync(dbeta, 0, C * sizeof(float), st) != hipSuccess)
+    return FIBER_ELAUNCH;
+  const int nrows = grid * 4, ysplit = nrows >= 64 ? 32 : 1;
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * C, 64), ysplit), dim3(256), 0, st, ws, dgamma, dbeta, nrows, C);
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }

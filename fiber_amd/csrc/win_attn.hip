@@ -1,0 +1,577 @@
+// Swin (shifted-)window attention, specialised + persistent (gfx950 / CDNA4).  head_dim 32, N = ws*ws <= 160.
+//
+// Same math and MFMA formulation as attn.hip's WINDOW mode (swin_transformer.py:195-219 with roll / partition /
+// reverse :99-126,364-387 folded into addressing, bias gather :208-211, shift mask :327-350), restructured for
+// throughput after rocprof showed the generic kernel latency-bound (one 9-wave workgroup per CU, exposed global-load
+// latency per window, two integer divisions per score for the bias index):
+//   * a workgroup is PERSISTENT over a run of windows of one head: per-head bias table, key (row,col) offsets and all
+//     per-lane geometry are computed once; per window only K/V (or Q/dO) tiles are re-staged;
+//   * the next window's tiles and per-lane Q/dO fragments are PREFETCHED into registers (global loads in flight)
+//     while the MFMAs / softmax of the current window run, and written to LDS after the barrier (T14 split staging);
+//   * bias index = qoff(i) - keyoff(j): one LDS int4 read per 4 scores + one LDS float read per score, no divisions;
+//   * the shift mask is evaluated only for windows that touch the wrapped border (last window row / column).
+// Backward: pass A (wave = query strip) -> dQ and the relative-position-bias gradient, accumulated in registers over
+// all windows the workgroup visits; pass B (wave = key strip) -> dK, dV.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXN = 160;          // keys per window (<= 10 tiles of 16)
+constexpr int MT = 10;
+constexpr int RS = 40;             // row stride (elements) of row-major LDS tiles: 32 + 8 pad (80 B, 16-B aligned)
+constexpr int TS = MAXN + 8;       // row stride of transposed LDS tiles
+
+struct WinP {
+  const bf16* qkv; bf16* o; const bf16* dout; bf16* dqkv;
+  float* lse; const float* delta; const float* bias_table; float* dbias_part;
+  int B, Hres, Wres, C, heads, ws, shift, nWw, nWh, nW, G, N, gpb;
+};
+
+__device__ __forceinline__ int region_of(int x, int n, int ws, int shift) { return x < n - ws ? 0 : (x < n - shift ? 1 : 2); }
+__device__ __forceinline__ float g4max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
+__device__ __forceinline__ float g4sum(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { o[e] = f2bf(a[e]); o[4 + e] = f2bf(b[e]); }
+  return o;
+}
+__device__ __forceinline__ bf16x8 tr_frag(const bf16* tr, int d, int t0, int g) {
+  const bf16x4 lo = *reinterpret_cast<const bf16x4*>(tr + d * TS + t0 * 16 + g * 4);
+  const bf16x4 hi = *reinterpret_cast<const bf16x4*>(tr + d * TS + t0 * 16 + 16 + g * 4);
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi[e]; }
+  return o;
+}
+__device__ __forceinline__ bf16x8 zero8() {
+  bf16x8 z;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) z[e] = f2bf(0.f);
+  return z;
+}
+
+// window g, window-local (pr,pc) -> token row of the [B*H*W] tensors and shift-mask region label
+struct Geo {
+  int b, wr, wc;
+  bool border;
+  __device__ __forceinline__ void set(const WinP& p, int g) {
+    b = g / p.nW;
+    const int w = g - b * p.nW;
+    wr = w / p.nWw;
+    wc = w - wr * p.nWw;
+    border = p.shift > 0 && (wr == p.nWh - 1 || wc == p.nWw - 1);
+  }
+  __device__ __forceinline__ int tok(const WinP& p, int pr, int pc) const {
+    int r = wr * p.ws + pr + p.shift, c = wc * p.ws + pc + p.shift;
+    r = r >= p.Hres ? r - p.Hres : r;
+    c = c >= p.Wres ? c - p.Wres : c;
+    return (b * p.Hres + r) * p.Wres + c;
+  }
+  __device__ __forceinline__ int reg(const WinP& p, int pr, int pc) const {
+    return region_of(wr * p.ws + pr, p.Hres, p.ws, p.shift) * 3 + region_of(wc * p.ws + pc, p.Wres, p.ws, p.shift);
+  }
+};
+
+struct Smem {
+  int* koff; int* kreg; float* btab; float* lse; float* dlt;
+  bf16* a0; bf16* a1; bf16* t0; bf16* t1;
+};
+__device__ __forceinline__ Smem carve(char* base, int nb, int n_rm, int n_tr) {
+  Smem S;
+  S.koff = reinterpret_cast<int*>(base);
+  S.kreg = S.koff + MAXN;
+  S.lse = reinterpret_cast<float*>(S.kreg + MAXN);
+  S.dlt = S.lse + MAXN;
+  S.btab = S.dlt + MAXN;
+  bf16* img = reinterpret_cast<bf16*>(base + (size_t)(4 * MAXN + ((nb + 3) & ~3)) * 4);
+  S.a0 = img; img += (n_rm > 0) * MAXN * RS;
+  S.a1 = img; img += (n_rm > 1) * MAXN * RS;
+  S.t0 = img; img += (n_tr > 0) * 32 * TS;
+  S.t1 = img;
+  return S;
+}
+size_t smem_bytes(int nb, int n_rm, int n_tr) {
+  return (size_t)(4 * MAXN + ((nb + 3) & ~3)) * 4 + (size_t)n_rm * MAXN * RS * 2 + (size_t)n_tr * 32 * TS * 2;
+}
+
+// common per-block setup: bias column of this head, key offsets, zeroed LDS tiles (padding rows stay zero forever)
+__device__ __forceinline__ void setup(const WinP& p, const Smem& S, int h, int nb, int n_rm, int n_tr) {
+  for (int t = threadIdx.x; t < nb; t += blockDim.x) S.btab[t] = p.bias_table[(size_t)t * p.heads + h];
+  for (int j = threadIdx.x; j < MAXN; j += blockDim.x) {
+    const int jj = j < p.N ? j : 0;
+    const int pr = jj / p.ws, pc = jj - pr * p.ws;
+    S.koff[j] = pr * (2 * p.ws - 1) + pc;
+    S.kreg[j] = 0;
+    S.lse[j] = INFINITY;
+    S.dlt[j] = 0.f;
+  }
+  const int words = (n_rm * MAXN * RS + n_tr * 32 * TS) / 2;
+  uint32_t* z = reinterpret_cast<uint32_t*>(S.a0);
+  for (int t = threadIdx.x; t < words; t += blockDim.x) z[t] = 0u;
+}
+
+// ================================================================ forward =====================================
+__global__ __launch_bounds__(640) void win_fwd_kernel(WinP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nb = (2 * p.ws - 1) * (2 * p.ws - 1);
+  Smem S = carve(smem, nb, 1, 1);
+  bf16* Ks = S.a0; bf16* Vt = S.t0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int gq = lane >> 4, lq = lane & 15;
+  const int h = blockIdx.y, C = p.C, ld = 3 * C;
+  const int ntile = (p.N + 15) >> 4;
+  setup(p, S, h, nb, 1, 1);
+
+  // this thread's staging chunk (row sr of the window, 16-byte chunk sc of the 64-byte head slice)
+  const int sr = tid >> 2, sc = tid & 3;
+  const bool sval = sr < p.N;
+  const int spr = (sval ? sr : 0) / p.ws, spc = (sval ? sr : 0) - spr * p.ws;
+  // this lane's query
+  const int i = wave * 16 + lq;
+  const bool qval = i < p.N;
+  const int ic = qval ? i : p.N - 1;
+  const int qpr = ic / p.ws, qpc = ic - qpr * p.ws;
+  const int qoff = (qpr + p.ws - 1) * (2 * p.ws - 1) + qpc + p.ws - 1;
+  const float scale = 0.17677669529663687f;
+
+  const int g0 = blockIdx.x * p.gpb, g1 = min(p.G, g0 + p.gpb);
+  if (g0 >= g1) return;
+  Geo geo;
+  geo.set(p, g0);
+  bf16x8 kr = zero8(), vr = zero8(), qn;
+  int qtok = geo.tok(p, qpr, qpc);
+  {
+    const int st = geo.tok(p, spr, spc);
+    if (sval) {
+      kr = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + C + h * 32 + sc * 8);
+      vr = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + 2 * C + h * 32 + sc * 8);
+    }
+    qn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)qtok * ld + h * 32 + gq * 8);
+  }
+  for (int g = g0; g < g1; ++g) {
+    __syncthreads();                                  // previous window's LDS reads done (also covers setup)
+    if (sval) {
+      *reinterpret_cast<bf16x8*>(Ks + sr * RS + sc * 8) = kr;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) Vt[(sc * 8 + e) * TS + sr] = vr[e];
+    }
+    const bool border = geo.border;
+    if (border && tid < p.N) { const int pr = tid / p.ws; S.kreg[tid] = geo.reg(p, pr, tid - pr * p.ws); }
+    const int qreg = border ? geo.reg(p, qpr, qpc) : 0;
+    const bf16x8 qf = qn;
+    const int otok = qtok;
+    __syncthreads();
+    if (g + 1 < g1) {                                  // prefetch next window while this one computes
+      geo.set(p, g + 1);
+      qtok = geo.tok(p, qpr, qpc);
+      const int st = geo.tok(p, spr, spc);
+      if (sval) {
+        kr = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + C + h * 32 + sc * 8);
+        vr = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + 2 * C + h * 32 + sc * 8);
+      }
+      qn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)qtok * ld + h * 32 + gq * 8);
+    }
+    f32x4 s[MT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < MT; ++kt) {
+      s[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      if (kt < ntile) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 16 + lq) * RS + gq * 8);
+        f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);   // S^T[key][query]
+        const int4 ko = *reinterpret_cast<const int4*>(S.koff + kt * 16 + gq * 4);
+        const int kk[4] = {ko.x, ko.y, ko.z, ko.w};
+        int4 kg = int4{0, 0, 0, 0};
+        if (border) kg = *reinterpret_cast<const int4*>(S.kreg + kt * 16 + gq * 4);
+        const int kgg[4] = {kg.x, kg.y, kg.z, kg.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = a[r] * scale + S.btab[qoff - kk[r]];
+          if (border && kgg[r] != qreg) v += -100.f;
+          if (kt * 16 + gq * 4 + r >= p.N) v = -INFINITY;
+          s[kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+    }
+    mx = g4max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < MT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = kt < ntile ? __expf(s[kt][r] - mx) : 0.f;
+        s[kt][r] = e;
+        sum += e;
+      }
+    sum = g4sum(sum);
+    f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int t2 = 0; t2 < MT / 2; ++t2) {
+      if (t2 * 2 < ntile) {
+        const bf16x8 pf = pack8(s[2 * t2], s[2 * t2 + 1]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Vt, dt * 16 + lq, 2 * t2, gq), pf, oacc[dt], 0, 0, 0);
+      }
+    }
+    if (qval) {
+      const float inv = 1.f / sum;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = f2bf(oacc[dt][r] * inv);
+        *reinterpret_cast<bf16x4*>(p.o + (size_t)otok * C + h * 32 + dt * 16 + gq * 4) = o;
+      }
+      if (gq == 0) p.lse[(size_t)otok * p.heads + h] = mx + __logf(sum);
+    }
+  }
+}
+
+// ================================================================ backward pass A: dQ + dbias =================
+__global__ __launch_bounds__(640) void win_bwd_dq_kernel(WinP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nb = (2 * p.ws - 1) * (2 * p.ws - 1);
+  Smem S = carve(smem, nb, 2, 1);
+  bf16* Ks = S.a0; bf16* Vs = S.a1; bf16* Kt = S.t0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int gq = lane >> 4, lq = lane & 15;
+  const int h = blockIdx.y, C = p.C, ld = 3 * C;
+  const int ntile = (p.N + 15) >> 4;
+  setup(p, S, h, nb, 2, 1);
+  const int sr = tid >> 2, sc = tid & 3;
+  const bool sval = sr < p.N;
+  const int spr = (sval ? sr : 0) / p.ws, spc = (sval ? sr : 0) - spr * p.ws;
+  const int i = wave * 16 + lq;
+  const bool qval = i < p.N;
+  const int ic = qval ? i : p.N - 1;
+  const int qpr = ic / p.ws, qpc = ic - qpr * p.ws;
+  const int qoff = (qpr + p.ws - 1) * (2 * p.ws - 1) + qpc + p.ws - 1;
+  const float scale = 0.17677669529663687f;
+
+  f32x4 dbacc[MT];
+#pragma unroll
+  for (int kt = 0; kt < MT; ++kt) dbacc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int g0 = blockIdx.x * p.gpb, g1 = min(p.G, g0 + p.gpb);
+  Geo geo;
+  bf16x8 kr = zero8(), vr = zero8(), qn = zero8(), don = zero8();
+  float lsen = 0.f, dltn = 0.f;
+  int qtok = 0;
+  if (g0 < g1) {
+    geo.set(p, g0);
+    qtok = geo.tok(p, qpr, qpc);
+    const int st = geo.tok(p, spr, spc);
+    if (sval) {
+      kr = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + C + h * 32 + sc * 8);
+      vr = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + 2 * C + h * 32 + sc * 8);
+    }
+    qn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)qtok * ld + h * 32 + gq * 8);
+    don = *reinterpret_cast<const bf16x8*>(p.dout + (size_t)qtok * C + h * 32 + gq * 8);
+    lsen = p.lse[(size_t)qtok * p.heads + h];
+    dltn = p.delta[(size_t)qtok * p.heads + h];
+  }
+  for (int g = g0; g < g1; ++g) {
+    __syncthreads();
+    if (sval) {
+      *reinterpret_cast<bf16x8*>(Ks + sr * RS + sc * 8) = kr;
+      *reinterpret_cast<bf16x8*>(Vs + sr * RS + sc * 8) = vr;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) Kt[(sc * 8 + e) * TS + sr] = kr[e];
+    }
+    const bool border = geo.border;
+    if (border && tid < p.N) { const int pr = tid / p.ws; S.kreg[tid] = geo.reg(p, pr, tid - pr * p.ws); }
+    const int qreg = border ? geo.reg(p, qpr, qpc) : 0;
+    const bf16x8 qf = qn, dof = don;
+    const float lse = lsen, dlt = dltn;
+    const int otok = qtok;
+    __syncthreads();
+    if (g + 1 < g1) {
+      geo.set(p, g + 1);
+      qtok = geo.tok(p, qpr, qpc);
+      const int st = geo.tok(p, spr, spc);
+      if (sval) {
+        kr = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + C + h * 32 + sc * 8);
+        vr = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + 2 * C + h * 32 + sc * 8);
+      }
+      qn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)qtok * ld + h * 32 + gq * 8);
+      don = *reinterpret_cast<const bf16x8*>(p.dout + (size_t)qtok * C + h * 32 + gq * 8);
+      lsen = p.lse[(size_t)qtok * p.heads + h];
+      dltn = p.delta[(size_t)qtok * p.heads + h];
+    }
+    f32x4 dqacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int t2 = 0; t2 < MT / 2; ++t2) {
+      if (t2 * 2 < ntile) {
+        f32x4 ds[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int kt = 2 * t2 + u;
+          ds[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (kt < ntile) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 16 + lq) * RS + gq * 8);
+            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + (kt * 16 + lq) * RS + gq * 8);
+            const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const int4 ko = *reinterpret_cast<const int4*>(S.koff + kt * 16 + gq * 4);
+            const int kk[4] = {ko.x, ko.y, ko.z, ko.w};
+            int4 kg = int4{0, 0, 0, 0};
+            if (border) kg = *reinterpret_cast<const int4*>(S.kreg + kt * 16 + gq * 4);
+            const int kgg[4] = {kg.x, kg.y, kg.z, kg.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float sv = a[r] * scale + S.btab[qoff - kk[r]];
+              if (border && kgg[r] != qreg) sv += -100.f;
+              const bool ok = qval && (kt * 16 + gq * 4 + r < p.N);
+              const float d = ok ? __expf(sv - lse) * (dp[r] - dlt) : 0.f;
+              ds[u][r] = d;
+              dbacc[kt][r] += d;
+            }
+          }
+        }
+        const bf16x8 dsf = pack8(ds[0], ds[1]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          dqacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Kt, dt * 16 + lq, 2 * t2, gq), dsf, dqacc[dt], 0, 0, 0);
+      }
+    }
+    if (qval) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = f2bf(dqacc[dt][r] * scale);
+        *reinterpret_cast<bf16x4*>(p.dqkv + (size_t)otok * ld + h * 32 + dt * 16 + gq * 4) = o;
+      }
+    }
+  }
+  if (qval) {                                          // every (z, h, i, j<N) entry is written, zeros included
+    float* dst = p.dbias_part + (((size_t)blockIdx.x * p.heads + h) * p.N + i) * p.N;
+#pragma unroll
+    for (int kt = 0; kt < MT; ++kt)
+      if (kt < ntile)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = kt * 16 + gq * 4 + r;
+          if (j < p.N) dst[j] = dbacc[kt][r];
+        }
+  }
+}
+
+// ================================================================ backward pass B: dK, dV ======================
+__global__ __launch_bounds__(640) void win_bwd_dkv_kernel(WinP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nb = (2 * p.ws - 1) * (2 * p.ws - 1);
+  Smem S = carve(smem, nb, 2, 2);
+  bf16* Qs = S.a0; bf16* dOs = S.a1; bf16* Qt = S.t0; bf16* dOt = S.t1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int gq = lane >> 4, lq = lane & 15;
+  const int h = blockIdx.y, C = p.C, ld = 3 * C;
+  const int ntile = (p.N + 15) >> 4;
+  setup(p, S, h, nb, 2, 2);
+  const int sr = tid >> 2, sc = tid & 3;
+  const bool sval = sr < p.N;
+  const int spr = (sval ? sr : 0) / p.ws, spc = (sval ? sr : 0) - spr * p.ws;
+  const int j = wave * 16 + lq;                         // this lane's key
+  const bool kval = j < p.N;
+  const int jc = kval ? j : p.N - 1;
+  const int kpr = jc / p.ws, kpc = jc - kpr * p.ws;
+  // bias index for (query i, key j) = koff[i] + cst - koff[j]
+  const int kconst = (p.ws - 1) * (2 * p.ws - 1) + p.ws - 1 - (kpr * (2 * p.ws - 1) + kpc);
+  const float scale = 0.17677669529663687f;
+
+  const int g0 = blockIdx.x * p.gpb, g1 = min(p.G, g0 + p.gpb);
+  if (g0 >= g1) return;
+  Geo geo;
+  geo.set(p, g0);
+  bf16x8 qr = zero8(), dr = zero8(), kn, vn;
+  float lser = INFINITY, dltr = 0.f;
+  int ktok = geo.tok(p, kpr, kpc);
+  {
+    const int st = geo.tok(p, spr, spc);
+    if (sval) {
+      qr = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + h * 32 + sc * 8);
+      dr = *reinterpret_cast<const bf16x8*>(p.dout + (size_t)st * C + h * 32 + sc * 8);
+      if (sc == 0) { lser = p.lse[(size_t)st * p.heads + h]; dltr = p.delta[(size_t)st * p.heads + h]; }
+    }
+    kn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)ktok * ld + C + h * 32 + gq * 8);
+    vn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)ktok * ld + 2 * C + h * 32 + gq * 8);
+  }
+  for (int g = g0; g < g1; ++g) {
+    __syncthreads();
+    if (sval) {
+      *reinterpret_cast<bf16x8*>(Qs + sr * RS + sc * 8) = qr;
+      *reinterpret_cast<bf16x8*>(dOs + sr * RS + sc * 8) = dr;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { Qt[(sc * 8 + e) * TS + sr] = qr[e]; dOt[(sc * 8 + e) * TS + sr] = dr[e]; }
+      if (sc == 0) { S.lse[sr] = lser; S.dlt[sr] = dltr; }
+    }
+    const bool border = geo.border;
+    if (border && tid < p.N) { const int pr = tid / p.ws; S.kreg[tid] = geo.reg(p, pr, tid - pr * p.ws); }
+    const int kreg = border ? geo.reg(p, kpr, kpc) : 0;
+    const bf16x8 kf = kn, vf = vn;
+    const int otok = ktok;
+    __syncthreads();
+    if (g + 1 < g1) {
+      geo.set(p, g + 1);
+      ktok = geo.tok(p, kpr, kpc);
+      const int st = geo.tok(p, spr, spc);
+      if (sval) {
+        qr = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + h * 32 + sc * 8);
+        dr = *reinterpret_cast<const bf16x8*>(p.dout + (size_t)st * C + h * 32 + sc * 8);
+        if (sc == 0) { lser = p.lse[(size_t)st * p.heads + h]; dltr = p.delta[(size_t)st * p.heads + h]; }
+      }
+      kn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)ktok * ld + C + h * 32 + gq * 8);
+      vn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)ktok * ld + 2 * C + h * 32 + gq * 8);
+    }
+    f32x4 dkacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 dvacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int t2 = 0; t2 < MT / 2; ++t2) {
+      if (t2 * 2 < ntile) {
+        f32x4 ds[2], pd[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int qt = 2 * t2 + u;
+          ds[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          pd[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (qt < ntile) {
+            const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + (qt * 16 + lq) * RS + gq * 8);
+            const bf16x8 df = *reinterpret_cast<const bf16x8*>(dOs + (qt * 16 + lq) * RS + gq * 8);
+            const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);   // S[query][key]
+            const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);  // dP[query][key]
+            const int4 qo = *reinterpret_cast<const int4*>(S.koff + qt * 16 + gq * 4);
+            const int qq[4] = {qo.x, qo.y, qo.z, qo.w};
+            const float4 l4 = *reinterpret_cast<const float4*>(S.lse + qt * 16 + gq * 4);
+            const float4 d4 = *reinterpret_cast<const float4*>(S.dlt + qt * 16 + gq * 4);
+            const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+            int4 qg = int4{0, 0, 0, 0};
+            if (border) qg = *reinterpret_cast<const int4*>(S.kreg + qt * 16 + gq * 4);
+            const int qgg[4] = {qg.x, qg.y, qg.z, qg.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float sv = a[r] * scale + S.btab[qq[r] + kconst];
+              if (border && qgg[r] != kreg) sv += -100.f;
+              const float pr = kval ? __expf(sv - ll[r]) : 0.f;     // padded queries carry lse = +inf -> 0
+              pd[u][r] = pr;
+              ds[u][r] = pr * (dp[r] - dd[r]);
+            }
+          }
+        }
+        const bf16x8 dsf = pack8(ds[0], ds[1]), pf = pack8(pd[0], pd[1]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Qt, dt * 16 + lq, 2 * t2, gq), dsf, dkacc[dt], 0, 0, 0);
+          dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(dOt, dt * 16 + lq, 2 * t2, gq), pf, dvacc[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (kval) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        bf16x4 ok, ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ok[r] = f2bf(dkacc[dt][r] * scale); ov[r] = f2bf(dvacc[dt][r]); }
+        *reinterpret_cast<bf16x4*>(p.dqkv + (size_t)otok * ld + C + h * 32 + dt * 16 + gq * 4) = ok;
+        *reinterpret_cast<bf16x4*>(p.dqkv + (size_t)otok * ld + 2 * C + h * 32 + dt * 16 + gq * 4) = ov;
+      }
+    }
+  }
+}
+
+// delta[row, h] = sum_d dO[row, h*32+d] * O[row, h*32+d]
+__global__ __launch_bounds__(256) void win_delta_kernel(const bf16* __restrict__ o, const bf16* __restrict__ dout,
+                                                        float* __restrict__ delta, size_t nvec, int H) {
+  for (size_t idx = blockIdx.x * (size_t)256 + threadIdx.x; idx < nvec; idx += (size_t)gridDim.x * 256) {
+    const bf16x8 a = reinterpret_cast<const bf16x8*>(o)[idx], b = reinterpret_cast<const bf16x8*>(dout)[idx];
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += bf2f(a[e]) * bf2f(b[e]);
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    if ((idx & 3) == 0) delta[idx >> 2] = s;           // [row, h] with 4 vectors per head
+  }
+}
+
+// dtable[rel_index(i,j), h] += sum_z part[z, h, i, j]
+__global__ __launch_bounds__(256) void win_dbias_scatter_kernel(const float* __restrict__ part, float* __restrict__ dtable,
+                                                                int nz, int H, int ws) {
+  const int i = blockIdx.x, h = blockIdx.y, N = ws * ws, W2 = 2 * ws - 1;
+  const int pri = i / ws, pci = i - pri * ws;
+  for (int j = threadIdx.x; j < N; j += 256) {
+    float s = 0.f;
+    for (int z = 0; z < nz; ++z) s += part[(((size_t)z * H + h) * N + i) * N + j];
+    const int prj = j / ws, pcj = j - prj * ws;
+    atomicAdd(dtable + (size_t)((pri - prj + ws - 1) * W2 + (pci - pcj + ws - 1)) * H + h, s);
+  }
+}
+
+bool attrs_set = false;
+void ensure_attrs() {
+  if (attrs_set) return;
+  const int big = 160 * 1024;
+  hipFuncSetAttribute((const void*)win_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)win_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)win_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  attrs_set = true;
+}
+
+int blocks_for(int G, int heads) {
+  int nz = 768 / heads;
+  nz = nz < 1 ? 1 : nz;
+  return nz > G ? G : nz;
+}
+
+WinP make(const void* qkv, int B, int Hres, int Wres, int C, int heads, int ws, int shift) {
+  WinP p{};
+  p.qkv = (const bf16*)qkv;
+  p.B = B; p.Hres = Hres; p.Wres = Wres; p.C = C; p.heads = heads; p.ws = ws; p.shift = shift;
+  p.nWw = Wres / ws; p.nWh = Hres / ws; p.nW = p.nWw * p.nWh; p.G = B * p.nW; p.N = ws * ws;
+  const int nz = blocks_for(p.G, heads);
+  p.gpb = cdiv(p.G, nz);
+  return p;
+}
+
+}  // namespace
+
+// Used by attn.hip's C entry points when the window fits the specialised path (head_dim 32, N <= 160).
+int fiber_win_fwd_launch(const void* qkv, const float* bias_table, void* o, float* lse, int B, int Hres, int Wres, int C,
+                         int heads, int ws, int shift, hipStream_t st) {
+  ensure_attrs();
+  WinP p = make(qkv, B, Hres, Wres, C, heads, ws, shift);
+  p.o = (bf16*)o; p.lse = lse; p.bias_table = bias_table;
+  const int nw = cdiv(p.N, 16), nb = (2 * ws - 1) * (2 * ws - 1);
+  hipLaunchKernelGGL(win_fwd_kernel, dim3(cdiv(p.G, p.gpb), heads), dim3(64 * nw), smem_bytes(nb, 1, 1), st, p);
+  FIBER_CHECK_LAUNCH();
+  return FIBER_OK;
+}
+
+int fiber_win_bwd_slices(int n_windows, int heads) {
+  const int nz = blocks_for(n_windows, heads);
+  return cdiv(n_windows, cdiv(n_windows, nz));
+}
+
+int fiber_win_bwd_launch(const void* qkv, const float* bias_table, const void* o, const void* dout, const float* lse,
+                         void* dqkv, float* dbias_table, float* delta_ws, float* dbias_ws, int B, int Hres, int Wres, int C,
+                         int heads, int ws, int shift, hipStream_t st) {
+  ensure_attrs();
+  WinP p = make(qkv, B, Hres, Wres, C, heads, ws, shift);
+  p.o = (bf16*)o; p.lse = (float*)lse; p.bias_table = bias_table; p.dout = (const bf16*)dout; p.dqkv = (bf16*)dqkv;
+  p.delta = delta_ws; p.dbias_part = dbias_ws;
+  const int nw = cdiv(p.N, 16), nb = (2 * ws - 1) * (2 * ws - 1);
+  const size_t nvec = (size_t)B * Hres * Wres * C / 8;
+  size_t g = (nvec + 255) / 256;
+  hipLaunchKernelGGL(win_delta_kernel, dim3((int)(g > 4096 ? 4096 : g)), dim3(256), 0, st, (const bf16*)o, (const bf16*)dout, delta_ws, nvec, heads);
+  FIBER_CHECK_LAUNCH();
+  const int gz = cdiv(p.G, p.gpb);
+  hipLaunchKernelGGL(win_bwd_dq_kernel, dim3(gz, heads), dim3(64 * nw), smem_bytes(nb, 2, 1), st, p);
+  FIBER_CHECK_LAUNCH();
+  if (hipMemsetAsync(dbias_table, 0, (size_t)nb * heads * sizeof(float), st) != hipSuccess) return FIBER_ELAUNCH;
+  hipLaunchKernelGGL(win_dbias_scatter_kernel, dim3(p.N, heads), dim3(256), 0, st, dbias_ws, dbias_table, gz, heads, ws);
+  FIBER_CHECK_LAUNCH();
+  hipLaunchKernelGGL(win_bwd_dkv_kernel, dim3(gz, heads), dim3(64 * nw), smem_bytes(nb, 2, 2), st, p);
+  FIBER_CHECK_LAUNCH();
+  return FIBER_OK;
+}
