@@ -56,7 +56,8 @@ __global__ __launch_bounds__(256) void dot_kernel(const bf16* __restrict__ a, co
   if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
-// column sums of a [M, N] bf16 matrix -> fp32 [N]; block = 32 column-vectors x 8 row lanes, partials via atomics
+// column sums of a [M, N] bf16 matrix -> fp32.  block = 32 column-vectors x 8 row lanes covering 256 columns and one
+// row slab; writes out[blockIdx.y][col] (no atomics, no pre-zeroing); a second pass folds the slabs when gridDim.y > 1.
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, float* __restrict__ out, int M, int N,
                                                      int ld, int rows_per_block) {
   __shared__ float red[8][32 * 8 + 1];
@@ -74,12 +75,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x,
 #pragma unroll
   for (int e = 0; e < 8; ++e) red[rl][cv * 8 + e] = s[e];
   __syncthreads();
-  const int c = threadIdx.x;  // 256 columns handled by this block
+  const int c = threadIdx.x;
   float t = 0.f;
 #pragma unroll
   for (int r = 0; r < 8; ++r) t += red[r][c];
   const int gc = blockIdx.x * 256 + c;
-  if (gc < N) atomicAdd(out + gc, t);
+  if (gc < N) out[(size_t)blockIdx.y * N + gc] = t;
+}
+
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ part, float* __restrict__ out, int slabs, int N) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  float s = 0.f;
+  for (int y = 0; y < slabs; ++y) s += part[(size_t)y * N + c];
+  out[c] = s;
 }
 
 __global__ __launch_bounds__(256) void dropout_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, size_t nvec,
@@ -149,17 +158,29 @@ extern "C" int fiber_dot_bf16(const void* a, const void* b, float* out, long n, 
   return FIBER_OK;
 }
 
-// out[n] += sum_m x[m,n]   (out fp32[N], zero-initialised by the caller); N % 8 == 0
-extern "C" int fiber_colsum_bf16(const void* x, float* out, int M, int N, int ld, hipStream_t stream) {
+// Row slabs the column-sum uses for an [M, N] input: the caller provides a workspace of slabs*N floats when slabs > 1.
+extern "C" int fiber_colsum_slabs(int M, int N) {
+  const int gx = cdiv(N, 256);
+  int gy = cdiv(M, 512);
+  const int cap = cdiv(1024, gx);
+  gy = gy > cap ? cap : gy;
+  return gy < 1 ? 1 : gy;
+}
+
+// out[n] = sum_m x[m,n]   (out fp32[N], overwritten); N % 8 == 0; workspace fp32[slabs*N] (may be NULL when slabs == 1)
+extern "C" int fiber_colsum_bf16(const void* x, float* out, float* workspace, int M, int N, int ld, hipStream_t stream) {
   if (M <= 0 || N <= 0) return FIBER_OK;
   if ((N & 7) || (ld & 7)) return FIBER_EINVAL;
   const int gx = cdiv(N, 256);
-  int gy = cdiv(M, 256);
-  const int cap = cdiv(2048, gx);
-  gy = gy > cap ? cap : gy;
-  const int rpb = cdiv(M, gy);
-  hipLaunchKernelGGL(colsum_kernel, dim3(gx, cdiv(M, rpb)), dim3(256), 0, stream, (const bf16*)x, out, M, N, ld, rpb);
+  const int gy0 = fiber_colsum_slabs(M, N);
+  const int rpb = cdiv(M, gy0), gy = cdiv(M, rpb);
+  if (gy > 1 && !workspace) return FIBER_EINVAL;
+  hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, stream, (const bf16*)x, gy > 1 ? workspace : out, M, N, ld, rpb);
   FIBER_CHECK_LAUNCH();
+  if (gy > 1) {
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, workspace, out, gy, N);
+    FIBER_CHECK_LAUNCH();
+  }
   return FIBER_OK;
 }
 

@@ -23,7 +23,8 @@ constexpr int BK = 64;
 
 struct GemmArgs {
   const bf16* X; const bf16* W; const float* bias; const bf16* R; bf16* Y; bf16* Ypre;
-  int M, N, K, ldx, ldw, ldy, ldr, act;
+  const float* rowscale;   // optional per-sample scale (timm DropPath): row m uses rowscale[m / rows_per_sample]
+  int M, N, K, ldx, ldw, ldy, ldr, act, rows_per_sample;
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row * 8 + (chunk ^ ((row >> 1) & 7))) * 8; }  // element offset
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
   for (int i = 0; i < TM; ++i) {
     const int m = tm0 + wm * WTM + i * 32 + (lane & 31);
     if (m >= a.M) continue;
+    const float rsc = a.rowscale ? a.rowscale[m / a.rows_per_sample] : 1.f;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -144,6 +146,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
         }
+        if (a.rowscale) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= rsc;
+        }
         if (a.R) {
           const bf16x4 r = *reinterpret_cast<const bf16x4*>(a.R + (size_t)m * a.ldr + n);
 #pragma unroll
@@ -161,16 +167,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 }  // namespace
 
 // C ABI ---------------------------------------------------------------------------------------------------------
-// Y = act(X.W^T + bias) + residual.  bias: fp32[N] or NULL; residual: bf16[M,ldr] or NULL; act: 0 none, 1 exact GELU
+// Y = rowscale * act(X.W^T + bias) + residual.  bias: fp32[N] or NULL; residual: bf16[M,ldr] or NULL; act: 0 none, 1 exact GELU;
+// rowscale: fp32[M / rows_per_sample] or NULL (per-sample DropPath factor on the branch, swin_transformer.py:390-391)
 // (Ypre, if non-NULL with act=1, receives the pre-activation for the backward pass).  K % 8 == 0, N % 4 == 0,
 // all leading dimensions multiples of 8 elements (16-byte rows).
 extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bias, const void* residual, void* Y,
-                                  void* Ypre, int M, int N, int K, int ldx, int ldw, int ldy, int ldr, int act,
-                                  hipStream_t stream) {
+                                  void* Ypre, const float* rowscale, int rows_per_sample, int M, int N, int K, int ldx,
+                                  int ldw, int ldy, int ldr, int act, hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0) return FIBER_OK;
   if ((K & 7) || (N & 3) || (ldx & 7) || (ldw & 7) || (ldy & 3) || (residual && (ldr & 3))) return FIBER_EINVAL;
-  GemmArgs a{(const bf16*)X, (const bf16*)W, bias, (const bf16*)residual, (bf16*)Y, (bf16*)Ypre,
-             M, N, K, ldx, ldw, ldy, ldr, act};
+  if (rowscale && rows_per_sample <= 0) return FIBER_EINVAL;
+  GemmArgs a{(const bf16*)X, (const bf16*)W, bias, (const bf16*)residual, (bf16*)Y, (bf16*)Ypre, rowscale,
+             M, N, K, ldx, ldw, ldy, ldr, act, rows_per_sample};
   const long big = (long)cdiv(M, 128) * cdiv(N, 128);
   if (big >= 192) {
     hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), dim3((unsigned)big), dim3(256), 0, stream, a);

@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
 template <int LPR, int NV, bool MERGE>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, bf16* __restrict__ dx,
+                                                     const float* __restrict__ rstd, const bf16* __restrict__ dres,
+                                                     bf16* __restrict__ dx,
                                                      float* __restrict__ part /*[grid*4 waves][2][C]*/, int rows, int C,
                                                      MergeMap mm) {
   constexpr int RPW = 64 / LPR;
@@ -140,10 +141,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
     for (int i = 0; i < NV; ++i) {
       const int vi = gl + i * LPR;
       if (rok && vi < nvec) {
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f2bf(rs * (dg[i][e] - s1 - xh[i][e] * s2));
         const size_t off = MERGE ? mm.src(row, vi * 8) : (size_t)row * C + vi * 8;
+        bf16x8 o;
+        if (dres) {                                      // fused residual-path gradient: dx = LN'(dy) + dres
+          const bf16x8 rr = *reinterpret_cast<const bf16x8*>(dres + off);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = f2bf(rs * (dg[i][e] - s1 - xh[i][e] * s2) + bf2f(rr[e]));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = f2bf(rs * (dg[i][e] - s1 - xh[i][e] * s2));
+        }
         *reinterpret_cast<bf16x8*>(dx + off) = o;
       }
     }
@@ -218,10 +225,10 @@ int launch_fwd(const bf16* x, const float* g, const float* b, bf16* y, float* me
 }
 
 template <bool MERGE>
-int launch_bwd(const bf16* dy, const bf16* x, const float* g, const float* mean, const float* rstd, bf16* dx,
-               float* dgamma, float* dbeta, float* ws, int grid, int rows, int C, MergeMap mm, hipStream_t st) {
+int launch_bwd(const bf16* dy, const bf16* x, const float* g, const float* mean, const float* rstd, const bf16* dres,
+               bf16* dx, float* dgamma, float* dbeta, float* ws, int grid, int rows, int C, MergeMap mm, hipStream_t st) {
 #define BWD(LPR, NV, ...) hipLaunchKernelGGL((ln_bwd_kernel<LPR, NV, MERGE>), dim3(grid), dim3(256), 0, st, __VA_ARGS__)
-  LN_DISPATCH(BWD, dy, x, g, mean, rstd, dx, ws, rows, C, mm);
+  LN_DISPATCH(BWD, dy, x, g, mean, rstd, dres, dx, ws, rows, C, mm);
 #undef BWD
   FIBER_CHECK_LAUNCH();
   if (hipMemsetAsync(dgamma, 0, C * sizeof(float), st) != hipSuccess || hipMemsetAsync(dbeta, 0, C * sizeof(float), st) != hipSuccess)
@@ -249,11 +256,11 @@ extern "C" int fiber_layernorm_fwd_bf16(const void* x, const float* gamma, const
 }
 
 extern "C" int fiber_layernorm_bwd_bf16(const void* dy, const void* x, const float* gamma, const float* mean,
-                                        const float* rstd, void* dx, float* dgamma, float* dbeta, float* workspace,
-                                        int rows, int C, hipStream_t stream) {
+                                        const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                                        float* workspace, int rows, int C, hipStream_t stream) {
   if (rows <= 0) return FIBER_OK;
   if (C & 7) return FIBER_EINVAL;
-  return launch_bwd<false>((const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (bf16*)dx, dgamma, dbeta, workspace,
+  return launch_bwd<false>((const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, workspace,
                            fiber_layernorm_bwd_grid(rows), rows, C, MergeMap{0, 0, 0}, stream);
 }
 
@@ -272,6 +279,6 @@ extern "C" int fiber_patch_merge_ln_bwd_bf16(const void* dy, const void* x, cons
                                              int B, int H, int W, int C, hipStream_t stream) {
   if ((C & 7) || (H & 1) || (W & 1)) return FIBER_EINVAL;
   const int rows = B * (H / 2) * (W / 2);
-  return launch_bwd<true>((const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (bf16*)dx, dgamma, dbeta, workspace,
+  return launch_bwd<true>((const bf16*)dy, (const bf16*)x, gamma, mean, rstd, nullptr, (bf16*)dx, dgamma, dbeta, workspace,
                           fiber_layernorm_bwd_grid(rows), rows, 4 * C, MergeMap{H, W, C}, stream);
 }

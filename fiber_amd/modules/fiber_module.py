@@ -202,10 +202,13 @@ class FIBERTransformerSS(LightningModule):
         if len(self.current_tasks) == 0:
             ret.update(self.infer(batch))
             return ret
-        if "mlm" in self.current_tasks:
-            ret.update(objectives.compute_mlm(self, batch))
-        if "itm" in self.current_tasks:
-            ret.update(objectives.compute_itm(self, batch, batch.get("itm_labels_override")))
+        if ("mlm" in self.current_tasks and "itm" in self.current_tasks and self.config.get("fuse_mlm_itm", True)):
+            ret.update(objectives.compute_mlm_itm_fused(self, batch, batch.get("itm_labels_override")))
+        else:
+            if "mlm" in self.current_tasks:
+                ret.update(objectives.compute_mlm(self, batch))
+            if "itm" in self.current_tasks:
+                ret.update(objectives.compute_itm(self, batch, batch.get("itm_labels_override")))
         if "vqa" in self.current_tasks:
             raise NotImplementedError("VQA fine-tune head is SURVEY.md section 8(f) 'next'")
         return ret

@@ -46,6 +46,44 @@ def compute_itm(pl_module, batch, itm_labels=None):
     return ret
 
 
+def compute_mlm_itm_fused(pl_module, batch, itm_labels=None):
+    """compute_mlm + compute_itm (objectives.py:17-75) evaluated in ONE fused-backbone pass over the 2B concatenated
+    samples [masked-text pairs ; true/false-image pairs].  Every op on the path is per-sample (LayerNorm, window /
+    cross attention, per-sample DropPath), so the two halves are exactly the two separate infer() calls of the
+    reference; one pass halves the kernel-launch count and doubles the GEMM M dimension.  Same return keys."""
+    B = len(batch["text"])
+    pos_len = B // 2
+    if itm_labels is None:
+        itm_labels = torch.cat([torch.ones(pos_len), torch.zeros(B - pos_len)]).to(pl_module.device)
+        itm_labels = itm_labels[torch.randperm(itm_labels.size(0))]
+    else:
+        itm_labels = itm_labels.to(pl_module.device).float()
+    sel = itm_labels.view(-1, 1, 1, 1) == 1
+    true_img, false_img = batch["image"][0], batch["false_image_0"][0]
+    fused = {
+        "image": [torch.cat([true_img, torch.where(sel, true_img, false_img)], 0)],
+        "text_ids": torch.cat([batch["text_ids_mlm"], batch["text_ids"]], 0),
+        "text_labels": torch.cat([batch["text_labels_mlm"], batch["text_labels"]], 0),
+        "text_masks": torch.cat([batch["text_masks"], batch["text_masks"]], 0),
+    }
+    infer = pl_module.infer(fused, mask_text=False, mask_image=False)
+    mlm_logits = pl_module.mlm_score(infer["text_feats"][:B])
+    mlm_labels = batch["text_labels_mlm"]
+    mlm_loss = F.cross_entropy(mlm_logits.view(-1, pl_module.hparams.config["vocab_size"]).float(), mlm_labels.view(-1),
+                               ignore_index=-100)
+    itm_logits = pl_module.itm_score(infer["cls_feats"][B:])
+    itm_loss = F.cross_entropy(itm_logits, itm_labels.long())
+    ret = {"mlm_loss": mlm_loss, "mlm_logits": mlm_logits, "mlm_labels": mlm_labels, "mlm_ids": batch["text_ids_mlm"],
+           "itm_loss": itm_loss, "itm_logits": itm_logits, "itm_labels": itm_labels}
+    phase = "train" if pl_module.training else "val"
+    for task in ("mlm", "itm"):
+        loss = getattr(pl_module, f"{phase}_{task}_loss")(ret[f"{task}_loss"])
+        acc = getattr(pl_module, f"{phase}_{task}_accuracy")(ret[f"{task}_logits"], ret[f"{task}_labels"])
+        pl_module.log(f"{task}/{phase}/loss", loss)
+        pl_module.log(f"{task}/{phase}/accuracy", acc)
+    return ret
+
+
 def init_weights(module):
     if isinstance(module, (nn.Linear, nn.Embedding)):
         module.weight.data.normal_(mean=0.0, std=0.02)

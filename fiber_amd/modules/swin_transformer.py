@@ -78,15 +78,15 @@ class WindowAttention(nn.Module):
             self.alpha_i2t = nn.Parameter(torch.Tensor([0]))
             self.norm_i2t_i = nn.LayerNorm(dim)
 
-    def forward(self, u, res, shift, shortcut=None, y=None, y_mask=None):
-        """u: LayerNorm'ed tokens [B, H*W, C] in image order.  Returns proj(attn) (+ i2t branch) (+ shortcut if given)."""
+    def forward(self, u, res, shift, shortcut=None, y=None, y_mask=None, rowscale=None):
+        """u: LayerNorm'ed tokens [B, H*W, C] in image order.  Returns [rowscale *] (proj(attn) (+ i2t branch)) (+ shortcut)."""
         B, L, C = u.shape
         H, W = res
         ws = self.window_size[0]
         qkv = ops.linear(u, self.qkv.weight, self.qkv.bias)
         o = ops.window_attention(qkv, self.relative_position_bias_table, B, H, W, self.num_heads, ws, shift)
         if y is None:
-            return ops.linear(o, self.proj.weight, self.proj.bias, residual=shortcut)
+            return ops.linear(o, self.proj.weight, self.proj.bias, residual=shortcut, rowscale=rowscale)
         a = ops.linear(o, self.proj.weight, self.proj.bias)
         S = y.shape[1]
         assert y.shape[0] == B, "text batch must match image batch"
@@ -97,6 +97,8 @@ class WindowAttention(nn.Module):
         yi = ops.mha(qi, kv[:, :C], kv[:, C:], km, B, self.num_heads, self.scale)
         yi = ops.linear(yi.view(B, L, C), self.proj_i2t.weight, self.proj_i2t.bias)
         a = ops.scale_add(a, yi, self.alpha_i2t)
+        if rowscale is not None:
+            return ops.rowscale_add(shortcut, a, rowscale)
         return a if shortcut is None else ops.add(shortcut, a)
 
 
@@ -122,16 +124,14 @@ class SwinTransformerBlock(nn.Module):
         B, L, C = x.shape
         assert L == H * W, "input feature has wrong size"
         dp = self.drop_path_rate if self.training else 0.0
-        u = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        if dp == 0.0:
-            x = self.attn(u, (H, W), self.shift_size, shortcut=x, y=y, y_mask=y_mask)
-        else:
-            x = ops.drop_path_add(x, self.attn(u, (H, W), self.shift_size, y=y, y_mask=y_mask), dp, True)
-        h = ops.linear(ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps),
-                       self.mlp.fc1.weight, self.mlp.fc1.bias, act="gelu")
-        if dp == 0.0:
-            return ops.linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=x)
-        return ops.drop_path_add(x, ops.linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias), dp, True)
+        # two independent DropPath draws per block (swin_transformer.py:390-391), folded into the GEMM epilogues
+        s1 = ops.drop_path_scale(B, dp, x.device) if dp > 0.0 else None
+        s2 = ops.drop_path_scale(B, dp, x.device) if dp > 0.0 else None
+        u, x = ops.layernorm_res(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x = self.attn(u, (H, W), self.shift_size, shortcut=x, y=y, y_mask=y_mask, rowscale=s1)
+        v, x = ops.layernorm_res(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        h = ops.linear(v, self.mlp.fc1.weight, self.mlp.fc1.bias, act="gelu")
+        return ops.linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=x, rowscale=s2)
 
 
 class PatchMerging(nn.Module):

@@ -44,7 +44,7 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def gemm_nt(x2, wb, bias=None, residual=None, act=0, want_pre=False):
+def gemm_nt(x2, wb, bias=None, residual=None, act=0, want_pre=False, rowscale=None, rows_per_sample=0):
     """y = act(x2 @ wb^T + bias) + residual  on the HIP kernel.  x2 [M,K] bf16 (row stride may exceed K)."""
     M, K = x2.shape
     N = wb.shape[0]
@@ -52,13 +52,17 @@ def gemm_nt(x2, wb, bias=None, residual=None, act=0, want_pre=False):
     y = torch.empty((M, N), dtype=BF16, device=x2.device)
     pre = torch.empty((M, N), dtype=BF16, device=x2.device) if (want_pre and act) else None
     lib.call("fiber_gemm_nt_bf16", lib.ptr(x2), lib.ptr(wb), lib.ptr(bias), lib.ptr(residual), lib.ptr(y), lib.ptr(pre),
-             M, N, K, x2.stride(0), wb.stride(0), N, residual.stride(0) if residual is not None else 0, act)
+             lib.ptr(rowscale), rows_per_sample, M, N, K, x2.stride(0), wb.stride(0), N,
+             residual.stride(0) if residual is not None else 0, act)
     return y, pre
 
 
 def colsum(x2):
-    out = torch.zeros(x2.shape[1], dtype=torch.float32, device=x2.device)
-    lib.call("fiber_colsum_bf16", lib.ptr(x2), lib.ptr(out), x2.shape[0], x2.shape[1], x2.stride(0))
+    M, N = x2.shape
+    out = torch.empty(N, dtype=torch.float32, device=x2.device)
+    slabs = lib.plain("fiber_colsum_slabs", M, N)
+    ws = torch.empty(slabs * N, dtype=torch.float32, device=x2.device) if slabs > 1 else None
+    lib.call("fiber_colsum_bf16", lib.ptr(x2), lib.ptr(out), lib.ptr(ws), M, N, x2.stride(0))
     return out
 
 
@@ -92,22 +96,28 @@ def wgrad(dh, x2):
 
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, act):
+    def forward(ctx, x, weight, bias, residual, act, rowscale):
         shp = x.shape
         x2 = _c(x).view(-1, shp[-1])
         wb = bf16_weight(weight)
         r2 = _c(residual).view(-1, weight.shape[0]) if residual is not None else None
         need_pre = bool(act) and any(ctx.needs_input_grad[:3])
-        y, pre = gemm_nt(x2, wb, bias, r2, act, need_pre)
-        ctx.save_for_backward(x2, weight, pre)
+        rps = (x2.shape[0] // rowscale.numel()) if rowscale is not None else 0
+        y, pre = gemm_nt(x2, wb, bias, r2, act, need_pre, rowscale, rps)
+        ctx.save_for_backward(x2, weight, pre, rowscale)
         ctx.act, ctx.has_bias, ctx.has_res, ctx.shp = act, bias is not None, residual is not None, shp
         return y.view(*shp[:-1], weight.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        x2, weight, pre = ctx.saved_tensors
+        x2, weight, pre, rowscale = ctx.saved_tensors
         dy2 = _c(dy).view(-1, weight.shape[0])
         dres = dy if ctx.has_res else None
+        if rowscale is not None:                      # branch gradient = per-sample scale * dy
+            ds = torch.empty_like(dy2)
+            lib.call("fiber_rowscale_add_bf16", None, lib.ptr(dy2), lib.ptr(rowscale), lib.ptr(ds), dy2.numel(),
+                     dy2.numel() // rowscale.numel())
+            dy2 = ds
         if ctx.act:
             dh = torch.empty_like(dy2)
             lib.call("fiber_gelu_bwd_bf16", lib.ptr(dy2), lib.ptr(pre), lib.ptr(dh), dy2.numel())
@@ -117,10 +127,10 @@ class _Linear(torch.autograd.Function):
         dx = torch.matmul(dh, wb).view(ctx.shp) if ctx.needs_input_grad[0] else None
         dw = wgrad(dh, x2) if ctx.needs_input_grad[1] else None
         db = colsum(dh) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return dx, dw, db, dres, None
+        return dx, dw, db, dres, None, None
 
 
-def linear(x, weight, bias=None, residual=None, act=None):
+def linear(x, weight, bias=None, residual=None, act=None, rowscale=None):
     """nn.Linear with fused bias / exact GELU / residual.  Falls back to a library GEMM only for shapes the tile
     kernel does not cover (N % 4 != 0, e.g. the 2-way ITM head, or K % 8 != 0)."""
     N, K = weight.shape
@@ -128,8 +138,9 @@ def linear(x, weight, bias=None, residual=None, act=None):
         y = torch.nn.functional.linear(x, weight.to(BF16), bias.to(BF16) if bias is not None else None)
         if act:
             y = torch.nn.functional.gelu(y)
+        assert rowscale is None
         return y + residual if residual is not None else y
-    return _Linear.apply(x, weight, bias, residual, 1 if act else 0)
+    return _Linear.apply(x, weight, bias, residual, 1 if act else 0, rowscale)
 
 
 class _LayerNorm(torch.autograd.Function):
@@ -154,13 +165,51 @@ class _LayerNorm(torch.autograd.Function):
         dg = torch.empty(C, dtype=torch.float32, device=dy.device)
         db = torch.empty_like(dg)
         ws = torch.empty(lib.plain("fiber_layernorm_bwd_grid", rows) * 8 * C, dtype=torch.float32, device=dy.device)
-        lib.call("fiber_layernorm_bwd_bf16", lib.ptr(dy2), lib.ptr(x2), lib.ptr(gamma), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dx),
+        lib.call("fiber_layernorm_bwd_bf16", lib.ptr(dy2), lib.ptr(x2), lib.ptr(gamma), lib.ptr(mean), lib.ptr(rstd), None, lib.ptr(dx),
                  lib.ptr(dg), lib.ptr(db), lib.ptr(ws), rows, C)
         return dx.view(dy.shape), dg, db, None
 
 
 def layernorm(x, gamma, beta, eps=1e-5):
     return _LayerNorm.apply(x, gamma, beta, eps)
+
+
+class _LayerNormRes(torch.autograd.Function):
+    """(LN(x), x): the second output is x itself, to be used for the residual connection.  Its incoming gradient is
+    added inside the LayerNorm backward kernel, so autograd never launches a separate activation-sized add."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        C = x.shape[-1]
+        x2 = _c(x).view(-1, C)
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        lib.call("fiber_layernorm_fwd_bf16", lib.ptr(x2), lib.ptr(gamma), lib.ptr(beta), lib.ptr(y), lib.ptr(mean), lib.ptr(rstd), rows, C, eps)
+        ctx.save_for_backward(x2, gamma, mean, rstd)
+        return y.view(x.shape), x2.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        x2, gamma, mean, rstd = ctx.saved_tensors
+        rows, C = x2.shape
+        if dy is None:
+            return dres, None, None, None
+        dy2 = _c(dy).view(rows, C)
+        dr2 = _c(dres).view(rows, C) if dres is not None else None
+        dx = torch.empty_like(x2)
+        dg = torch.empty(C, dtype=torch.float32, device=dy.device)
+        db = torch.empty_like(dg)
+        ws = torch.empty(lib.plain("fiber_layernorm_bwd_grid", rows) * 8 * C, dtype=torch.float32, device=dy.device)
+        lib.call("fiber_layernorm_bwd_bf16", lib.ptr(dy2), lib.ptr(x2), lib.ptr(gamma), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dr2),
+                 lib.ptr(dx), lib.ptr(dg), lib.ptr(db), lib.ptr(ws), rows, C)
+        return dx.view(dy.shape), dg, db, None
+
+
+def layernorm_res(x, gamma, beta, eps=1e-5):
+    """Returns (LN(x), x_for_residual)."""
+    return _LayerNormRes.apply(x, gamma, beta, eps)
 
 
 class _PatchMergeLN(torch.autograd.Function):
@@ -373,15 +422,23 @@ class _RowScaleAdd(torch.autograd.Function):
         return dout, dx, None
 
 
+def drop_path_scale(batch, p, device):
+    """timm 0.4.12 DropPath factor per sample: floor(keep + U[0,1)) / keep (fp32 [batch])."""
+    keep = 1.0 - p
+    g = torch.Generator(device=device)
+    g.manual_seed(next_seed() & 0x7FFFFFFFFFFFFFFF)
+    return (torch.floor(keep + torch.rand(batch, device=device, generator=g)) / keep).float()
+
+
+def rowscale_add(resid, x, scale):
+    return _RowScaleAdd.apply(resid, x, scale)
+
+
 def drop_path_add(resid, x, p, training):
     """resid + DropPath_p(x): timm 0.4.12 per-sample mask floor(keep + U[0,1)) scaled by 1/keep."""
     if not training or p <= 0.0:
-        return resid + x
-    keep = 1.0 - p
-    g = torch.Generator(device=x.device)
-    g.manual_seed(next_seed() & 0x7FFFFFFFFFFFFFFF)
-    scale = torch.floor(keep + torch.rand(x.shape[0], device=x.device, generator=g)) / keep
-    return _RowScaleAdd.apply(resid, x, scale.float())
+        return add(resid, x)
+    return _RowScaleAdd.apply(resid, x, drop_path_scale(x.shape[0], p, x.device))
 
 
 class _RobertaEmbed(torch.autograd.Function):

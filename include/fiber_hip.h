@@ -19,19 +19,22 @@ extern "C" {
 #endif
 typedef struct ihipStream_t* fiber_stream_t;
 
-/* nn.Linear (+bias, +exact-erf GELU, +residual) : Y = act(X.W^T + bias) + R
+/* nn.Linear (+bias, +exact-erf GELU, +per-sample DropPath scale, +residual) : Y = rowscale*act(X.W^T + bias) + R
  * replaces: swin_transformer.py:197,221,233,238,257 (qkv/proj/i2t linears), timm Mlp fc1/fc2 (:325), PatchMerging.reduction
  * (:431), roberta.py:231-241,337,398,415, fiber_module.py:349-350.  act: 0 none, 1 GELU (Ypre, if non-NULL, gets the
  * pre-activation).  Requires K%8==0, N%4==0, ldx/ldw%8==0, ldy/ldr%4==0. */
-int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bias, const void* residual, void* Y, void* Ypre, int M,
-                       int N, int K, int ldx, int ldw, int ldy, int ldr, int act, fiber_stream_t stream);
+int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bias, const void* residual, void* Y, void* Ypre,
+                       const float* rowscale, int rows_per_sample, int M, int N, int K, int ldx, int ldw, int ldy, int ldr,
+                       int act, fiber_stream_t stream);
 
 /* nn.LayerNorm over the last dim (C%8==0, C<=4096); saves mean/rstd.  replaces swin_transformer.py:362,391,244; roberta.py:485,422 */
 int fiber_layernorm_fwd_bf16(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int rows,
                              int C, float eps, fiber_stream_t stream);
 int fiber_layernorm_bwd_grid(int rows); /* workspace = grid*8*C floats */
-int fiber_layernorm_bwd_bf16(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
-                             float* dgamma, float* dbeta, float* workspace, int rows, int C, fiber_stream_t stream);
+/* dres (nullable): gradient arriving on the residual path of the same x; fused: dx = LN'(dy) + dres */
+int fiber_layernorm_bwd_bf16(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                             const void* dres, void* dx, float* dgamma, float* dbeta, float* workspace, int rows, int C,
+                             fiber_stream_t stream);
 
 /* PatchMerging gather+concat+LayerNorm (swin_transformer.py:411-430): x [B,H*W,C] -> y [B,H*W/4,4C] */
 int fiber_patch_merge_ln_fwd_bf16(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int B,
@@ -76,7 +79,8 @@ int fiber_im2col_patch4(const float* img, void* cols, int B, int H, int W, fiber
 int fiber_gelu_bwd_bf16(const void* dgelu, const void* h_pre, void* dh, long n, fiber_stream_t stream);
 int fiber_scale_add_bf16(const void* a, const void* b, const float* alpha, float mult, void* out, long n, fiber_stream_t stream);
 int fiber_dot_bf16(const void* a, const void* b, float* out, long n, fiber_stream_t stream);
-int fiber_colsum_bf16(const void* x, float* out, int M, int N, int ld, fiber_stream_t stream);
+int fiber_colsum_slabs(int M, int N); /* workspace = slabs*N floats when slabs > 1 */
+int fiber_colsum_bf16(const void* x, float* out, float* workspace, int M, int N, int ld, fiber_stream_t stream);
 int fiber_dropout_bf16(const void* x, void* y, long n, float p, uint64_t seed, fiber_stream_t stream);
 int fiber_rowscale_add_bf16(const void* r, const void* x, const float* scale, void* out, long n, long per_sample,
                             fiber_stream_t stream);

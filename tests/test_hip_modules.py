@@ -191,3 +191,28 @@ def test_training_mode_runs_with_dropout():
         gsum = sum(p.grad.double().abs().sum().item() for p in model.parameters() if p.grad is not None)
         assert np.isfinite(loss.item()) and np.isfinite(gsum)
     assert losses[0] == losses[1]
+
+
+def test_fused_mlm_itm_pass_equals_two_passes():
+    """One 2B-sample backbone pass (compute_mlm_itm_fused) gives the same losses / gradients as the reference's two
+    separate infer() calls (compute_mlm + compute_itm)."""
+    from fiber_amd.config import make_config
+    from fiber_amd.modules import FIBERTransformerSS, fiber_utils, objectives
+    ref = detgen.fill_(R.FiberRef(cases.TINY).eval())
+    model = FIBERTransformerSS(make_config(**cases.TINY)).eval()
+    load_from_oracle(model, ref)
+    model.to(DEV)
+    fiber_utils.set_task(model)
+    b = detgen.synth_batch(4, 96, 12, 1000, seed=5, min_len=6)
+    bd = _to_dev(b)
+    two = objectives.compute_mlm(model, bd)["mlm_loss"] + objectives.compute_itm(model, bd, itm_labels=b["itm_labels"])["itm_loss"]
+    two.backward()
+    g2 = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad(set_to_none=True)
+    out = objectives.compute_mlm_itm_fused(model, bd, itm_labels=b["itm_labels"])
+    one = out["mlm_loss"] + out["itm_loss"]
+    one.backward()
+    assert abs(one.item() - two.item()) < 2e-3, (one.item(), two.item())
+    for n in ("vit_model.layers.2.blocks.15.attn.qkv.weight", "text_transformer.encoder.layer.7.intermediate.dense.weight",
+              "vit_model.layers.3.blocks.1.attn.alpha_i2t", "vit_model.patch_embed.proj.weight"):
+        assert rel_l2(dict(model.named_parameters())[n].grad, g2[n]) < 2e-2, n
