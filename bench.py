@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("FIBER_BENCH_BATCH", "32")), help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("FIBER_BENCH_BATCH", "64")), help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -116,9 +116,8 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+    from fiber_amd import parallel
+    parallel.init_distributed("nccl")
 
     from fiber_amd import lib, ops
     from fiber_amd.config import make_config
@@ -131,17 +130,11 @@ def main():
     for n, p in model.named_parameters():
         if "alpha_" in n:
             p.data.fill_(0.5)          # reference init is 0: fusion branches would carry no signal
-    unused = set(model.unused_parameter_names())
-    for n, p in model.named_parameters():
-        if n in unused:
-            p.requires_grad_(False)    # never touched on the MLM+ITM fused path -> keep DDP's reducer static
+    parallel.freeze_unused(model, model.unused_parameter_names())   # never touched on the fused MLM+ITM path
     model.to(device).train()
     fiber_utils.set_task(model)
     (opt,), (sched,) = model.configure_optimizers()
-    net = model
-    if world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], broadcast_buffers=False,
-                                                        gradient_as_bucket_view=True, bucket_cap_mb=64)
+    net = parallel.wrap_ddp(model, device)
     batch = synth_batch(args.batch, cfg["image_size"], cfg["max_text_len"], cfg["vocab_size"], device, seed=rank)
 
     def step():

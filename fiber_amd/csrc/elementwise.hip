@@ -84,11 +84,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x,
 }
 
 __global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ part, float* __restrict__ out, int slabs, int N) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= N) return;
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float s = 0.f;
-  for (int y = 0; y < slabs; ++y) s += part[(size_t)y * N + c];
-  out[c] = s;
+  if (c < N)
+    for (int y = rl; y < slabs; y += 4) s += part[(size_t)y * N + c];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < N) out[c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
 }
 
 __global__ __launch_bounds__(256) void dropout_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, size_t nvec,
@@ -162,7 +166,8 @@ extern "C" int fiber_dot_bf16(const void* a, const void* b, float* out, long n, 
 extern "C" int fiber_colsum_slabs(int M, int N) {
   const int gx = cdiv(N, 256);
   int gy = cdiv(M, 512);
-  const int cap = cdiv(1024, gx);
+  int cap = cdiv(1024, gx);
+  cap = cap > 256 ? 256 : cap;
   gy = gy > cap ? cap : gy;
   return gy < 1 ? 1 : gy;
 }
@@ -178,7 +183,7 @@ extern "C" int fiber_colsum_bf16(const void* x, float* out, float* workspace, in
   hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, stream, (const bf16*)x, gy > 1 ? workspace : out, M, N, ld, rpb);
   FIBER_CHECK_LAUNCH();
   if (gy > 1) {
-    hipLaunchKernelGGL(colsum_fold_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, workspace, out, gy, N);
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3(cdiv(N, 64)), dim3(256), 0, stream, workspace, out, gy, N);
     FIBER_CHECK_LAUNCH();
   }
   return FIBER_OK;

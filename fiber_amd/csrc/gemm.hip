@@ -15,6 +15,8 @@
 // The MFMA is issued with swapped operands (D^T = W.X^T) so each lane owns 4 consecutive output columns and the
 // epilogue (bias, exact-erf GELU, residual, optional pre-activation copy) reads/writes 8-byte vectors.
 // Workgroup ids are remapped so that consecutive tiles of one X row-panel land on the same XCD (shared L2).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -164,6 +166,165 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// v2: same tile / MFMA structure, but (1) operands go global -> LDS directly (global_load_lds_dwordx4: no VGPR round
+// trip, no ds_write issue cost -- rocprof + the LDS budget showed v1 LDS-bound: 32 KB of ds_write_b128 per K tile cost
+// ~415 LDS cycles next to 512 MFMA cycles); the XOR swizzle moves to the per-lane SOURCE address because the DMA writes
+// lane-linear (wave base + lane*16 B); (2) the epilogue is staged through LDS so that every global store / residual
+// load is a full 16-byte, row-contiguous access (v1's per-lane 8-byte stores touched 32 rows per instruction and held
+// the HBM-bound stage-0/1 GEMMs at ~50 % of the bandwidth roofline).  Requires K % 64 == 0 and N % 8 == 0.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmArgs a) {
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int PA = BM / 32, PB = BN / 32;
+  constexpr int CLD = BN + 8;                          // epilogue tile row stride (elements)
+  static_assert(BM * CLD <= 2 * (BM + BN) * BK, "epilogue tile must fit in the operand buffers");
+  __shared__ __attribute__((aligned(16))) bf16 smem[2 * (BM + BN) * BK];
+  bf16* As = smem;                                     // [2][BM*BK]
+  bf16* Bs = smem + 2 * BM * BK;                       // [2][BN*BK]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tilesN = (a.N + BN - 1) / BN, tilesM = (a.M + BM - 1) / BM;
+  const int nblk = tilesM * tilesN;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm0 = (bid / tilesN) * BM, tn0 = (bid % tilesN) * BN;
+
+  // DMA slot of this lane in pass p: tile row = p*32 + wave*8 + (lane>>3), physical chunk = lane&7
+  const int srow = wave * 8 + (lane >> 3), spc = lane & 7;
+  const bf16* xsrc[PA];
+  const bf16* wsrc[PB];
+#pragma unroll
+  for (int p = 0; p < PA; ++p) {
+    const int row = srow + p * 32;
+    int r = tm0 + row;
+    r = r < a.M ? r : a.M - 1;
+    xsrc[p] = a.X + (size_t)r * a.ldx + ((spc ^ ((row >> 1) & 7)) << 3);
+  }
+#pragma unroll
+  for (int p = 0; p < PB; ++p) {
+    const int row = srow + p * 32;
+    int r = tn0 + row;
+    r = r < a.N ? r : a.N - 1;
+    wsrc[p] = a.W + (size_t)r * a.ldw + ((spc ^ ((row >> 1) & 7)) << 3);
+  }
+  auto dma = [&](int kt, int buf) {
+#pragma unroll
+    for (int p = 0; p < PA; ++p)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[p] + kt * BK),
+                                       (__attribute__((address_space(3))) void*)(As + buf * BM * BK + (p * 32 + wave * 8) * BK), 16, 0, 0);
+#pragma unroll
+    for (int p = 0; p < PB; ++p)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[p] + kt * BK),
+                                       (__attribute__((address_space(3))) void*)(Bs + buf * BN * BK + (p * 32 + wave * 8) * BK), 16, 0, 0);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = a.K / BK;
+  dma(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int frow = lane & 31, fk = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) dma(kt + 1, cur ^ 1);             // in flight while this tile's MFMAs run
+    const bf16* Ac = As + cur * BM * BK;
+    const bf16* Bc = Bs + cur * BN * BK;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(Ac + swz(wm * WTM + i * 32 + frow, ks * 2 + fk));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(Bc + swz(wn * WTN + j * 32 + frow, ks * 2 + fk));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: registers -> LDS tile (bf16) -> coalesced 16-byte rows ------------------------------------------
+  bf16* Cs = smem;
+  constexpr int CPR = BN / 8;                           // 16-byte chunks per tile row
+  constexpr int RPP = 256 / CPR;                        // tile rows per store pass
+  const int erow = tid / CPR, echunk = tid % CPR;
+  auto stage_tile = [&](bool pre) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int ml = wm * WTM + i * 32 + (lane & 31);
+      const int m = tm0 + ml;
+      const float rsc = (!pre && a.rowscale && m < a.M) ? a.rowscale[m / a.rows_per_sample] : 1.f;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int nl = wn * WTN + j * 32 + q * 8 + (lane >> 5) * 4;
+          const int n = tn0 + nl;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
+          if (a.bias && n < a.N) {
+            const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+          }
+          if (!pre) {
+            if (a.act == 1) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= rsc;
+          }
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+          *reinterpret_cast<bf16x4*>(Cs + ml * CLD + nl) = o;
+        }
+    }
+  };
+  auto store_tile = [&](bf16* dst, bool add_res) {
+#pragma unroll
+    for (int r0 = 0; r0 < BM; r0 += RPP) {
+      const int ml = r0 + erow, m = tm0 + ml, n = tn0 + echunk * 8;
+      if (m < a.M && n < a.N) {
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(Cs + ml * CLD + echunk * 8);
+        if (add_res) {
+          const bf16x8 r = *reinterpret_cast<const bf16x8*>(a.R + (size_t)m * a.ldr + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(r[e]));
+        }
+        *reinterpret_cast<bf16x8*>(dst + (size_t)m * a.ldy + n) = v;
+      }
+    }
+  };
+  if (a.act == 1 && a.Ypre) {
+    stage_tile(true);
+    __syncthreads();
+    store_tile(a.Ypre, false);
+    __syncthreads();
+  }
+  stage_tile(false);
+  __syncthreads();
+  store_tile(a.Y, a.R != nullptr);
+}
+
 }  // namespace
 
 // C ABI ---------------------------------------------------------------------------------------------------------
@@ -180,11 +341,14 @@ extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bia
   GemmArgs a{(const bf16*)X, (const bf16*)W, bias, (const bf16*)residual, (bf16*)Y, (bf16*)Ypre, rowscale,
              M, N, K, ldx, ldw, ldy, ldr, act, rows_per_sample};
   const long big = (long)cdiv(M, 128) * cdiv(N, 128);
+  const bool v2 = (K % 64 == 0) && (N % 8 == 0) && (ldy % 8 == 0) && (!residual || ldr % 8 == 0) && !getenv("FIBER_GEMM_V1");
   if (big >= 192) {
-    hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), dim3((unsigned)big), dim3(256), 0, stream, a);
+    if (v2) hipLaunchKernelGGL((gemm_nt_glds_kernel<128, 128>), dim3((unsigned)big), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), dim3((unsigned)big), dim3(256), 0, stream, a);
   } else {
     const long small = (long)cdiv(M, 64) * cdiv(N, 64);
-    hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), dim3((unsigned)small), dim3(256), 0, stream, a);
+    if (v2) hipLaunchKernelGGL((gemm_nt_glds_kernel<64, 64>), dim3((unsigned)small), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), dim3((unsigned)small), dim3(256), 0, stream, a);
   }
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;

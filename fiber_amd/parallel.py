@@ -1,0 +1,44 @@
+"""Data-parallel wiring for the fused path: one process per GPU, RCCL (backend "nccl") over xGMI.
+
+The reference trains with Lightning DDP (`pl.Trainer(accelerator="ddp")`, coarse_grained/run.py:50-54), i.e. bucketed
+gradient all-reduce overlapped with backward.  The only collective on this path is that all-reduce.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Initialise torch.distributed from torchrun's env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, local, world
+
+
+def freeze_unused(model, names):
+    """requires_grad=False for parameters that never get a gradient on the fused path, so DDP's reducer is static
+    (find_unused_parameters=False) and no bucket waits for a gradient that never comes."""
+    names = set(names)
+    n = 0
+    for k, p in model.named_parameters():
+        if k in names:
+            p.requires_grad_(False)
+            n += 1
+    return n
+
+
+def wrap_ddp(model, device=None, bucket_cap_mb=64):
+    """DistributedDataParallel with bucket views (gradients are written straight into the all-reduce buckets)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return model
+    ids = [device.index] if (device is not None and device.type == "cuda") else None
+    return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, broadcast_buffers=False,
+                                                     gradient_as_bucket_view=True, bucket_cap_mb=bucket_cap_mb)

@@ -1,0 +1,102 @@
+"""CPU, world_size 2, gloo: the data-parallel wiring used by bench.py (fiber_amd/parallel.py).
+
+The HIP path cannot run without a GPU, so the DP logic is exercised with a small plain-torch module that has the same
+structure hazards as the real one: a parameter that is never used (must be frozen for a static reducer) and a parameter
+used twice per step.  Checks: averaged gradients == single-process gradients over the concatenated batch, and weights
+stay identical across ranks after optimizer steps."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+class Toy(nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.a = nn.Linear(8, 16)
+        self.b = nn.Linear(16, 4)
+        self.unused = nn.Linear(4, 4)          # like vit_model.norm / text pooler on the fused path
+
+    def forward(self, batch):
+        h = torch.tanh(self.a(batch["x"]))
+        h2 = torch.tanh(self.a(batch["x2"]))   # shared weights used twice (MLM + ITM passes)
+        return {"loss": (self.b(h) - batch["y"]).pow(2).mean() + self.b(h2).pow(2).mean()}
+
+
+def _data(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    return {"x": torch.randn(n, 8, generator=g), "x2": torch.randn(n, 8, generator=g), "y": torch.randn(n, 4, generator=g)}
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from fiber_amd import parallel
+    r, _, w = parallel.init_distributed("gloo")
+    assert (r, w) == (rank, world)
+    m = Toy()
+    assert parallel.freeze_unused(m, ["unused.weight", "unused.bias"]) == 2
+    net = parallel.wrap_ddp(m)
+    opt = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=0.1)
+    full = _data(8, 1)
+    shard = {k: v[rank * 4:(rank + 1) * 4] for k, v in full.items()}
+    net(shard)["loss"].backward()
+    grads = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    opt.step()
+    flat = torch.cat([p.detach().flatten() for p in m.parameters()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        torch.save({"grads": grads, "same": bool(torch.equal(gathered[0], gathered[1]))}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_gradients_match_single_process(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    res = torch.load(out)
+    assert res["same"], "weights diverged across ranks"
+    ref = Toy()
+    ref(_data(8, 1))["loss"].backward()
+    for k, p in ref.named_parameters():
+        if k.startswith("unused"):
+            assert k not in res["grads"]
+            continue
+        torch.testing.assert_close(res["grads"][k], p.grad, rtol=1e-5, atol=1e-6)
+
+
+def test_unused_parameter_list_is_consistent_with_reference_golden(golden):
+    """unused_parameter_names() == the parameters that received no gradient in the REFERENCE run (golden fixture)."""
+    from fiber_amd.config import make_config
+    from fiber_amd.modules import FIBERTransformerSS
+    from oracle import cases
+    for name in ("path_tiny", "path_swin_t"):
+        pc, gold = cases.PATH_CASES[name], golden(name)
+        m = FIBERTransformerSS(make_config(**pc["config"]))
+        mine = {n for n in m.unused_parameter_names() if not n.startswith("rank_output.")}
+        ref = {n for n in gold["unused_params"].tolist() if not n.startswith("rank_output.")}
+        assert mine == ref, (sorted(mine - ref)[:5], sorted(ref - mine)[:5])
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The shared library loads on a CPU-only host and exports every function include/fiber_hip.h declares."""
+    import re
+    from fiber_amd import lib
+    if not os.path.isfile(lib.LIB_PATH):
+        pytest.skip("libfiber_hip.so not built (run __graft_entry__.build())")
+    l = lib.load()
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "fiber_hip.h")).read()
+    declared = set(re.findall(r"\bint\s+(fiber_\w+)\s*\(", hdr))
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(l, name), f"{name} declared in fiber_hip.h but not exported"
+    assert declared == set(lib.exported_symbols()), declared ^ set(lib.exported_symbols())
