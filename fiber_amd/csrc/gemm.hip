@@ -173,19 +173,21 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 // lane-linear (wave base + lane*16 B); (2) the epilogue is staged through LDS so that every global store / residual
 // load is a full 16-byte, row-contiguous access (v1's per-lane 8-byte stores touched 32 rows per instruction and held
 // the HBM-bound stage-0/1 GEMMs at ~50 % of the bandwidth roofline).  Requires K % 64 == 0 and N % 8 == 0.
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmArgs a) {
-  constexpr int WTM = BM / 2, WTN = BN / 2;
+template <int BM, int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_glds_kernel(GemmArgs a) {
+  constexpr int NT = 64 * WM * WN;                     // threads per workgroup
+  constexpr int WTM = BM / WM, WTN = BN / WN;          // per-wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int PA = BM / 32, PB = BN / 32;
+  constexpr int RPD = NT / 8;                          // tile rows covered by one DMA pass (8 lanes x 16 B per 128-B row)
+  constexpr int PA = BM / RPD, PB = BN / RPD;
   constexpr int CLD = BN + 8;                          // epilogue tile row stride (elements)
-  static_assert(BM * CLD <= 2 * (BM + BN) * BK, "epilogue tile must fit in the operand buffers");
-  __shared__ __attribute__((aligned(16))) bf16 smem[2 * (BM + BN) * BK];
-  bf16* As = smem;                                     // [2][BM*BK]
-  bf16* Bs = smem + 2 * BM * BK;                       // [2][BN*BK]
+  static_assert(BM * CLD <= NS * (BM + BN) * BK, "epilogue tile must fit in the operand buffers");
+  __shared__ __attribute__((aligned(16))) bf16 smem[NS * (BM + BN) * BK];
+  bf16* As = smem;                                     // [NS][BM*BK]
+  bf16* Bs = smem + NS * BM * BK;                      // [NS][BN*BK]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int tilesN = (a.N + BN - 1) / BN, tilesM = (a.M + BM - 1) / BM;
   const int nblk = tilesM * tilesN;
   int bid = blockIdx.x;
@@ -195,33 +197,36 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmArgs a) {
   }
   const int tm0 = (bid / tilesN) * BM, tn0 = (bid % tilesN) * BN;
 
-  // DMA slot of this lane in pass p: tile row = p*32 + wave*8 + (lane>>3), physical chunk = lane&7
+  // DMA slot of this lane in pass p: tile row = p*RPD + wave*8 + (lane>>3), physical chunk = lane&7
   const int srow = wave * 8 + (lane >> 3), spc = lane & 7;
   const bf16* xsrc[PA];
   const bf16* wsrc[PB];
 #pragma unroll
   for (int p = 0; p < PA; ++p) {
-    const int row = srow + p * 32;
+    const int row = srow + p * RPD;
     int r = tm0 + row;
     r = r < a.M ? r : a.M - 1;
     xsrc[p] = a.X + (size_t)r * a.ldx + ((spc ^ ((row >> 1) & 7)) << 3);
   }
 #pragma unroll
   for (int p = 0; p < PB; ++p) {
-    const int row = srow + p * 32;
+    const int row = srow + p * RPD;
     int r = tn0 + row;
     r = r < a.N ? r : a.N - 1;
     wsrc[p] = a.W + (size_t)r * a.ldw + ((spc ^ ((row >> 1) & 7)) << 3);
   }
+  // one DMA instruction (1 KiB per wave): index d in [0, PA+PB) selects the operand and pass
+  auto dma1 = [&](int d, int kt, int buf) {
+    if (d < PA)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[d < PA ? d : 0] + kt * BK),
+                                       (__attribute__((address_space(3))) void*)(As + buf * BM * BK + (d * RPD + wave * 8) * BK), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[d >= PA ? d - PA : 0] + kt * BK),
+                                       (__attribute__((address_space(3))) void*)(Bs + buf * BN * BK + ((d - PA) * RPD + wave * 8) * BK), 16, 0, 0);
+  };
   auto dma = [&](int kt, int buf) {
 #pragma unroll
-    for (int p = 0; p < PA; ++p)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[p] + kt * BK),
-                                       (__attribute__((address_space(3))) void*)(As + buf * BM * BK + (p * 32 + wave * 8) * BK), 16, 0, 0);
-#pragma unroll
-    for (int p = 0; p < PB; ++p)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[p] + kt * BK),
-                                       (__attribute__((address_space(3))) void*)(Bs + buf * BN * BK + (p * 32 + wave * 8) * BK), 16, 0, 0);
+    for (int d = 0; d < PA + PB; ++d) dma1(d, kt, buf);
   };
 
   f32x16 acc[TM][TN];
@@ -233,37 +238,77 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = a.K / BK;
-  dma(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
   const int frow = lane & 31, fk = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) dma(kt + 1, cur ^ 1);             // in flight while this tile's MFMAs run
-    const bf16* Ac = As + cur * BM * BK;
-    const bf16* Bc = Bs + cur * BN * BK;
+  const bool dbg_nodma = a.act & 0x100;                // ablation switch (tools/gemm_probe.py)
+  constexpr int KS = BK / 16;
+  constexpr int DPK = (PA + PB + KS - 2) / (KS - 1);   // DMA instructions issued per k-step (spread over the first KS-1 steps)
+  // K-tile body, software pipelined inside the wave: fragments of k-step ks+1 are requested and a slice of the NEXT
+  // tiles' DMA is issued BEFORE the MFMAs of k-step ks, so LDS latency and DMA issue cost sit under matrix-pipe time
+  // (in the lockstep version every wave issued all DMA right after the barrier and the three phases simply added up).
+  auto compute = [&](int buf, bool prefetch, int kt_next, int nbuf) {
+    const bf16* Ac = As + buf * BM * BK;
+    const bf16* Bc = Bs + buf * BN * BK;
+    bf16x8 fa[2][TM], fb[2][TN];
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      bf16x8 fa[TM], fb[TN];
+    for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(Ac + swz(wm * WTM + i * 32 + frow, fk));
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(Ac + swz(wm * WTM + i * 32 + frow, ks * 2 + fk));
+    for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const bf16x8*>(Bc + swz(wn * WTN + j * 32 + frow, fk));
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(Bc + swz(wn * WTN + j * 32 + frow, ks * 2 + fk));
+    for (int ks = 0; ks < KS; ++ks) {
+      const int c = ks & 1, n = c ^ 1;
+      if (ks + 1 < KS) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[n][i] = *reinterpret_cast<const bf16x8*>(Ac + swz(wm * WTM + i * 32 + frow, (ks + 1) * 2 + fk));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[n][j] = *reinterpret_cast<const bf16x8*>(Bc + swz(wn * WTN + j * 32 + frow, (ks + 1) * 2 + fk));
+        if (prefetch) {
+#pragma unroll
+          for (int d = ks * DPK; d < (ks + 1) * DPK && d < PA + PB; ++d) dma1(d, kt_next, nbuf);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[c][j], fa[c][i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
+  };
+  if constexpr (NS == 2) {
+    dma(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      compute(cur, kt + 1 < nk && !dbg_nodma, kt + 1, cur ^ 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
+    // NS-deep ring: NS-1 K tiles stay in flight across the (raw) barrier; the wait is COUNTED (PA+PB DMA instructions
+    // per wave per tile), never a drain, so L2/HBM latency of tile kt+NS-1 hides under NS-1 tiles of MFMAs.
+    static_assert(NS == 3 && PA + PB == 6, "counted vmcnt below is written for 3 stages x 6 DMA instructions");
+    dma(0, 0);
+    if (nk > 1) dma(1, 1);
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile kt landed (tile kt+1 may still fly)
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                     // every wave's share of tile kt is in LDS; tile kt-1 fully consumed
+      asm volatile("" ::: "memory");
+      const int nb = buf == 0 ? 2 : buf - 1;            // (kt+2) % 3: the buffer read during iteration kt-1
+      compute(buf, kt + 2 < nk && !dbg_nodma, kt + 2, nb);
+      buf = buf == 2 ? 0 : buf + 1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
   // ---- epilogue: registers -> LDS tile (bf16) -> coalesced 16-byte rows ------------------------------------------
   bf16* Cs = smem;
   constexpr int CPR = BN / 8;                           // 16-byte chunks per tile row
-  constexpr int RPP = 256 / CPR;                        // tile rows per store pass
+  constexpr int RPP = NT / CPR;                         // tile rows per store pass
   const int erow = tid / CPR, echunk = tid % CPR;
   auto stage_tile = [&](bool pre) {
 #pragma unroll
@@ -285,7 +330,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmArgs a) {
             v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
           }
           if (!pre) {
-            if (a.act == 1) {
+            if ((a.act & 0xff) == 1) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
             }
@@ -299,30 +344,31 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(GemmArgs a) {
         }
     }
   };
-  auto store_tile = [&](bf16* dst, bool add_res) {
-#pragma unroll
-    for (int r0 = 0; r0 < BM; r0 += RPP) {
-      const int ml = r0 + erow, m = tm0 + ml, n = tn0 + echunk * 8;
-      if (m < a.M && n < a.N) {
-        bf16x8 v = *reinterpret_cast<const bf16x8*>(Cs + ml * CLD + echunk * 8);
-        if (add_res) {
-          const bf16x8 r = *reinterpret_cast<const bf16x8*>(a.R + (size_t)m * a.ldr + n);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(r[e]));
-        }
-        *reinterpret_cast<bf16x8*>(dst + (size_t)m * a.ldy + n) = v;
-      }
-    }
-  };
-  if (a.act == 1 && a.Ypre) {
-    stage_tile(true);
-    __syncthreads();
-    store_tile(a.Ypre, false);
-    __syncthreads();
-  }
-  stage_tile(false);
+  // Single staging pass: the tile staged in LDS is the PRE-activation when act=GELU; the coalesced store pass writes it
+  // to Ypre (if requested), applies GELU / DropPath scale / residual on 8-wide vectors and writes Y.  (GELU is evaluated
+  // on the bf16-rounded pre-activation, i.e. exactly the value the backward pass will differentiate at.)
+  const bool gelu = (a.act & 0xff) == 1;
+  stage_tile(gelu);
   __syncthreads();
-  store_tile(a.Y, a.R != nullptr);
+#pragma unroll
+  for (int r0 = 0; r0 < BM; r0 += RPP) {
+    const int ml = r0 + erow, m = tm0 + ml, n = tn0 + echunk * 8;
+    if (m < a.M && n < a.N) {
+      bf16x8 v = *reinterpret_cast<const bf16x8*>(Cs + ml * CLD + echunk * 8);
+      if (gelu) {
+        if (a.Ypre) *reinterpret_cast<bf16x8*>(a.Ypre + (size_t)m * a.ldy + n) = v;
+        const float rsc = a.rowscale ? a.rowscale[m / a.rows_per_sample] : 1.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = f2bf(gelu_erf(bf2f(v[e])) * rsc);
+      }
+      if (a.R) {
+        const bf16x8 r = *reinterpret_cast<const bf16x8*>(a.R + (size_t)m * a.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(r[e]));
+      }
+      *reinterpret_cast<bf16x8*>(a.Y + (size_t)m * a.ldy + n) = v;
+    }
+  }
 }
 
 }  // namespace
@@ -341,13 +387,19 @@ extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bia
   GemmArgs a{(const bf16*)X, (const bf16*)W, bias, (const bf16*)residual, (bf16*)Y, (bf16*)Ypre, rowscale,
              M, N, K, ldx, ldw, ldy, ldr, act, rows_per_sample};
   const long big = (long)cdiv(M, 128) * cdiv(N, 128);
+  const long huge = (long)cdiv(M, 256) * cdiv(N, 128);
   const bool v2 = (K % 64 == 0) && (N % 8 == 0) && (ldy % 8 == 0) && (!residual || ldr % 8 == 0) && !getenv("FIBER_GEMM_V1");
-  if (big >= 192) {
-    if (v2) hipLaunchKernelGGL((gemm_nt_glds_kernel<128, 128>), dim3((unsigned)big), dim3(256), 0, stream, a);
+  // Tile choice: the 128x128 tile is L2->LDS bandwidth bound (64 flop per staged byte, ~10 TB/s fabric => ~650 TFLOP/s,
+  // measured with tools/gemm_probe.py); 256x128 (8 waves, 85 flop/B) lifts that ceiling when there are enough tiles.
+  static const int force = getenv("FIBER_GEMM_TILE") ? atoi(getenv("FIBER_GEMM_TILE")) : 0;
+  if (v2 && ((huge >= 400 && K >= 256 && force == 0) || force == 256)) {
+    hipLaunchKernelGGL((gemm_nt_glds_kernel<256, 128, 4, 2, 3>), dim3((unsigned)huge), dim3(512), 0, stream, a);
+  } else if (big >= 192 || force == 128) {
+    if (v2) hipLaunchKernelGGL((gemm_nt_glds_kernel<128, 128, 2, 2, 2>), dim3((unsigned)big), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), dim3((unsigned)big), dim3(256), 0, stream, a);
   } else {
     const long small = (long)cdiv(M, 64) * cdiv(N, 64);
-    if (v2) hipLaunchKernelGGL((gemm_nt_glds_kernel<64, 64>), dim3((unsigned)small), dim3(256), 0, stream, a);
+    if (v2) hipLaunchKernelGGL((gemm_nt_glds_kernel<64, 64, 2, 2, 2>), dim3((unsigned)small), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), dim3((unsigned)small), dim3(256), 0, stream, a);
   }
   FIBER_CHECK_LAUNCH();

@@ -112,7 +112,8 @@ __device__ __forceinline__ void setup(const WinP& p, const Smem& S, int h, int n
 }
 
 // ================================================================ forward =====================================
-__global__ __launch_bounds__(640) void win_fwd_kernel(WinP p) {
+template <int MAXC>   // 16-byte staging chunks per thread (4*N chunks over 64*waves threads)
+__global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_fwd_kernel(WinP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nb = (2 * p.ws - 1) * (2 * p.ws - 1);
   Smem S = carve(smem, nb, 1, 1);
@@ -123,12 +124,18 @@ __global__ __launch_bounds__(640) void win_fwd_kernel(WinP p) {
   const int ntile = (p.N + 15) >> 4;
   setup(p, S, h, nb, 1, 1);
 
-  // this thread's staging chunk (row sr of the window, 16-byte chunk sc of the 64-byte head slice)
-  const int sr = tid >> 2, sc = tid & 3;
-  const bool sval = sr < p.N;
-  const int spr = (sval ? sr : 0) / p.ws, spc = (sval ? sr : 0) - spr * p.ws;
-  // this lane's query
-  const int i = wave * 16 + lq;
+  // this thread's staging chunks: chunk id = tid + c*blockDim -> (row = id>>2 of the window, 16-byte piece id&3)
+  int spr[MAXC], spc[MAXC];
+  bool sval[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int id = tid + c * blockDim.x;
+    sval[c] = (id >> 2) < p.N;
+    const int r = sval[c] ? (id >> 2) : 0;
+    spr[c] = r / p.ws; spc[c] = r - spr[c] * p.ws;
+  }
+  // this lane's query: workgroup z owns strips [z*nw, (z+1)*nw) so that several small workgroups share a CU
+  const int i = (blockIdx.z * (blockDim.x >> 6) + wave) * 16 + lq;
   const bool qval = i < p.N;
   const int ic = qval ? i : p.N - 1;
   const int qpr = ic / p.ws, qpc = ic - qpr * p.ws;
@@ -137,27 +144,48 @@ __global__ __launch_bounds__(640) void win_fwd_kernel(WinP p) {
 
   const int g0 = blockIdx.x * p.gpb, g1 = min(p.G, g0 + p.gpb);
   if (g0 >= g1) return;
+  // The wave owns the same query strip in every window it visits, so its slice of the relative-position bias
+  // (bias_table[rel_index(i, j)], swin_transformer.py:208-211) is window-invariant: gather it ONCE into registers
+  // (-inf for padded keys) and the per-score work becomes a single fma.
+  __syncthreads();
+  f32x4 breg[MT];
+#pragma unroll
+  for (int kt = 0; kt < MT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int jj = kt * 16 + gq * 4 + r;
+      breg[kt][r] = (kt < ntile && jj < p.N) ? S.btab[qoff - S.koff[jj]] : -INFINITY;
+    }
   Geo geo;
   geo.set(p, g0);
-  bf16x8 kr = zero8(), vr = zero8(), qn;
+  bf16x8 kr[MAXC], vr[MAXC], qn;
   int qtok = geo.tok(p, qpr, qpc);
-  {
-    const int st = geo.tok(p, spr, spc);
-    if (sval) {
-      kr = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + C + h * 32 + sc * 8);
-      vr = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + 2 * C + h * 32 + sc * 8);
+  auto prefetch = [&]() {
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      if (sval[c]) {
+        const int sc = (tid + c * blockDim.x) & 3;
+        const int st = geo.tok(p, spr[c], spc[c]);
+        kr[c] = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + C + h * 32 + sc * 8);
+        vr[c] = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + 2 * C + h * 32 + sc * 8);
+      }
     }
     qn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)qtok * ld + h * 32 + gq * 8);
-  }
+  };
+  prefetch();
   for (int g = g0; g < g1; ++g) {
     __syncthreads();                                  // previous window's LDS reads done (also covers setup)
-    if (sval) {
-      *reinterpret_cast<bf16x8*>(Ks + sr * RS + sc * 8) = kr;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) Vt[(sc * 8 + e) * TS + sr] = vr[e];
+    for (int c = 0; c < MAXC; ++c) {
+      if (sval[c]) {
+        const int id = tid + c * blockDim.x, sr = id >> 2, sc = id & 3;
+        *reinterpret_cast<bf16x8*>(Ks + sr * RS + sc * 8) = kr[c];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Vt[(sc * 8 + e) * TS + sr] = vr[c][e];
+      }
     }
     const bool border = geo.border;
-    if (border && tid < p.N) { const int pr = tid / p.ws; S.kreg[tid] = geo.reg(p, pr, tid - pr * p.ws); }
+    if (border) for (int t = tid; t < p.N; t += blockDim.x) { const int pr = t / p.ws; S.kreg[t] = geo.reg(p, pr, t - pr * p.ws); }
     const int qreg = border ? geo.reg(p, qpr, qpc) : 0;
     const bf16x8 qf = qn;
     const int otok = qtok;
@@ -165,12 +193,7 @@ __global__ __launch_bounds__(640) void win_fwd_kernel(WinP p) {
     if (g + 1 < g1) {                                  // prefetch next window while this one computes
       geo.set(p, g + 1);
       qtok = geo.tok(p, qpr, qpc);
-      const int st = geo.tok(p, spr, spc);
-      if (sval) {
-        kr = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + C + h * 32 + sc * 8);
-        vr = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + 2 * C + h * 32 + sc * 8);
-      }
-      qn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)qtok * ld + h * 32 + gq * 8);
+      prefetch();
     }
     f32x4 s[MT];
     float mx = -INFINITY;
@@ -180,16 +203,13 @@ __global__ __launch_bounds__(640) void win_fwd_kernel(WinP p) {
       if (kt < ntile) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 16 + lq) * RS + gq * 8);
         f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);   // S^T[key][query]
-        const int4 ko = *reinterpret_cast<const int4*>(S.koff + kt * 16 + gq * 4);
-        const int kk[4] = {ko.x, ko.y, ko.z, ko.w};
         int4 kg = int4{0, 0, 0, 0};
         if (border) kg = *reinterpret_cast<const int4*>(S.kreg + kt * 16 + gq * 4);
         const int kgg[4] = {kg.x, kg.y, kg.z, kg.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = a[r] * scale + S.btab[qoff - kk[r]];
+          float v = fmaf(a[r], scale, breg[kt][r]);
           if (border && kgg[r] != qreg) v += -100.f;
-          if (kt * 16 + gq * 4 + r >= p.N) v = -INFINITY;
           s[kt][r] = v;
           mx = fmaxf(mx, v);
         }
@@ -231,7 +251,8 @@ __global__ __launch_bounds__(640) void win_fwd_kernel(WinP p) {
 }
 
 // ================================================================ backward pass A: dQ + dbias =================
-__global__ __launch_bounds__(640) void win_bwd_dq_kernel(WinP p) {
+template <int MAXC>   // 16-byte staging chunks per thread (4*N chunks over 64*waves threads)
+__global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dq_kernel(WinP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nb = (2 * p.ws - 1) * (2 * p.ws - 1);
   Smem S = carve(smem, nb, 2, 1);
@@ -241,48 +262,73 @@ __global__ __launch_bounds__(640) void win_bwd_dq_kernel(WinP p) {
   const int h = blockIdx.y, C = p.C, ld = 3 * C;
   const int ntile = (p.N + 15) >> 4;
   setup(p, S, h, nb, 2, 1);
-  const int sr = tid >> 2, sc = tid & 3;
-  const bool sval = sr < p.N;
-  const int spr = (sval ? sr : 0) / p.ws, spc = (sval ? sr : 0) - spr * p.ws;
-  const int i = wave * 16 + lq;
+  int spr[MAXC], spc[MAXC];
+  bool sval[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int id = tid + c * blockDim.x;
+    sval[c] = (id >> 2) < p.N;
+    const int r = sval[c] ? (id >> 2) : 0;
+    spr[c] = r / p.ws; spc[c] = r - spr[c] * p.ws;
+  }
+  const int i = (blockIdx.z * (blockDim.x >> 6) + wave) * 16 + lq;
   const bool qval = i < p.N;
   const int ic = qval ? i : p.N - 1;
   const int qpr = ic / p.ws, qpc = ic - qpr * p.ws;
   const int qoff = (qpr + p.ws - 1) * (2 * p.ws - 1) + qpc + p.ws - 1;
   const float scale = 0.17677669529663687f;
 
-  f32x4 dbacc[MT];
+  f32x4 dbacc[MT], breg[MT];
+  __syncthreads();
 #pragma unroll
-  for (int kt = 0; kt < MT; ++kt) dbacc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int kt = 0; kt < MT; ++kt) {
+    dbacc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int jj = kt * 16 + gq * 4 + r;
+      breg[kt][r] = (kt < ntile && jj < p.N) ? S.btab[qoff - S.koff[jj]] : -INFINITY;   // window-invariant bias slice
+    }
+  }
 
   const int g0 = blockIdx.x * p.gpb, g1 = min(p.G, g0 + p.gpb);
   Geo geo;
-  bf16x8 kr = zero8(), vr = zero8(), qn = zero8(), don = zero8();
+  bf16x8 kr[MAXC], vr[MAXC], qn = zero8(), don = zero8();
   float lsen = 0.f, dltn = 0.f;
   int qtok = 0;
-  if (g0 < g1) {
-    geo.set(p, g0);
-    qtok = geo.tok(p, qpr, qpc);
-    const int st = geo.tok(p, spr, spc);
-    if (sval) {
-      kr = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + C + h * 32 + sc * 8);
-      vr = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + 2 * C + h * 32 + sc * 8);
+  auto prefetch = [&]() {
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      if (sval[c]) {
+        const int sc = (tid + c * blockDim.x) & 3;
+        const int st = geo.tok(p, spr[c], spc[c]);
+        kr[c] = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + C + h * 32 + sc * 8);
+        vr[c] = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + 2 * C + h * 32 + sc * 8);
+      }
     }
     qn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)qtok * ld + h * 32 + gq * 8);
     don = *reinterpret_cast<const bf16x8*>(p.dout + (size_t)qtok * C + h * 32 + gq * 8);
     lsen = p.lse[(size_t)qtok * p.heads + h];
     dltn = p.delta[(size_t)qtok * p.heads + h];
+  };
+  if (g0 < g1) {
+    geo.set(p, g0);
+    qtok = geo.tok(p, qpr, qpc);
+    prefetch();
   }
   for (int g = g0; g < g1; ++g) {
     __syncthreads();
-    if (sval) {
-      *reinterpret_cast<bf16x8*>(Ks + sr * RS + sc * 8) = kr;
-      *reinterpret_cast<bf16x8*>(Vs + sr * RS + sc * 8) = vr;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) Kt[(sc * 8 + e) * TS + sr] = kr[e];
+    for (int c = 0; c < MAXC; ++c) {
+      if (sval[c]) {
+        const int id = tid + c * blockDim.x, sr = id >> 2, sc = id & 3;
+        *reinterpret_cast<bf16x8*>(Ks + sr * RS + sc * 8) = kr[c];
+        *reinterpret_cast<bf16x8*>(Vs + sr * RS + sc * 8) = vr[c];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Kt[(sc * 8 + e) * TS + sr] = kr[c][e];
+      }
     }
     const bool border = geo.border;
-    if (border && tid < p.N) { const int pr = tid / p.ws; S.kreg[tid] = geo.reg(p, pr, tid - pr * p.ws); }
+    if (border) for (int t = tid; t < p.N; t += blockDim.x) { const int pr = t / p.ws; S.kreg[t] = geo.reg(p, pr, t - pr * p.ws); }
     const int qreg = border ? geo.reg(p, qpr, qpc) : 0;
     const bf16x8 qf = qn, dof = don;
     const float lse = lsen, dlt = dltn;
@@ -291,15 +337,7 @@ __global__ __launch_bounds__(640) void win_bwd_dq_kernel(WinP p) {
     if (g + 1 < g1) {
       geo.set(p, g + 1);
       qtok = geo.tok(p, qpr, qpc);
-      const int st = geo.tok(p, spr, spc);
-      if (sval) {
-        kr = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + C + h * 32 + sc * 8);
-        vr = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + 2 * C + h * 32 + sc * 8);
-      }
-      qn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)qtok * ld + h * 32 + gq * 8);
-      don = *reinterpret_cast<const bf16x8*>(p.dout + (size_t)qtok * C + h * 32 + gq * 8);
-      lsen = p.lse[(size_t)qtok * p.heads + h];
-      dltn = p.delta[(size_t)qtok * p.heads + h];
+      prefetch();
     }
     f32x4 dqacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -315,17 +353,14 @@ __global__ __launch_bounds__(640) void win_bwd_dq_kernel(WinP p) {
             const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + (kt * 16 + lq) * RS + gq * 8);
             const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            const int4 ko = *reinterpret_cast<const int4*>(S.koff + kt * 16 + gq * 4);
-            const int kk[4] = {ko.x, ko.y, ko.z, ko.w};
             int4 kg = int4{0, 0, 0, 0};
             if (border) kg = *reinterpret_cast<const int4*>(S.kreg + kt * 16 + gq * 4);
             const int kgg[4] = {kg.x, kg.y, kg.z, kg.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float sv = a[r] * scale + S.btab[qoff - kk[r]];
+              float sv = fmaf(a[r], scale, breg[kt][r]);        // -inf on padded keys -> p = 0
               if (border && kgg[r] != qreg) sv += -100.f;
-              const bool ok = qval && (kt * 16 + gq * 4 + r < p.N);
-              const float d = ok ? __expf(sv - lse) * (dp[r] - dlt) : 0.f;
+              const float d = qval ? __expf(sv - lse) * (dp[r] - dlt) : 0.f;
               ds[u][r] = d;
               dbacc[kt][r] += d;
             }
@@ -361,7 +396,8 @@ __global__ __launch_bounds__(640) void win_bwd_dq_kernel(WinP p) {
 }
 
 // ================================================================ backward pass B: dK, dV ======================
-__global__ __launch_bounds__(640) void win_bwd_dkv_kernel(WinP p) {
+template <int MAXC>   // 16-byte staging chunks per thread (4*N chunks over 64*waves threads)
+__global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dkv_kernel(WinP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nb = (2 * p.ws - 1) * (2 * p.ws - 1);
   Smem S = carve(smem, nb, 2, 2);
@@ -371,10 +407,16 @@ __global__ __launch_bounds__(640) void win_bwd_dkv_kernel(WinP p) {
   const int h = blockIdx.y, C = p.C, ld = 3 * C;
   const int ntile = (p.N + 15) >> 4;
   setup(p, S, h, nb, 2, 2);
-  const int sr = tid >> 2, sc = tid & 3;
-  const bool sval = sr < p.N;
-  const int spr = (sval ? sr : 0) / p.ws, spc = (sval ? sr : 0) - spr * p.ws;
-  const int j = wave * 16 + lq;                         // this lane's key
+  int spr[MAXC], spc[MAXC];
+  bool sval[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int id = tid + c * blockDim.x;
+    sval[c] = (id >> 2) < p.N;
+    const int r = sval[c] ? (id >> 2) : 0;
+    spr[c] = r / p.ws; spc[c] = r - spr[c] * p.ws;
+  }
+  const int j = (blockIdx.z * (blockDim.x >> 6) + wave) * 16 + lq;   // this lane's key
   const bool kval = j < p.N;
   const int jc = kval ? j : p.N - 1;
   const int kpr = jc / p.ws, kpc = jc - kpr * p.ws;
@@ -384,32 +426,50 @@ __global__ __launch_bounds__(640) void win_bwd_dkv_kernel(WinP p) {
 
   const int g0 = blockIdx.x * p.gpb, g1 = min(p.G, g0 + p.gpb);
   if (g0 >= g1) return;
+  __syncthreads();
+  f32x4 breg[MT];                                       // window-invariant bias slice of this key strip
+#pragma unroll
+  for (int qt = 0; qt < MT; ++qt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ii = qt * 16 + gq * 4 + r;
+      breg[qt][r] = (qt < ntile && ii < p.N) ? S.btab[S.koff[ii] + kconst] : 0.f;
+    }
   Geo geo;
   geo.set(p, g0);
-  bf16x8 qr = zero8(), dr = zero8(), kn, vn;
-  float lser = INFINITY, dltr = 0.f;
+  bf16x8 qr[MAXC], dr[MAXC], kn, vn;
+  float lser[MAXC], dltr[MAXC];
   int ktok = geo.tok(p, kpr, kpc);
-  {
-    const int st = geo.tok(p, spr, spc);
-    if (sval) {
-      qr = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + h * 32 + sc * 8);
-      dr = *reinterpret_cast<const bf16x8*>(p.dout + (size_t)st * C + h * 32 + sc * 8);
-      if (sc == 0) { lser = p.lse[(size_t)st * p.heads + h]; dltr = p.delta[(size_t)st * p.heads + h]; }
+  auto prefetch = [&]() {
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      if (sval[c]) {
+        const int sc = (tid + c * blockDim.x) & 3;
+        const int st = geo.tok(p, spr[c], spc[c]);
+        qr[c] = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + h * 32 + sc * 8);
+        dr[c] = *reinterpret_cast<const bf16x8*>(p.dout + (size_t)st * C + h * 32 + sc * 8);
+        if (sc == 0) { lser[c] = p.lse[(size_t)st * p.heads + h]; dltr[c] = p.delta[(size_t)st * p.heads + h]; }
+      }
     }
     kn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)ktok * ld + C + h * 32 + gq * 8);
     vn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)ktok * ld + 2 * C + h * 32 + gq * 8);
-  }
+  };
+  prefetch();
   for (int g = g0; g < g1; ++g) {
     __syncthreads();
-    if (sval) {
-      *reinterpret_cast<bf16x8*>(Qs + sr * RS + sc * 8) = qr;
-      *reinterpret_cast<bf16x8*>(dOs + sr * RS + sc * 8) = dr;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { Qt[(sc * 8 + e) * TS + sr] = qr[e]; dOt[(sc * 8 + e) * TS + sr] = dr[e]; }
-      if (sc == 0) { S.lse[sr] = lser; S.dlt[sr] = dltr; }
+    for (int c = 0; c < MAXC; ++c) {
+      if (sval[c]) {
+        const int id = tid + c * blockDim.x, sr = id >> 2, sc = id & 3;
+        *reinterpret_cast<bf16x8*>(Qs + sr * RS + sc * 8) = qr[c];
+        *reinterpret_cast<bf16x8*>(dOs + sr * RS + sc * 8) = dr[c];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { Qt[(sc * 8 + e) * TS + sr] = qr[c][e]; dOt[(sc * 8 + e) * TS + sr] = dr[c][e]; }
+        if (sc == 0) { S.lse[sr] = lser[c]; S.dlt[sr] = dltr[c]; }
+      }
     }
     const bool border = geo.border;
-    if (border && tid < p.N) { const int pr = tid / p.ws; S.kreg[tid] = geo.reg(p, pr, tid - pr * p.ws); }
+    if (border) for (int t = tid; t < p.N; t += blockDim.x) { const int pr = t / p.ws; S.kreg[t] = geo.reg(p, pr, t - pr * p.ws); }
     const int kreg = border ? geo.reg(p, kpr, kpc) : 0;
     const bf16x8 kf = kn, vf = vn;
     const int otok = ktok;
@@ -417,14 +477,7 @@ __global__ __launch_bounds__(640) void win_bwd_dkv_kernel(WinP p) {
     if (g + 1 < g1) {
       geo.set(p, g + 1);
       ktok = geo.tok(p, kpr, kpc);
-      const int st = geo.tok(p, spr, spc);
-      if (sval) {
-        qr = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + h * 32 + sc * 8);
-        dr = *reinterpret_cast<const bf16x8*>(p.dout + (size_t)st * C + h * 32 + sc * 8);
-        if (sc == 0) { lser = p.lse[(size_t)st * p.heads + h]; dltr = p.delta[(size_t)st * p.heads + h]; }
-      }
-      kn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)ktok * ld + C + h * 32 + gq * 8);
-      vn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)ktok * ld + 2 * C + h * 32 + gq * 8);
+      prefetch();
     }
     f32x4 dkacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     f32x4 dvacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -442,8 +495,6 @@ __global__ __launch_bounds__(640) void win_bwd_dkv_kernel(WinP p) {
             const bf16x8 df = *reinterpret_cast<const bf16x8*>(dOs + (qt * 16 + lq) * RS + gq * 8);
             const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);   // S[query][key]
             const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);  // dP[query][key]
-            const int4 qo = *reinterpret_cast<const int4*>(S.koff + qt * 16 + gq * 4);
-            const int qq[4] = {qo.x, qo.y, qo.z, qo.w};
             const float4 l4 = *reinterpret_cast<const float4*>(S.lse + qt * 16 + gq * 4);
             const float4 d4 = *reinterpret_cast<const float4*>(S.dlt + qt * 16 + gq * 4);
             const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
@@ -452,7 +503,7 @@ __global__ __launch_bounds__(640) void win_bwd_dkv_kernel(WinP p) {
             const int qgg[4] = {qg.x, qg.y, qg.z, qg.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float sv = a[r] * scale + S.btab[qq[r] + kconst];
+              float sv = fmaf(a[r], scale, breg[qt][r]);
               if (border && qgg[r] != kreg) sv += -100.f;
               const float pr = kval ? __expf(sv - ll[r]) : 0.f;     // padded queries carry lse = +inf -> 0
               pd[u][r] = pr;
@@ -512,10 +563,19 @@ bool attrs_set = false;
 void ensure_attrs() {
   if (attrs_set) return;
   const int big = 160 * 1024;
-  hipFuncSetAttribute((const void*)win_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  hipFuncSetAttribute((const void*)win_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  hipFuncSetAttribute((const void*)win_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)win_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)win_bwd_dq_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)win_bwd_dkv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   attrs_set = true;
+}
+
+// waves per workgroup / strip groups: small workgroups (<= 4 waves) so that several co-reside on a CU and one group's
+// barrier / staging phases overlap the others' MFMA phases (one 9-wave workgroup per CU left the CU idle at barriers)
+void strip_geometry(int N, int& nw, int& sg) {
+  // One workgroup per (window run, head) with one wave per 16-query strip: each thread stages exactly one 16-byte chunk
+  // (MAXC = 1).  A split into <=4-wave strip groups (MAXC = 3, several workgroups per CU) measured no faster.
+  nw = cdiv(N, 16);
+  sg = 1;
 }
 
 int blocks_for(int G, int heads) {
@@ -542,8 +602,10 @@ int fiber_win_fwd_launch(const void* qkv, const float* bias_table, void* o, floa
   ensure_attrs();
   WinP p = make(qkv, B, Hres, Wres, C, heads, ws, shift);
   p.o = (bf16*)o; p.lse = lse; p.bias_table = bias_table;
-  const int nw = cdiv(p.N, 16), nb = (2 * ws - 1) * (2 * ws - 1);
-  hipLaunchKernelGGL(win_fwd_kernel, dim3(cdiv(p.G, p.gpb), heads), dim3(64 * nw), smem_bytes(nb, 1, 1), st, p);
+  const int nb = (2 * ws - 1) * (2 * ws - 1);
+  int nw, sg;
+  strip_geometry(p.N, nw, sg);
+  hipLaunchKernelGGL(win_fwd_kernel<1>, dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes(nb, 1, 1), st, p);
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }
@@ -560,18 +622,20 @@ int fiber_win_bwd_launch(const void* qkv, const float* bias_table, const void* o
   WinP p = make(qkv, B, Hres, Wres, C, heads, ws, shift);
   p.o = (bf16*)o; p.lse = (float*)lse; p.bias_table = bias_table; p.dout = (const bf16*)dout; p.dqkv = (bf16*)dqkv;
   p.delta = delta_ws; p.dbias_part = dbias_ws;
-  const int nw = cdiv(p.N, 16), nb = (2 * ws - 1) * (2 * ws - 1);
+  const int nb = (2 * ws - 1) * (2 * ws - 1);
+  int nw, sg;
+  strip_geometry(p.N, nw, sg);
   const size_t nvec = (size_t)B * Hres * Wres * C / 8;
   size_t g = (nvec + 255) / 256;
   hipLaunchKernelGGL(win_delta_kernel, dim3((int)(g > 4096 ? 4096 : g)), dim3(256), 0, st, (const bf16*)o, (const bf16*)dout, delta_ws, nvec, heads);
   FIBER_CHECK_LAUNCH();
   const int gz = cdiv(p.G, p.gpb);
-  hipLaunchKernelGGL(win_bwd_dq_kernel, dim3(gz, heads), dim3(64 * nw), smem_bytes(nb, 2, 1), st, p);
+  hipLaunchKernelGGL(win_bwd_dq_kernel<1>, dim3(gz, heads, sg), dim3(64 * nw), smem_bytes(nb, 2, 1), st, p);
   FIBER_CHECK_LAUNCH();
   if (hipMemsetAsync(dbias_table, 0, (size_t)nb * heads * sizeof(float), st) != hipSuccess) return FIBER_ELAUNCH;
   hipLaunchKernelGGL(win_dbias_scatter_kernel, dim3(p.N, heads), dim3(256), 0, st, dbias_ws, dbias_table, gz, heads, ws);
   FIBER_CHECK_LAUNCH();
-  hipLaunchKernelGGL(win_bwd_dkv_kernel, dim3(gz, heads), dim3(64 * nw), smem_bytes(nb, 2, 2), st, p);
+  hipLaunchKernelGGL(win_bwd_dkv_kernel<1>, dim3(gz, heads, sg), dim3(64 * nw), smem_bytes(nb, 2, 2), st, p);
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }
