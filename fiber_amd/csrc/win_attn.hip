@@ -12,6 +12,8 @@
 //   * the shift mask is evaluated only for windows that touch the wrapped border (last window row / column).
 // Backward: pass A (wave = query strip) -> dQ and the relative-position-bias gradient, accumulated in registers over
 // all windows the workgroup visits; pass B (wave = key strip) -> dK, dV.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -25,6 +27,7 @@ struct WinP {
   const bf16* qkv; bf16* o; const bf16* dout; bf16* dqkv;
   float* lse; const float* delta; const float* bias_table; float* dbias_part;
   int B, Hres, Wres, C, heads, ws, shift, nWw, nWh, nW, G, N, gpb;
+  int dbg;   // ablation switches (FIBER_WIN_DBG): 1 = skip the MFMA/softmax body, 2 = skip LDS staging writes
 };
 
 __device__ __forceinline__ int region_of(int x, int n, int ws, int shift) { return x < n - ws ? 0 : (x < n - shift ? 1 : 2); }
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_fwd_kernel(WinP p) 
     __syncthreads();                                  // previous window's LDS reads done (also covers setup)
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
-      if (sval[c]) {
+      if (sval[c] && !(p.dbg & 2)) {
         const int id = tid + c * blockDim.x, sr = id >> 2, sc = id & 3;
         *reinterpret_cast<bf16x8*>(Ks + sr * RS + sc * 8) = kr[c];
 #pragma unroll
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_fwd_kernel(WinP p) 
 #pragma unroll
     for (int kt = 0; kt < MT; ++kt) {
       s[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-      if (kt < ntile) {
+      if (kt < ntile && !(p.dbg & 1)) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 16 + lq) * RS + gq * 8);
         f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);   // S^T[key][query]
         int4 kg = int4{0, 0, 0, 0};
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_fwd_kernel(WinP p) 
     f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int t2 = 0; t2 < MT / 2; ++t2) {
-      if (t2 * 2 < ntile) {
+      if (t2 * 2 < ntile && !(p.dbg & 1)) {
         const bf16x8 pf = pack8(s[2 * t2], s[2 * t2 + 1]);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dq_kernel(WinP 
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
-      if (sval[c]) {
+      if (sval[c] && !(p.dbg & 2)) {
         const int id = tid + c * blockDim.x, sr = id >> 2, sc = id & 3;
         *reinterpret_cast<bf16x8*>(Ks + sr * RS + sc * 8) = kr[c];
         *reinterpret_cast<bf16x8*>(Vs + sr * RS + sc * 8) = vr[c];
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dq_kernel(WinP 
     f32x4 dqacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int t2 = 0; t2 < MT / 2; ++t2) {
-      if (t2 * 2 < ntile) {
+      if (t2 * 2 < ntile && !(p.dbg & 1)) {
         f32x4 ds[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dkv_kernel(WinP
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
-      if (sval[c]) {
+      if (sval[c] && !(p.dbg & 2)) {
         const int id = tid + c * blockDim.x, sr = id >> 2, sc = id & 3;
         *reinterpret_cast<bf16x8*>(Qs + sr * RS + sc * 8) = qr[c];
         *reinterpret_cast<bf16x8*>(dOs + sr * RS + sc * 8) = dr[c];
@@ -483,7 +486,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dkv_kernel(WinP
     f32x4 dvacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int t2 = 0; t2 < MT / 2; ++t2) {
-      if (t2 * 2 < ntile) {
+      if (t2 * 2 < ntile && !(p.dbg & 1)) {
         f32x4 ds[2], pd[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -591,6 +594,8 @@ WinP make(const void* qkv, int B, int Hres, int Wres, int C, int heads, int ws, 
   p.nWw = Wres / ws; p.nWh = Hres / ws; p.nW = p.nWw * p.nWh; p.G = B * p.nW; p.N = ws * ws;
   const int nz = blocks_for(p.G, heads);
   p.gpb = cdiv(p.G, nz);
+  static const int dbg = getenv("FIBER_WIN_DBG") ? atoi(getenv("FIBER_WIN_DBG")) : 0;
+  p.dbg = dbg;
   return p;
 }
 
