@@ -198,6 +198,14 @@ extern "C" int fiber_colsum_bf16(const void* x, float* out, float* workspace, in
   return FIBER_OK;
 }
 
+// out[n] = sum_r part[r, n]  (fold of per-tile / per-slab partial rows, fp32)
+extern "C" int fiber_fold_rows_f32(const float* part, float* out, int rows, int N, hipStream_t stream) {
+  if (rows <= 0 || N <= 0) return FIBER_OK;
+  hipLaunchKernelGGL(colsum_fold_kernel, dim3(cdiv(N, 64)), dim3(256), 0, stream, part, out, rows, N);
+  FIBER_CHECK_LAUNCH();
+  return FIBER_OK;
+}
+
 // y = keep(seed, i) ? x / (1-p) : 0 ; the same call with dy as x gives the backward.
 extern "C" int fiber_dropout_bf16(const void* x, void* y, long n, float p, uint64_t seed, hipStream_t stream) {
   if (n <= 0) return FIBER_OK;

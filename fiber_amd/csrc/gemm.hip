@@ -26,7 +26,9 @@ constexpr int BK = 64;
 struct GemmArgs {
   const bf16* X; const bf16* W; const float* bias; const bf16* R; bf16* Y; bf16* Ypre;
   const float* rowscale;   // optional per-sample scale (timm DropPath): row m uses rowscale[m / rows_per_sample]
-  int M, N, K, ldx, ldw, ldy, ldr, act, rows_per_sample;
+  const bf16* aux;         // act == 2: pre-activation H [M, ldaux]; the output is acc * gelu'(H)  (fused GELU backward)
+  float* colpart;          // optional [tilesM, N] fp32: per-row-tile column sums of the stored output (bias gradient)
+  int M, N, K, ldx, ldw, ldy, ldr, act, rows_per_sample, ldaux;
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row * 8 + (chunk ^ ((row >> 1) & 7))) * 8; }  // element offset
@@ -347,9 +349,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_glds_kernel(GemmArgs a) 
   // Single staging pass: the tile staged in LDS is the PRE-activation when act=GELU; the coalesced store pass writes it
   // to Ypre (if requested), applies GELU / DropPath scale / residual on 8-wide vectors and writes Y.  (GELU is evaluated
   // on the bf16-rounded pre-activation, i.e. exactly the value the backward pass will differentiate at.)
-  const bool gelu = (a.act & 0xff) == 1;
+  const bool gelu = (a.act & 0xff) == 1, gelu_grad = (a.act & 0xff) == 2;
   stage_tile(gelu);
   __syncthreads();
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int r0 = 0; r0 < BM; r0 += RPP) {
     const int ml = r0 + erow, m = tm0 + ml, n = tn0 + echunk * 8;
@@ -360,6 +363,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_glds_kernel(GemmArgs a) 
         const float rsc = a.rowscale ? a.rowscale[m / a.rows_per_sample] : 1.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = f2bf(gelu_erf(bf2f(v[e])) * rsc);
+      } else if (gelu_grad) {
+        const bf16x8 h = *reinterpret_cast<const bf16x8*>(a.aux + (size_t)m * a.ldaux + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) * gelu_erf_grad(bf2f(h[e])));
       }
       if (a.R) {
         const bf16x8 r = *reinterpret_cast<const bf16x8*>(a.R + (size_t)m * a.ldr + n);
@@ -367,6 +374,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_glds_kernel(GemmArgs a) 
         for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(r[e]));
       }
       *reinterpret_cast<bf16x8*>(a.Y + (size_t)m * a.ldy + n) = v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) csum[e] += bf2f(v[e]);
+    }
+  }
+  if (a.colpart) {                                      // column sums of this tile: RPP row-lanes -> one row, via LDS
+    float* red = reinterpret_cast<float*>(Cs + BM * CLD);          // free LDS behind the staged tile
+    static_assert((size_t)BM * CLD * 2 + (size_t)RPP * BN * 4 <= sizeof(smem), "no LDS room for the column-sum reduction");
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[erow * BN + echunk * 8 + e] = csum[e];
+    __syncthreads();
+    for (int c = tid; c < BN; c += NT) {
+      float t = 0.f;
+      for (int r = 0; r < RPP; ++r) t += red[r * BN + c];
+      if (tn0 + c < a.N) a.colpart[(size_t)(tm0 / BM) * a.N + tn0 + c] = t;
     }
   }
 }
@@ -374,20 +395,32 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_glds_kernel(GemmArgs a) 
 }  // namespace
 
 // C ABI ---------------------------------------------------------------------------------------------------------
+// Row-tile height the dispatcher will use for an [M,N,K] problem (rows of `colpart` = ceil(M / tile)).
+extern "C" int fiber_gemm_row_tile(int M, int N, int K) {
+  const long big = (long)cdiv(M, 128) * cdiv(N, 128), huge = (long)cdiv(M, 256) * cdiv(N, 128);
+  static const int force = getenv("FIBER_GEMM_TILE") ? atoi(getenv("FIBER_GEMM_TILE")) : 0;
+  if ((huge >= 400 && K >= 256 && force == 0) || force == 256) return 256;
+  if (big >= 192 || force == 128) return 128;
+  return 64;
+}
+
 // Y = rowscale * act(X.W^T + bias) + residual.  bias: fp32[N] or NULL; residual: bf16[M,ldr] or NULL; act: 0 none, 1 exact GELU;
 // rowscale: fp32[M / rows_per_sample] or NULL (per-sample DropPath factor on the branch, swin_transformer.py:390-391)
 // (Ypre, if non-NULL with act=1, receives the pre-activation for the backward pass).  K % 8 == 0, N % 4 == 0,
 // all leading dimensions multiples of 8 elements (16-byte rows).
 extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bias, const void* residual, void* Y,
-                                  void* Ypre, const float* rowscale, int rows_per_sample, int M, int N, int K, int ldx,
-                                  int ldw, int ldy, int ldr, int act, hipStream_t stream) {
+                                  void* Ypre, const float* rowscale, int rows_per_sample, const void* aux, int ldaux,
+                                  float* colpart, int M, int N, int K, int ldx, int ldw, int ldy, int ldr, int act,
+                                  hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0) return FIBER_OK;
   if ((K & 7) || (N & 3) || (ldx & 7) || (ldw & 7) || (ldy & 3) || (residual && (ldr & 3))) return FIBER_EINVAL;
   if (rowscale && rows_per_sample <= 0) return FIBER_EINVAL;
+  if ((act & 0xff) == 2 && (!aux || (ldaux & 7))) return FIBER_EINVAL;
   GemmArgs a{(const bf16*)X, (const bf16*)W, bias, (const bf16*)residual, (bf16*)Y, (bf16*)Ypre, rowscale,
-             M, N, K, ldx, ldw, ldy, ldr, act, rows_per_sample};
+             (const bf16*)aux, colpart, M, N, K, ldx, ldw, ldy, ldr, act, rows_per_sample, ldaux};
   const long big = (long)cdiv(M, 128) * cdiv(N, 128);
   const long huge = (long)cdiv(M, 256) * cdiv(N, 128);
+  if (((act & 0xff) == 2 || colpart) && !((K % 64 == 0) && (N % 8 == 0) && (ldy % 8 == 0))) return FIBER_EINVAL;   // glds kernels only
   const bool v2 = (K % 64 == 0) && (N % 8 == 0) && (ldy % 8 == 0) && (!residual || ldr % 8 == 0) && !getenv("FIBER_GEMM_V1");
   // Tile choice: the 128x128 tile is L2->LDS bandwidth bound (64 flop per staged byte, ~10 TB/s fabric => ~650 TFLOP/s,
   // measured with tools/gemm_probe.py); 256x128 (8 waves, 85 flop/B) lifts that ceiling when there are enough tiles.

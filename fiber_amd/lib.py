@@ -15,7 +15,7 @@ P, I, F, L, U64 = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_uint64
 
 # name -> argtypes (stream appended automatically)
 SIGNATURES = {
-    "fiber_gemm_nt_bf16": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I],
+    "fiber_gemm_nt_bf16": [P, P, P, P, P, P, P, I, P, I, P, I, I, I, I, I, I, I, I],
     "fiber_layernorm_fwd_bf16": [P, P, P, P, P, P, I, I, F],
     "fiber_layernorm_bwd_bf16": [P, P, P, P, P, P, P, P, P, P, I, I],
     "fiber_patch_merge_ln_fwd_bf16": [P, P, P, P, P, P, I, I, I, I, F],
@@ -31,11 +31,12 @@ SIGNATURES = {
     "fiber_scale_add_bf16": [P, P, P, F, P, L],
     "fiber_dot_bf16": [P, P, P, L],
     "fiber_colsum_bf16": [P, P, P, I, I, I],
+    "fiber_fold_rows_f32": [P, P, I, I],
     "fiber_dropout_bf16": [P, P, L, F, U64],
     "fiber_rowscale_add_bf16": [P, P, P, P, L, L],
 }
 # host-side helpers without a stream argument
-PLAIN = {"fiber_layernorm_bwd_grid": [I], "fiber_window_attn_bwd_slices": [I, I], "fiber_colsum_slabs": [I, I]}
+PLAIN = {"fiber_layernorm_bwd_grid": [I], "fiber_window_attn_bwd_slices": [I, I], "fiber_colsum_slabs": [I, I], "fiber_gemm_row_tile": [I, I, I]}
 
 _lib = None
 

@@ -130,8 +130,7 @@ class SwinTransformerBlock(nn.Module):
         u, x = ops.layernorm_res(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         x = self.attn(u, (H, W), self.shift_size, shortcut=x, y=y, y_mask=y_mask, rowscale=s1)
         v, x = ops.layernorm_res(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        h = ops.linear(v, self.mlp.fc1.weight, self.mlp.fc1.bias, act="gelu")
-        return ops.linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=x, rowscale=s2)
+        return ops.mlp(v, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=x, rowscale=s2)
 
 
 class PatchMerging(nn.Module):

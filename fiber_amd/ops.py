@@ -12,8 +12,11 @@ import torch
 
 from . import lib
 
+import os
+
 BF16 = torch.bfloat16
 _wcache = {}
+_FUSED_MLP_BWD = os.environ.get("FIBER_FUSED_MLP_BWD", "0") == "1"   # measured: no faster yet (epilogue math is not overlapped)
 
 
 def bf16_weight(w):
@@ -25,6 +28,18 @@ def bf16_weight(w):
     wb = w.detach().to(BF16).contiguous()
     _wcache[key] = (w._version, wb, w)
     return wb
+
+
+def bf16_weight_t(w):
+    """bf16 TRANSPOSED copy of an fp32 [N, K] parameter -> [K, N] (the B operand of the dgrad GEMM dX = dY . W in the
+    kernel's NT form), refreshed when the parameter's version counter changes."""
+    key = ("T", id(w))
+    hit = _wcache.get(key)
+    if hit is not None and hit[0] == w._version and hit[2] is w:
+        return hit[1]
+    wt = w.detach().t().to(BF16).contiguous()
+    _wcache[key] = (w._version, wt, w)
+    return wt
 
 
 def cast_bf16(w):
@@ -44,16 +59,25 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def gemm_nt(x2, wb, bias=None, residual=None, act=0, want_pre=False, rowscale=None, rows_per_sample=0):
+def gemm_nt(x2, wb, bias=None, residual=None, act=0, want_pre=False, rowscale=None, rows_per_sample=0, aux=None,
+            want_colsum=False):
     """y = act(x2 @ wb^T + bias) + residual  on the HIP kernel.  x2 [M,K] bf16 (row stride may exceed K)."""
     M, K = x2.shape
     N = wb.shape[0]
     assert x2.dtype == BF16 and wb.dtype == BF16 and x2.stride(1) == 1 and wb.stride(1) == 1
     y = torch.empty((M, N), dtype=BF16, device=x2.device)
     pre = torch.empty((M, N), dtype=BF16, device=x2.device) if (want_pre and act) else None
+    colpart = None
+    if want_colsum:
+        tiles = -(-M // lib.plain("fiber_gemm_row_tile", M, N, K))
+        colpart = torch.empty((tiles, N), dtype=torch.float32, device=x2.device)
     lib.call("fiber_gemm_nt_bf16", lib.ptr(x2), lib.ptr(wb), lib.ptr(bias), lib.ptr(residual), lib.ptr(y), lib.ptr(pre),
-             lib.ptr(rowscale), rows_per_sample, M, N, K, x2.stride(0), wb.stride(0), N,
-             residual.stride(0) if residual is not None else 0, act)
+             lib.ptr(rowscale), rows_per_sample, lib.ptr(aux), aux.stride(0) if aux is not None else 0, lib.ptr(colpart),
+             M, N, K, x2.stride(0), wb.stride(0), N, residual.stride(0) if residual is not None else 0, act)
+    if want_colsum:
+        cs = torch.empty(N, dtype=torch.float32, device=x2.device)
+        lib.call("fiber_fold_rows_f32", lib.ptr(colpart), lib.ptr(cs), colpart.shape[0], N)
+        return y, cs
     return y, pre
 
 
@@ -141,6 +165,55 @@ def linear(x, weight, bias=None, residual=None, act=None, rowscale=None):
         assert rowscale is None
         return y + residual if residual is not None else y
     return _Linear.apply(x, weight, bias, residual, 1 if act else 0, rowscale)
+
+
+class _MLP(torch.autograd.Function):
+    """y = [rowscale *] (fc2(gelu(fc1(x)))) + residual  (timm Mlp inside a Swin block / RoBERTa intermediate+output).
+
+    Forward: two MFMA GEMMs (bias+GELU epilogue saving the pre-activation; bias+DropPath scale+residual epilogue).
+    Backward: dH = (dY . W2) * gelu'(H) is ONE hand-written GEMM whose epilogue applies the GELU derivative to the saved
+    pre-activation and emits the fc1 bias gradient (column sums) -- dG never exists in HBM and the separate gelu_bwd and
+    column-sum passes over the 4C-wide tensor disappear.  The remaining plain GEMMs (dX, dW1, dW2) use the library."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, residual, rowscale):
+        shp = x.shape
+        x2 = _c(x).view(-1, shp[-1])
+        r2 = _c(residual).view(-1, w2.shape[0]) if residual is not None else None
+        g, h = gemm_nt(x2, bf16_weight(w1), b1, None, 1, True)
+        rps = (x2.shape[0] // rowscale.numel()) if rowscale is not None else 0
+        y, _ = gemm_nt(g, bf16_weight(w2), b2, r2, 0, False, rowscale, rps)
+        ctx.save_for_backward(x2, w1, w2, h, g, rowscale)
+        ctx.has_res, ctx.shp = residual is not None, shp
+        return y.view(*shp[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, w2, h, g, rowscale = ctx.saved_tensors
+        dy2 = _c(dy).view(-1, w2.shape[0])
+        dres = dy if ctx.has_res else None
+        if rowscale is not None:
+            ds = torch.empty_like(dy2)
+            lib.call("fiber_rowscale_add_bf16", None, lib.ptr(dy2), lib.ptr(rowscale), lib.ptr(ds), dy2.numel(),
+                     dy2.numel() // rowscale.numel())
+            dy2 = ds
+        C, C4 = dy2.shape[1], h.shape[1]
+        if C % 64 == 0 and C4 % 8 == 0 and _FUSED_MLP_BWD:
+            dh, db1 = gemm_nt(dy2, bf16_weight_t(w2), None, None, 2, False, aux=h, want_colsum=True)
+        else:                                         # shapes the DMA kernel does not cover (e.g. Swin-T C=96)
+            dg = torch.matmul(dy2, bf16_weight(w2))
+            dh = torch.empty_like(dg)
+            lib.call("fiber_gelu_bwd_bf16", lib.ptr(dg), lib.ptr(h), lib.ptr(dh), dg.numel())
+            db1 = colsum(dh)
+        dw2 = wgrad(dy2, g)
+        db2 = colsum(dy2)
+        dx = torch.matmul(dh, bf16_weight(w1)).view(ctx.shp)
+        dw1 = wgrad(dh, x2)
+        return dx, dw1, db1, dw2, db2, dres, None
+
+
+def mlp(x, w1, b1, w2, b2, residual=None, rowscale=None):
+    return _MLP.apply(x, w1, b1, w2, b2, residual, rowscale)
 
 
 class _LayerNorm(torch.autograd.Function):

@@ -23,9 +23,12 @@ typedef struct ihipStream_t* fiber_stream_t;
  * replaces: swin_transformer.py:197,221,233,238,257 (qkv/proj/i2t linears), timm Mlp fc1/fc2 (:325), PatchMerging.reduction
  * (:431), roberta.py:231-241,337,398,415, fiber_module.py:349-350.  act: 0 none, 1 GELU (Ypre, if non-NULL, gets the
  * pre-activation).  Requires K%8==0, N%4==0, ldx/ldw%8==0, ldy/ldr%4==0. */
+/* act 2 = fused GELU backward: Y = (X.W^T) * gelu'(aux) with aux = saved pre-activation [M, ldaux];
+ * colpart (nullable) receives per-row-tile column sums of Y, [ceil(M / fiber_gemm_row_tile(M,N,K)), N] fp32 (bias gradient). */
 int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bias, const void* residual, void* Y, void* Ypre,
-                       const float* rowscale, int rows_per_sample, int M, int N, int K, int ldx, int ldw, int ldy, int ldr,
-                       int act, fiber_stream_t stream);
+                       const float* rowscale, int rows_per_sample, const void* aux, int ldaux, float* colpart, int M, int N,
+                       int K, int ldx, int ldw, int ldy, int ldr, int act, fiber_stream_t stream);
+int fiber_gemm_row_tile(int M, int N, int K);
 
 /* nn.LayerNorm over the last dim (C%8==0, C<=4096); saves mean/rstd.  replaces swin_transformer.py:362,391,244; roberta.py:485,422 */
 int fiber_layernorm_fwd_bf16(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int rows,
@@ -81,6 +84,7 @@ int fiber_scale_add_bf16(const void* a, const void* b, const float* alpha, float
 int fiber_dot_bf16(const void* a, const void* b, float* out, long n, fiber_stream_t stream);
 int fiber_colsum_slabs(int M, int N); /* workspace = slabs*N floats when slabs > 1 */
 int fiber_colsum_bf16(const void* x, float* out, float* workspace, int M, int N, int ld, fiber_stream_t stream);
+int fiber_fold_rows_f32(const float* part, float* out, int rows, int N, fiber_stream_t stream);
 int fiber_dropout_bf16(const void* x, void* y, long n, float p, uint64_t seed, fiber_stream_t stream);
 int fiber_rowscale_add_bf16(const void* r, const void* x, const float* scale, void* out, long n, long per_sample,
                             fiber_stream_t stream);

@@ -50,6 +50,24 @@ def main():
             t_wg = timeit(lambda: torch.matmul(dy.t(), x))
             f = lambda t: f"{t:8.1f}us {fl / t / 1e6:7.1f}TF"
             print(f"{name:10s} M={M:7d} N={N:5d} K={K:5d} | hip+epi {f(t_hip)} | hip {f(t_hip0)} | lib {f(t_lib)} | dgrad {f(t_dg)} | wgrad {f(t_wg)}")
+    if which in ("mlpbwd",):
+        print("== fc2 dgrad + GELU' + bias-grad: fused hip GEMM epilogue vs lib GEMM + gelu_bwd + colsum  [us]")
+        for name, L, C in (("s0", 9216, 128), ("s1", 2304, 256), ("s2", 576, 512), ("s3", 144, 1024)):
+            M = B * L
+            dy = torch.randn(M, C, device=dev).to(BF)
+            w2 = (torch.randn(C, 4 * C, device=dev) * 0.02)
+            h = torch.randn(M, 4 * C, device=dev).to(BF)
+            wt, wb = ops.bf16_weight_t(w2), ops.bf16_weight(w2)
+            t_f = timeit(lambda: ops.gemm_nt(dy, wt, None, None, 2, False, aux=h, want_colsum=True))
+            t_p = timeit(lambda: ops.gemm_nt(dy, wt, None, None, 0, False))
+            def unf():
+                dg = torch.matmul(dy, wb)
+                dh = torch.empty_like(dg)
+                lib.call("fiber_gelu_bwd_bf16", lib.ptr(dg), lib.ptr(h), lib.ptr(dh), dg.numel())
+                return ops.colsum(dh)
+            t_u = timeit(unf)
+            t_l = timeit(lambda: torch.matmul(dy, wb))
+            print(f"{name} M={M} C={C}: fused {t_f:8.1f}us | hip plain {t_p:8.1f} | unfused total {t_u:8.1f} (lib gemm {t_l:8.1f})")
     if which in ("all", "attn"):
         print(f"== window attention (B={B})  fwd | bwd  [us, TFLOP/s on 4*L*N*C algorithmic flops fwd, x2.5 bwd]")
         for name, H, C, heads in (("s0", 96, 128, 4), ("s1", 48, 256, 8), ("s2", 24, 512, 16), ("s3", 12, 1024, 32)):
