@@ -1,0 +1,67 @@
+"""CPU: the Lightning-free Trainer stand-in (gradient accumulation, scheduler stepping, max_steps) on a toy module, and
+the optimizer parameter-group rules / LR schedule of fiber_utils.set_schedule against the reference's rules."""
+import torch
+import torch.nn as nn
+
+from fiber_amd.lightning import LightningModule
+from fiber_amd.modules import fiber_utils
+from fiber_amd.trainer import Trainer
+
+
+class Toy(LightningModule):
+    def __init__(self, config):
+        super().__init__()
+        self.save_hyperparameters()
+        self.lin = nn.Linear(4, 1)
+        self.current_tasks = ["toy"]
+
+    def forward(self, batch):
+        return {"toy_loss": (self.lin(batch["x"]) - batch["y"]).pow(2).mean()}
+
+    def configure_optimizers(self):
+        return fiber_utils.set_schedule(self)
+
+
+def _cfg(**kw):
+    c = dict(learning_rate=0.1, weight_decay=0.0, lr_mult_head=5, lr_mult_cross_modal=5, end_lr=0, decay_power=1,
+             optim_type="sgd", warmup_steps=2, max_steps=10)
+    c.update(kw)
+    return c
+
+
+def test_trainer_accumulates_and_steps():
+    torch.manual_seed(0)
+    m = Toy(_cfg())
+    assert m.hparams.config["learning_rate"] == 0.1
+    w0 = m.lin.weight.detach().clone()
+    data = [{"x": torch.randn(8, 4), "y": torch.randn(8, 1)} for _ in range(4)]
+    tr = Trainer(max_steps=3, accumulate_grad_batches=2, log_every_n_steps=0)
+    tr.fit(m, data, device=torch.device("cpu"))
+    assert tr.global_step == 3 and m.global_step == 3
+    assert not torch.equal(w0, m.lin.weight.detach())
+
+
+def test_poly_schedule_matches_hf_formula():
+    # transformers 4.6.0 get_polynomial_decay_schedule_with_warmup(lr_end=0, power=1): linear warm-up then linear decay
+    f = lambda s: fiber_utils.poly_decay_lambda(s, 10, 100, 1e-5, 0.0, 1)
+    assert f(0) == 0.0 and abs(f(5) - 0.5) < 1e-12 and abs(f(10) - 1.0) < 1e-12
+    assert abs(f(55) - 0.5) < 1e-12 and f(100) == 0.0 and f(150) == 0.0
+
+
+def test_param_group_rules():
+    """fiber_utils.py:160-245: (plain|head|cross_modal) x (decay|no_decay); names containing cross_modal / i2t / t2i get
+    lr x lr_mult_cross_modal, heads lr x lr_mult_head, the no_decay list gets weight_decay 0."""
+    g = fiber_utils.param_group_index
+    assert g("vit_model.layers.0.blocks.0.attn.qkv.weight") == 0
+    assert g("vit_model.layers.0.blocks.0.attn.qkv.bias") == 1
+    assert g("vit_model.layers.0.blocks.0.norm1.weight") == 1
+    assert g("text_transformer.encoder.layer.0.attention.output.LayerNorm.weight") == 1
+    assert g("mlm_score.decoder.weight") == 2 and g("itm_score.fc.bias") == 3
+    assert g("vit_model.layers.2.blocks.15.attn.qkv_i2t.weight") == 4
+    assert g("vit_model.layers.2.blocks.15.attn.alpha_i2t") == 4
+    assert g("text_transformer.encoder.layer.7.crossattention_t2i.self.key.bias") == 5
+    assert g("cross_modal_text_transform.weight") == 4 and g("cross_modal_image_pooler.dense.bias") == 5
+    # norm_i2t_i.weight: "norm.weight"/"norm1.weight" are not substrings -> decays, cross-modal lr (as in the reference)
+    assert g("vit_model.layers.3.blocks.0.attn.norm_i2t_i.weight") == 4
+    # "bias" is a substring of relative_position_bias_table -> the reference puts it in the no-decay group
+    assert g("vit_model.layers.0.blocks.0.attn.relative_position_bias_table") == 1
