@@ -28,6 +28,7 @@ SIGNATURES = {
     "fiber_roberta_embed_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, U64],
     "fiber_im2col_patch4": [P, P, I, I, I],
     "fiber_gelu_bwd_bf16": [P, P, P, L],
+    "fiber_gelu_bwd_colsum_bf16": [P, P, P, P, P, I, I],
     "fiber_scale_add_bf16": [P, P, P, F, P, L],
     "fiber_dot_bf16": [P, P, P, L],
     "fiber_colsum_bf16": [P, P, P, I, I, I],

@@ -81,6 +81,17 @@ def gemm_nt(x2, wb, bias=None, residual=None, act=0, want_pre=False, rowscale=No
     return y, pre
 
 
+def gelu_bwd_colsum(dg, h):
+    """dh = dg * gelu'(h) and its column sums (bias gradient) in one pass."""
+    M, N = dg.shape
+    dh = torch.empty_like(dg)
+    db = torch.empty(N, dtype=torch.float32, device=dg.device)
+    slabs = lib.plain("fiber_colsum_slabs", M, N)
+    ws = torch.empty(slabs * N, dtype=torch.float32, device=dg.device) if slabs > 1 else None
+    lib.call("fiber_gelu_bwd_colsum_bf16", lib.ptr(dg), lib.ptr(h), lib.ptr(dh), lib.ptr(db), lib.ptr(ws), M, N)
+    return dh, db
+
+
 def colsum(x2):
     M, N = x2.shape
     out = torch.empty(N, dtype=torch.float32, device=x2.device)
@@ -142,15 +153,18 @@ class _Linear(torch.autograd.Function):
             lib.call("fiber_rowscale_add_bf16", None, lib.ptr(dy2), lib.ptr(rowscale), lib.ptr(ds), dy2.numel(),
                      dy2.numel() // rowscale.numel())
             dy2 = ds
+        db = None
         if ctx.act:
-            dh = torch.empty_like(dy2)
-            lib.call("fiber_gelu_bwd_bf16", lib.ptr(dy2), lib.ptr(pre), lib.ptr(dh), dy2.numel())
+            dh, db = gelu_bwd_colsum(dy2, pre)
         else:
             dh = dy2
         wb = bf16_weight(weight)
         dx = torch.matmul(dh, wb).view(ctx.shp) if ctx.needs_input_grad[0] else None
         dw = wgrad(dh, x2) if ctx.needs_input_grad[1] else None
-        db = colsum(dh) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = db if db is not None else colsum(dh)
+        else:
+            db = None
         return dx, dw, db, dres, None, None
 
 
@@ -201,10 +215,7 @@ class _MLP(torch.autograd.Function):
         if C % 64 == 0 and C4 % 8 == 0 and _FUSED_MLP_BWD:
             dh, db1 = gemm_nt(dy2, bf16_weight_t(w2), None, None, 2, False, aux=h, want_colsum=True)
         else:                                         # shapes the DMA kernel does not cover (e.g. Swin-T C=96)
-            dg = torch.matmul(dy2, bf16_weight(w2))
-            dh = torch.empty_like(dg)
-            lib.call("fiber_gelu_bwd_bf16", lib.ptr(dg), lib.ptr(h), lib.ptr(dh), dg.numel())
-            db1 = colsum(dh)
+            dh, db1 = gelu_bwd_colsum(torch.matmul(dy2, bf16_weight(w2)), h)
         dw2 = wgrad(dy2, g)
         db2 = colsum(dy2)
         dx = torch.matmul(dh, bf16_weight(w1)).view(ctx.shp)

@@ -80,6 +80,8 @@ int fiber_im2col_patch4(const float* img, void* cols, int B, int H, int W, fiber
 
 /* element-wise / reduction helpers (n % 8 == 0) */
 int fiber_gelu_bwd_bf16(const void* dgelu, const void* h_pre, void* dh, long n, fiber_stream_t stream);
+int fiber_gelu_bwd_colsum_bf16(const void* dgelu, const void* h_pre, void* dh, float* db, float* workspace, int M, int N,
+                               fiber_stream_t stream);
 int fiber_scale_add_bf16(const void* a, const void* b, const float* alpha, float mult, void* out, long n, fiber_stream_t stream);
 int fiber_dot_bf16(const void* a, const void* b, float* out, long n, fiber_stream_t stream);
 int fiber_colsum_slabs(int M, int N); /* workspace = slabs*N floats when slabs > 1 */
