@@ -612,20 +612,22 @@ void ensure_attrs() {
 
 // specialised persistent window kernels (win_attn.hip)
 int fiber_win_fwd_launch(const void* qkv, const float* bias_table, void* o, float* lse, int B, int Hres, int Wres, int C,
-                         int heads, int ws, int shift, hipStream_t st);
+                         int heads, int ws, int shift, int hmajor, hipStream_t st);
 int fiber_win_bwd_slices(int n_windows, int heads);
 int fiber_win_bwd_launch(const void* qkv, const float* bias_table, const void* o, const void* dout, const float* lse,
                          void* dqkv, float* dbias_table, float* delta_ws, float* dbias_ws, int B, int Hres, int Wres, int C,
-                         int heads, int ws, int shift, hipStream_t st);
+                         int heads, int ws, int shift, int hmajor, hipStream_t st);
 
 // --------------------------------------------------------------------------------------------------- C ABI
 // Window attention in image-token order.  qkv: [B*Hres*Wres, 3C] bf16 with channel layout [3][heads][32]
-// (swin_transformer.py:202); o: [B*Hres*Wres, C]; bias_table fp32 [(2ws-1)^2, heads]; lse fp32 [B*Hres*Wres, heads].
+// (swin_transformer.py:202) or, with head_major = 1, [heads][3][32] (the caller permutes the qkv weight rows: q|k|v of a
+// head become one contiguous 192-byte run per token, which raises cache-line efficiency of the per-head gathers); o: [B*Hres*Wres, C]; bias_table fp32 [(2ws-1)^2, heads]; lse fp32 [B*Hres*Wres, heads].
 // shift = 0 disables the cyclic shift and the region mask.  head_dim must be 32.
 extern "C" int fiber_window_attn_fwd_bf16(const void* qkv, const float* bias_table, void* o, float* lse, int B, int Hres,
-                                          int Wres, int C, int heads, int ws, int shift, hipStream_t stream) {
+                                          int Wres, int C, int heads, int ws, int shift, int head_major, hipStream_t stream) {
   if (C != heads * 32 || Hres % ws || Wres % ws || shift < 0 || shift >= ws) return FIBER_EINVAL;
-  if (ws * ws <= 160) return fiber_win_fwd_launch(qkv, bias_table, o, lse, B, Hres, Wres, C, heads, ws, shift, stream);
+  if (ws * ws <= 160) return fiber_win_fwd_launch(qkv, bias_table, o, lse, B, Hres, Wres, C, heads, ws, shift, head_major, stream);
+  if (head_major) return FIBER_EINVAL;                 // the generic (N > 160) path reads the reference layout only
   ensure_attrs();
   AttnP p{};
   const bf16* base = (const bf16*)qkv;
@@ -645,11 +647,12 @@ extern "C" int fiber_window_attn_bwd_slices(int n_windows, int heads) { return f
 extern "C" int fiber_window_attn_bwd_bf16(const void* qkv, const float* bias_table, const void* o, const void* dout,
                                           const float* lse, void* dqkv, float* dbias_table, float* delta_ws,
                                           float* dbias_ws, int B, int Hres, int Wres, int C, int heads, int ws, int shift,
-                                          hipStream_t stream) {
+                                          int head_major, hipStream_t stream) {
   if (C != heads * 32 || Hres % ws || Wres % ws || shift < 0 || shift >= ws) return FIBER_EINVAL;
   if (ws * ws <= 160)
     return fiber_win_bwd_launch(qkv, bias_table, o, dout, lse, dqkv, dbias_table, delta_ws, dbias_ws, B, Hres, Wres, C, heads,
-                                ws, shift, stream);
+                                ws, shift, head_major, stream);
+  if (head_major) return FIBER_EINVAL;
   ensure_attrs();
   AttnP p{};
   const bf16* base = (const bf16*)qkv;

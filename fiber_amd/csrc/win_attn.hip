@@ -27,6 +27,7 @@ struct WinP {
   const bf16* qkv; bf16* o; const bf16* dout; bf16* dqkv;
   float* lse; const float* delta; const float* bias_table; float* dbias_part;
   int B, Hres, Wres, C, heads, ws, shift, nWw, nWh, nW, G, N, gpb;
+  int hmajor;   // qkv channel layout: 0 = [3][heads][32] (reference, swin_transformer.py:202), 1 = [heads][3][32] (q|k|v of a head adjacent)
   int dbg;   // ablation switches (FIBER_WIN_DBG): 1 = skip the MFMA/softmax body, 2 = skip LDS staging writes
 };
 
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_fwd_kernel(WinP p) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gq = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y, C = p.C, ld = 3 * C;
+  const int qo = p.hmajor ? h * 96 : h * 32, ko = p.hmajor ? h * 96 + 32 : C + h * 32, vo = p.hmajor ? h * 96 + 64 : 2 * C + h * 32;
   const int ntile = (p.N + 15) >> 4;
   setup(p, S, h, nb, 1, 1);
 
@@ -169,11 +171,11 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_fwd_kernel(WinP p) 
       if (sval[c]) {
         const int sc = (tid + c * blockDim.x) & 3;
         const int st = geo.tok(p, spr[c], spc[c]);
-        kr[c] = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + C + h * 32 + sc * 8);
-        vr[c] = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + 2 * C + h * 32 + sc * 8);
+        kr[c] = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + ko + sc * 8);
+        vr[c] = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + vo + sc * 8);
       }
     }
-    qn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)qtok * ld + h * 32 + gq * 8);
+    qn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)qtok * ld + qo + gq * 8);
   };
   prefetch();
   for (int g = g0; g < g1; ++g) {
@@ -263,6 +265,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dq_kernel(WinP 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gq = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y, C = p.C, ld = 3 * C;
+  const int qo = p.hmajor ? h * 96 : h * 32, ko = p.hmajor ? h * 96 + 32 : C + h * 32, vo = p.hmajor ? h * 96 + 64 : 2 * C + h * 32;
   const int ntile = (p.N + 15) >> 4;
   setup(p, S, h, nb, 2, 1);
   int spr[MAXC], spc[MAXC];
@@ -304,11 +307,11 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dq_kernel(WinP 
       if (sval[c]) {
         const int sc = (tid + c * blockDim.x) & 3;
         const int st = geo.tok(p, spr[c], spc[c]);
-        kr[c] = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + C + h * 32 + sc * 8);
-        vr[c] = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + 2 * C + h * 32 + sc * 8);
+        kr[c] = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + ko + sc * 8);
+        vr[c] = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + vo + sc * 8);
       }
     }
-    qn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)qtok * ld + h * 32 + gq * 8);
+    qn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)qtok * ld + qo + gq * 8);
     don = *reinterpret_cast<const bf16x8*>(p.dout + (size_t)qtok * C + h * 32 + gq * 8);
     lsen = p.lse[(size_t)qtok * p.heads + h];
     dltn = p.delta[(size_t)qtok * p.heads + h];
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dq_kernel(WinP 
         bf16x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = f2bf(dqacc[dt][r] * scale);
-        *reinterpret_cast<bf16x4*>(p.dqkv + (size_t)otok * ld + h * 32 + dt * 16 + gq * 4) = o;
+        *reinterpret_cast<bf16x4*>(p.dqkv + (size_t)otok * ld + qo + dt * 16 + gq * 4) = o;
       }
     }
   }
@@ -408,6 +411,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dkv_kernel(WinP
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gq = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y, C = p.C, ld = 3 * C;
+  const int qo = p.hmajor ? h * 96 : h * 32, ko = p.hmajor ? h * 96 + 32 : C + h * 32, vo = p.hmajor ? h * 96 + 64 : 2 * C + h * 32;
   const int ntile = (p.N + 15) >> 4;
   setup(p, S, h, nb, 2, 2);
   int spr[MAXC], spc[MAXC];
@@ -449,13 +453,13 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dkv_kernel(WinP
       if (sval[c]) {
         const int sc = (tid + c * blockDim.x) & 3;
         const int st = geo.tok(p, spr[c], spc[c]);
-        qr[c] = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + h * 32 + sc * 8);
+        qr[c] = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + qo + sc * 8);
         dr[c] = *reinterpret_cast<const bf16x8*>(p.dout + (size_t)st * C + h * 32 + sc * 8);
         if (sc == 0) { lser[c] = p.lse[(size_t)st * p.heads + h]; dltr[c] = p.delta[(size_t)st * p.heads + h]; }
       }
     }
-    kn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)ktok * ld + C + h * 32 + gq * 8);
-    vn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)ktok * ld + 2 * C + h * 32 + gq * 8);
+    kn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)ktok * ld + ko + gq * 8);
+    vn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)ktok * ld + vo + gq * 8);
   };
   prefetch();
   for (int g = g0; g < g1; ++g) {
@@ -528,8 +532,8 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dkv_kernel(WinP
         bf16x4 ok, ov;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ok[r] = f2bf(dkacc[dt][r] * scale); ov[r] = f2bf(dvacc[dt][r]); }
-        *reinterpret_cast<bf16x4*>(p.dqkv + (size_t)otok * ld + C + h * 32 + dt * 16 + gq * 4) = ok;
-        *reinterpret_cast<bf16x4*>(p.dqkv + (size_t)otok * ld + 2 * C + h * 32 + dt * 16 + gq * 4) = ov;
+        *reinterpret_cast<bf16x4*>(p.dqkv + (size_t)otok * ld + ko + dt * 16 + gq * 4) = ok;
+        *reinterpret_cast<bf16x4*>(p.dqkv + (size_t)otok * ld + vo + dt * 16 + gq * 4) = ov;
       }
     }
   }
@@ -587,10 +591,11 @@ int blocks_for(int G, int heads) {
   return nz > G ? G : nz;
 }
 
-WinP make(const void* qkv, int B, int Hres, int Wres, int C, int heads, int ws, int shift) {
+WinP make(const void* qkv, int B, int Hres, int Wres, int C, int heads, int ws, int shift, int hmajor) {
   WinP p{};
   p.qkv = (const bf16*)qkv;
   p.B = B; p.Hres = Hres; p.Wres = Wres; p.C = C; p.heads = heads; p.ws = ws; p.shift = shift;
+  p.hmajor = hmajor;
   p.nWw = Wres / ws; p.nWh = Hres / ws; p.nW = p.nWw * p.nWh; p.G = B * p.nW; p.N = ws * ws;
   const int nz = blocks_for(p.G, heads);
   p.gpb = cdiv(p.G, nz);
@@ -603,9 +608,9 @@ WinP make(const void* qkv, int B, int Hres, int Wres, int C, int heads, int ws, 
 
 // Used by attn.hip's C entry points when the window fits the specialised path (head_dim 32, N <= 160).
 int fiber_win_fwd_launch(const void* qkv, const float* bias_table, void* o, float* lse, int B, int Hres, int Wres, int C,
-                         int heads, int ws, int shift, hipStream_t st) {
+                         int heads, int ws, int shift, int hmajor, hipStream_t st) {
   ensure_attrs();
-  WinP p = make(qkv, B, Hres, Wres, C, heads, ws, shift);
+  WinP p = make(qkv, B, Hres, Wres, C, heads, ws, shift, hmajor);
   p.o = (bf16*)o; p.lse = lse; p.bias_table = bias_table;
   const int nb = (2 * ws - 1) * (2 * ws - 1);
   int nw, sg;
@@ -622,9 +627,9 @@ int fiber_win_bwd_slices(int n_windows, int heads) {
 
 int fiber_win_bwd_launch(const void* qkv, const float* bias_table, const void* o, const void* dout, const float* lse,
                          void* dqkv, float* dbias_table, float* delta_ws, float* dbias_ws, int B, int Hres, int Wres, int C,
-                         int heads, int ws, int shift, hipStream_t st) {
+                         int heads, int ws, int shift, int hmajor, hipStream_t st) {
   ensure_attrs();
-  WinP p = make(qkv, B, Hres, Wres, C, heads, ws, shift);
+  WinP p = make(qkv, B, Hres, Wres, C, heads, ws, shift, hmajor);
   p.o = (bf16*)o; p.lse = (float*)lse; p.bias_table = bias_table; p.dout = (const bf16*)dout; p.dqkv = (bf16*)dqkv;
   p.delta = delta_ws; p.dbias_part = dbias_ws;
   const int nb = (2 * ws - 1) * (2 * ws - 1);

@@ -20,8 +20,8 @@ SIGNATURES = {
     "fiber_layernorm_bwd_bf16": [P, P, P, P, P, P, P, P, P, P, I, I],
     "fiber_patch_merge_ln_fwd_bf16": [P, P, P, P, P, P, I, I, I, I, F],
     "fiber_patch_merge_ln_bwd_bf16": [P, P, P, P, P, P, P, P, P, I, I, I, I],
-    "fiber_window_attn_fwd_bf16": [P, P, P, P, I, I, I, I, I, I, I],
-    "fiber_window_attn_bwd_bf16": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I],
+    "fiber_window_attn_fwd_bf16": [P, P, P, P, I, I, I, I, I, I, I, I],
+    "fiber_window_attn_bwd_bf16": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I],
     "fiber_mha_fwd_bf16": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, F, U64],
     "fiber_mha_bwd_bf16": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, F, F, U64],
     "fiber_roberta_embed_fwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, U64],

@@ -83,8 +83,12 @@ class WindowAttention(nn.Module):
         B, L, C = u.shape
         H, W = res
         ws = self.window_size[0]
-        qkv = ops.linear(u, self.qkv.weight, self.qkv.bias)
-        o = ops.window_attention(qkv, self.relative_position_bias_table, B, H, W, self.num_heads, ws, shift)
+        if ops.head_major_supported(ws):
+            qkv = ops.linear_qkv_head_major(u, self.qkv.weight, self.qkv.bias, self.num_heads)
+            o = ops.window_attention(qkv, self.relative_position_bias_table, B, H, W, self.num_heads, ws, shift, head_major=True)
+        else:
+            qkv = ops.linear(u, self.qkv.weight, self.qkv.bias)
+            o = ops.window_attention(qkv, self.relative_position_bias_table, B, H, W, self.num_heads, ws, shift)
         if y is None:
             return ops.linear(o, self.proj.weight, self.proj.bias, residual=shortcut, rowscale=rowscale)
         a = ops.linear(o, self.proj.weight, self.proj.bias)

@@ -331,21 +331,21 @@ def patch_merge_ln(x, gamma, beta, H, W, eps=1e-5):
 
 class _WindowAttn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, bias_table, B, H, W, heads, ws, shift):
+    def forward(ctx, qkv, bias_table, B, H, W, heads, ws, shift, head_major):
         C = qkv.shape[-1] // 3
         qkv = _c(qkv)
         rows = B * H * W
         o = torch.empty((rows, C), dtype=BF16, device=qkv.device)
         lse = torch.empty((rows, heads), dtype=torch.float32, device=qkv.device)
-        lib.call("fiber_window_attn_fwd_bf16", lib.ptr(qkv), lib.ptr(bias_table), lib.ptr(o), lib.ptr(lse), B, H, W, C, heads, ws, shift)
+        lib.call("fiber_window_attn_fwd_bf16", lib.ptr(qkv), lib.ptr(bias_table), lib.ptr(o), lib.ptr(lse), B, H, W, C, heads, ws, shift, head_major)
         ctx.save_for_backward(qkv, bias_table, o, lse)
-        ctx.dims = (B, H, W, C, heads, ws, shift)
+        ctx.dims = (B, H, W, C, heads, ws, shift, head_major)
         return o.view(B, H * W, C)
 
     @staticmethod
     def backward(ctx, do):
         qkv, bias_table, o, lse = ctx.saved_tensors
-        B, H, W, C, heads, ws, shift = ctx.dims
+        B, H, W, C, heads, ws, shift, head_major = ctx.dims
         do = _c(do)
         rows, N = B * H * W, ws * ws
         dqkv = torch.empty_like(qkv)
@@ -354,13 +354,71 @@ class _WindowAttn(torch.autograd.Function):
         nz = lib.plain("fiber_window_attn_bwd_slices", rows // N, heads)
         part = torch.empty(nz * heads * N * N, dtype=torch.float32, device=do.device)
         lib.call("fiber_window_attn_bwd_bf16", lib.ptr(qkv), lib.ptr(bias_table), lib.ptr(o), lib.ptr(do), lib.ptr(lse), lib.ptr(dqkv),
-                 lib.ptr(dtab), lib.ptr(delta), lib.ptr(part), B, H, W, C, heads, ws, shift)
-        return dqkv, dtab, None, None, None, None, None, None
+                 lib.ptr(dtab), lib.ptr(delta), lib.ptr(part), B, H, W, C, heads, ws, shift, head_major)
+        return dqkv, dtab, None, None, None, None, None, None, None
 
 
-def window_attention(qkv, bias_table, B, H, W, heads, ws, shift):
-    """qkv [B, H*W, 3C] in image-token order -> attention output [B, H*W, C] (shift/partition/reverse folded in)."""
-    return _WindowAttn.apply(qkv, bias_table, B, H, W, heads, ws, shift)
+def window_attention(qkv, bias_table, B, H, W, heads, ws, shift, head_major=False):
+    """qkv [B, H*W, 3C] in image-token order -> attention output [B, H*W, C] (shift/partition/reverse folded in).
+    head_major: qkv channels are [heads][3][32] (see linear_qkv_head_major) instead of the reference [3][heads][32]."""
+    return _WindowAttn.apply(qkv, bias_table, B, H, W, heads, ws, shift, 1 if head_major else 0)
+
+
+def head_major_supported(ws):
+    """The specialised window kernels (N = ws*ws <= 160) accept the head-major qkv layout."""
+    return ws * ws <= 160
+
+
+_perm_cache = {}
+
+
+def _qkv_perm(C, heads, device):
+    """perm[r'] = r: row r' = h*96 + which*32 + d of the head-major projection is row r = which*C + h*32 + d of qkv.weight."""
+    key = (C, heads, str(device))
+    if key not in _perm_cache:
+        h, which, d = torch.meshgrid(torch.arange(heads), torch.arange(3), torch.arange(32), indexing="ij")
+        perm = (which * C + h * 32 + d).reshape(-1).to(device)
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(3 * C, device=device)
+        _perm_cache[key] = (perm, inv)
+    return _perm_cache[key]
+
+
+class _LinearQKVHeadMajor(torch.autograd.Function):
+    """qkv = x . W^T + b with the OUTPUT channels reordered to [heads][3][32]: q|k|v of one head become one contiguous
+    192-byte run per token, so the per-head gathers of the window-attention kernels use 3/4 of every cache line they touch
+    instead of 1/2.  Only the bf16 working copy of the weight is permuted; parameters / gradients keep the reference layout."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, heads):
+        shp = x.shape
+        x2 = _c(x).view(-1, shp[-1])
+        C = weight.shape[1]
+        perm, inv = _qkv_perm(C, heads, x.device)
+        key = ("HM", id(weight))
+        hit = _wcache.get(key)
+        if hit is None or hit[0] != (weight._version, bias._version) or hit[2] is not weight:
+            _wcache[key] = ((weight._version, bias._version), (weight.detach()[perm].to(BF16).contiguous(), bias.detach()[perm].contiguous()), weight)
+        wp, bp = _wcache[key][1]
+        y, _ = gemm_nt(x2, wp, bp)
+        ctx.save_for_backward(x2, weight)
+        ctx.shp, ctx.heads = shp, heads
+        return y.view(*shp[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        dy2 = _c(dy).view(-1, weight.shape[0])
+        perm, inv = _qkv_perm(weight.shape[1], ctx.heads, dy.device)
+        wp = _wcache[("HM", id(weight))][1][0]
+        dx = torch.matmul(dy2, wp).view(ctx.shp)
+        dw = wgrad(dy2, x2)[inv]
+        db = colsum(dy2)[inv]
+        return dx, dw, db, None
+
+
+def linear_qkv_head_major(x, weight, bias, heads):
+    return _LinearQKVHeadMajor.apply(x, weight, bias, heads)
 
 
 def _ld(t):

@@ -48,12 +48,13 @@ int fiber_patch_merge_ln_bwd_bf16(const void* dy, const void* x, const float* ga
 
 /* Swin (shifted) window attention in image-token order: roll + window_partition + WindowAttention self-attn core +
  * window_reverse + roll (swin_transformer.py:99-126, 195-219, 364-387, mask 327-350).  qkv [B*H*W,3C] -> o [B*H*W,C]. */
+/* head_major: 0 = reference channel layout [3][heads][32]; 1 = [heads][3][32] (qkv weight rows permuted by the caller) */
 int fiber_window_attn_fwd_bf16(const void* qkv, const float* bias_table, void* o, float* lse, int B, int Hres, int Wres, int C,
-                               int heads, int ws, int shift, fiber_stream_t stream);
+                               int heads, int ws, int shift, int head_major, fiber_stream_t stream);
 int fiber_window_attn_bwd_slices(int n_windows, int heads);
 int fiber_window_attn_bwd_bf16(const void* qkv, const float* bias_table, const void* o, const void* dout, const float* lse,
                                void* dqkv, float* dbias_table, float* delta_ws, float* dbias_ws, int B, int Hres, int Wres,
-                               int C, int heads, int ws, int shift, fiber_stream_t stream);
+                               int C, int heads, int ws, int shift, int head_major, fiber_stream_t stream);
 
 /* Generic MHA core softmax(q.k^T*scale + kmask).v with optional attention-prob dropout: RoBERTa self-attention
  * (roberta.py:256-326), image->text cross-attention (swin_transformer.py:226-256) and text->image cross-attention

@@ -140,6 +140,27 @@ def test_window_attention(ops, B, H, W, heads, ws, shift):
     assert_close("dbias_table", table.grad, tr.grad, 1e-2)
 
 
+@pytest.mark.parametrize("B,H,W,heads,ws,shift", [(2, 8, 8, 2, 4, 2), (1, 24, 24, 4, 12, 6), (2, 14, 14, 3, 7, 3)])
+def test_window_attention_head_major_layout(ops, B, H, W, heads, ws, shift):
+    """[heads][3][32] channel layout (permuted qkv projection) gives the same result as the reference [3][heads][32]."""
+    C = heads * 32
+    x = bf(rnd(B, H * W, C)).requires_grad_(True)
+    w = rnd(3 * C, C, std=C ** -0.5).to(DEV).requires_grad_(True)
+    b = rnd(3 * C, seed=1, std=0.1).to(DEV).requires_grad_(True)
+    table = rnd((2 * ws - 1) ** 2, heads, std=0.5).to(DEV).requires_grad_(True)
+    do = bf(rnd(B, H * W, C, seed=5))
+    outs = []
+    for hm in (False, True):
+        for t in (x, w, b, table):
+            t.grad = None
+        qkv = ops.linear_qkv_head_major(x, w, b, heads) if hm else ops.linear(x, w, b)
+        o = ops.window_attention(qkv, table, B, H, W, heads, ws, shift, head_major=hm)
+        o.backward(do)
+        outs.append((o.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone(), table.grad.clone()))
+    for name, a, r in zip(("o", "dx", "dw", "db", "dtable"), outs[1], outs[0]):
+        assert_close(name, a, r, 6e-3)
+
+
 def _mha_ref(q, k, v, kmask, B, heads, scale):
     D = q.shape[1] // heads
     qh = q.view(B, -1, heads, D).transpose(1, 2)
