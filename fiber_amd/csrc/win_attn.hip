@@ -66,6 +66,11 @@ struct Geo {
     wc = w - wr * p.nWw;
     border = p.shift > 0 && (wr == p.nWh - 1 || wc == p.nWw - 1);
   }
+  // advance to window g+1 without integer divisions (the loop visits consecutive windows)
+  __device__ __forceinline__ void next(const WinP& p) {
+    if (++wc == p.nWw) { wc = 0; if (++wr == p.nWh) { wr = 0; ++b; } }
+    border = p.shift > 0 && (wr == p.nWh - 1 || wc == p.nWw - 1);
+  }
   __device__ __forceinline__ int tok(const WinP& p, int pr, int pc) const {
     int r = wr * p.ws + pr + p.shift, c = wc * p.ws + pc + p.shift;
     r = r >= p.Hres ? r - p.Hres : r;
@@ -196,9 +201,9 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_fwd_kernel(WinP p) 
     const int otok = qtok;
     __syncthreads();
     if (g + 1 < g1) {                                  // prefetch next window while this one computes
-      geo.set(p, g + 1);
+      geo.next(p);
       qtok = geo.tok(p, qpr, qpc);
-      prefetch();
+      if (!(p.dbg & 8)) prefetch();
     }
     f32x4 s[MT];
     float mx = -INFINITY;
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_fwd_kernel(WinP p) 
           oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Vt, dt * 16 + lq, 2 * t2, gq), pf, oacc[dt], 0, 0, 0);
       }
     }
-    if (qval) {
+    if (qval && !(p.dbg & 4)) {
       const float inv = 1.f / sum;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dq_kernel(WinP 
     const int otok = qtok;
     __syncthreads();
     if (g + 1 < g1) {
-      geo.set(p, g + 1);
+      geo.next(p);
       qtok = geo.tok(p, qpr, qpc);
       prefetch();
     }
@@ -482,7 +487,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dkv_kernel(WinP
     const int otok = ktok;
     __syncthreads();
     if (g + 1 < g1) {
-      geo.set(p, g + 1);
+      geo.next(p);
       ktok = geo.tok(p, kpr, kpc);
       prefetch();
     }
@@ -586,7 +591,11 @@ void strip_geometry(int N, int& nw, int& sg) {
 }
 
 int blocks_for(int G, int heads) {
-  int nz = 768 / heads;
+  // One 9-wave workgroup fits per CU, so launch exactly one round (256 workgroups = 256/heads window runs per head):
+  // rocprof ablation showed ~45 % of the kernel was per-workgroup setup (bias column, key offsets, LDS clear, bias-slice
+  // gather) + per-window geometry when 768 short-lived workgroups ran in 3 rounds.
+  static const int per = getenv("FIBER_WIN_BLOCKS") ? atoi(getenv("FIBER_WIN_BLOCKS")) : 256;
+  int nz = per / heads;
   nz = nz < 1 ? 1 : nz;
   return nz > G ? G : nz;
 }
