@@ -164,8 +164,9 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_fwd_kernel(WinP p) 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int jj = kt * 16 + gq * 4 + r;
-      breg[kt][r] = (kt < ntile && jj < p.N) ? S.btab[qoff - S.koff[jj]] : -INFINITY;
+      breg[kt][r] = (kt < ntile && jj < p.N) ? S.btab[qoff - S.koff[jj]] * 1.4426950408889634f : -INFINITY;   // log2 domain
     }
+  const float scale2 = scale * 1.4426950408889634f;     // scores kept in the log2 domain: exp is a bare v_exp_f32
   Geo geo;
   geo.set(p, g0);
   bf16x8 kr[MAXC], vr[MAXC], qn;
@@ -218,8 +219,8 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_fwd_kernel(WinP p) 
         const int kgg[4] = {kg.x, kg.y, kg.z, kg.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = fmaf(a[r], scale, breg[kt][r]);
-          if (border && kgg[r] != qreg) v += -100.f;
+          float v = fmaf(a[r], scale2, breg[kt][r]);
+          if (border && kgg[r] != qreg) v -= 144.26950408889634f;     // -100 * log2(e)
           s[kt][r] = v;
           mx = fmaxf(mx, v);
         }
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_fwd_kernel(WinP p) 
     for (int kt = 0; kt < MT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = kt < ntile ? __expf(s[kt][r] - mx) : 0.f;
+        const float e = kt < ntile ? __builtin_amdgcn_exp2f(s[kt][r] - mx) : 0.f;
         s[kt][r] = e;
         sum += e;
       }
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_fwd_kernel(WinP p) 
         for (int r = 0; r < 4; ++r) o[r] = f2bf(oacc[dt][r] * inv);
         *reinterpret_cast<bf16x4*>(p.o + (size_t)otok * C + h * 32 + dt * 16 + gq * 4) = o;
       }
-      if (gq == 0) p.lse[(size_t)otok * p.heads + h] = mx + __logf(sum);
+      if (gq == 0) p.lse[(size_t)otok * p.heads + h] = mx * 0.6931471805599453f + __logf(sum);
     }
   }
 }
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dq_kernel(WinP 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int jj = kt * 16 + gq * 4 + r;
-      breg[kt][r] = (kt < ntile && jj < p.N) ? S.btab[qoff - S.koff[jj]] : -INFINITY;   // window-invariant bias slice
+      breg[kt][r] = (kt < ntile && jj < p.N) ? S.btab[qoff - S.koff[jj]] * 1.4426950408889634f : -INFINITY;   // window-invariant bias slice, log2 domain
     }
   }
 
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dq_kernel(WinP 
     if (border) for (int t = tid; t < p.N; t += blockDim.x) { const int pr = t / p.ws; S.kreg[t] = geo.reg(p, pr, t - pr * p.ws); }
     const int qreg = border ? geo.reg(p, qpr, qpc) : 0;
     const bf16x8 qf = qn, dof = don;
-    const float lse = lsen, dlt = dltn;
+    const float lse = lsen * 1.4426950408889634f, dlt = dltn;
     const int otok = qtok;
     __syncthreads();
     if (g + 1 < g1) {
@@ -369,9 +370,9 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dq_kernel(WinP 
             const int kgg[4] = {kg.x, kg.y, kg.z, kg.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float sv = fmaf(a[r], scale, breg[kt][r]);        // -inf on padded keys -> p = 0
-              if (border && kgg[r] != qreg) sv += -100.f;
-              const float d = qval ? __expf(sv - lse) * (dp[r] - dlt) : 0.f;
+              float sv = fmaf(a[r], scale * 1.4426950408889634f, breg[kt][r]);        // log2 domain; -inf on padded keys -> p = 0
+              if (border && kgg[r] != qreg) sv -= 144.26950408889634f;
+              const float d = qval ? __builtin_amdgcn_exp2f(sv - lse) * (dp[r] - dlt) : 0.f;
               ds[u][r] = d;
               dbacc[kt][r] += d;
             }
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dkv_kernel(WinP
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ii = qt * 16 + gq * 4 + r;
-      breg[qt][r] = (qt < ntile && ii < p.N) ? S.btab[S.koff[ii] + kconst] : 0.f;
+      breg[qt][r] = (qt < ntile && ii < p.N) ? S.btab[S.koff[ii] + kconst] * 1.4426950408889634f : 0.f;   // log2 domain
     }
   Geo geo;
   geo.set(p, g0);
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dkv_kernel(WinP
         *reinterpret_cast<bf16x8*>(dOs + sr * RS + sc * 8) = dr[c];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { Qt[(sc * 8 + e) * TS + sr] = qr[c][e]; dOt[(sc * 8 + e) * TS + sr] = dr[c][e]; }
-        if (sc == 0) { S.lse[sr] = lser[c]; S.dlt[sr] = dltr[c]; }
+        if (sc == 0) { S.lse[sr] = lser[c] * 1.4426950408889634f; S.dlt[sr] = dltr[c]; }   // lse staged in the log2 domain
       }
     }
     const bool border = geo.border;
@@ -515,9 +516,9 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dkv_kernel(WinP
             const int qgg[4] = {qg.x, qg.y, qg.z, qg.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float sv = fmaf(a[r], scale, breg[qt][r]);
-              if (border && qgg[r] != kreg) sv += -100.f;
-              const float pr = kval ? __expf(sv - ll[r]) : 0.f;     // padded queries carry lse = +inf -> 0
+              float sv = fmaf(a[r], scale * 1.4426950408889634f, breg[qt][r]);
+              if (border && qgg[r] != kreg) sv -= 144.26950408889634f;
+              const float pr = kval ? __builtin_amdgcn_exp2f(sv - ll[r]) : 0.f;     // padded queries carry lse = +inf -> 0
               pd[u][r] = pr;
               ds[u][r] = pr * (dp[r] - dd[r]);
             }
