@@ -115,8 +115,17 @@ def time_dominant_kernel(B, device):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
     tf = 2.0 * M * N * K / (us * 1e-6) / 1e12
-    return {"kernel": "gemm_nt_glds_kernel<256,128,4,2,3> (stage-2 fc1: bias + GELU + pre-activation store)", "shape": [M, N, K], "us": round(us, 2),
-            "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4)}
+    alg_bytes = 2 * (M * K + N * K + 2 * M * N)          # X, W in; Y and the saved pre-activation out
+    out = {"kernel": "gemm_nt_glds_kernel<256,128,4,2,3> (stage-2 fc1: bias + GELU + pre-activation store)", "shape": [M, N, K], "us": round(us, 2),
+           "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
+           "algorithmic_bytes": alg_bytes, "algorithmic_GBps": round(alg_bytes / us / 1e3, 1), "traffic": None}
+    try:   # HBM bytes per launch from the committed PMC pass (profiles/, collected with rocprofv3 --pmc on this same shape)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")))
+        if pmc["shape"] == [M, N, K]:
+            out["traffic"] = int(pmc["traffic_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        pass
+    return out
 
 
 def main():
@@ -202,6 +211,7 @@ def main():
                          "basis": "675.8 GFLOP algorithmic per image per step (BASELINE.md section 3) / measured step time, per GPU"},
         }
         res["roofline"]["dominant_kernel"] = time_dominant_kernel(args.batch, device)
+        res["roofline"]["traffic"] = res["roofline"]["dominant_kernel"]["traffic"]
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
