@@ -91,11 +91,15 @@ def set_schedule(pl_module):
         if gi is not None and p.requires_grad:
             groups[gi]["params"].append(p)
     if cfg["optim_type"] == "adamw":
+        # transformers 4.6.0 AdamW(correct_bias=True) == decoupled weight decay + bias correction == torch AdamW.
+        # (torch's fused=True variant measured no faster here once the bf16 working copies are refreshed every step.)
         optimizer = torch.optim.AdamW(groups, lr=lr, eps=1e-8, betas=(0.9, 0.98))
     elif cfg["optim_type"] == "adam":
         optimizer = torch.optim.Adam(groups, lr=lr)
     else:
         optimizer = torch.optim.SGD(groups, lr=lr, momentum=0.9)
+    from .. import ops
+    optimizer.register_step_post_hook(lambda *a, **k: ops.mark_weights_dirty())   # bf16 working copies follow the update
     tr = getattr(pl_module, "trainer", None)
     max_steps = getattr(tr, "max_steps", None) if tr is not None else None
     if max_steps is None:

@@ -19,14 +19,28 @@ _wcache = {}
 _FUSED_MLP_BWD = os.environ.get("FIBER_FUSED_MLP_BWD", "0") == "1"   # measured: no faster yet (epilogue math is not overlapped)
 
 
+_gen = [0]
+
+
+def mark_weights_dirty():
+    """Invalidate every cached bf16 working copy.  Fused / foreach optimizers update parameters through TensorList
+    kernels that do NOT bump `Tensor._version`, so the version counter alone would leave stale weights in use;
+    fiber_utils.set_schedule registers this as an optimizer step post-hook."""
+    _gen[0] += 1
+
+
+def _stamp(w):
+    return (w._version, _gen[0])
+
+
 def bf16_weight(w):
-    """bf16 copy of an fp32 parameter, refreshed when the parameter's version counter changes."""
+    """bf16 copy of an fp32 parameter, refreshed when the parameter changes (version counter or optimizer step)."""
     key = id(w)
     hit = _wcache.get(key)
-    if hit is not None and hit[0] == w._version and hit[2] is w:
+    if hit is not None and hit[0] == _stamp(w) and hit[2] is w:
         return hit[1]
     wb = w.detach().to(BF16).contiguous()
-    _wcache[key] = (w._version, wb, w)
+    _wcache[key] = (_stamp(w), wb, w)
     return wb
 
 
@@ -35,10 +49,10 @@ def bf16_weight_t(w):
     kernel's NT form), refreshed when the parameter's version counter changes."""
     key = ("T", id(w))
     hit = _wcache.get(key)
-    if hit is not None and hit[0] == w._version and hit[2] is w:
+    if hit is not None and hit[0] == _stamp(w) and hit[2] is w:
         return hit[1]
     wt = w.detach().t().to(BF16).contiguous()
-    _wcache[key] = (w._version, wt, w)
+    _wcache[key] = (_stamp(w), wt, w)
     return wt
 
 
@@ -397,8 +411,8 @@ class _LinearQKVHeadMajor(torch.autograd.Function):
         perm, inv = _qkv_perm(C, heads, x.device)
         key = ("HM", id(weight))
         hit = _wcache.get(key)
-        if hit is None or hit[0] != (weight._version, bias._version) or hit[2] is not weight:
-            _wcache[key] = ((weight._version, bias._version), (weight.detach()[perm].to(BF16).contiguous(), bias.detach()[perm].contiguous()), weight)
+        if hit is None or hit[0] != (_stamp(weight), _stamp(bias)) or hit[2] is not weight:
+            _wcache[key] = ((_stamp(weight), _stamp(bias)), (weight.detach()[perm].to(BF16).contiguous(), bias.detach()[perm].contiguous()), weight)
         wp, bp = _wcache[key][1]
         y, _ = gemm_nt(x2, wp, bp)
         ctx.save_for_backward(x2, weight)
@@ -631,10 +645,10 @@ class _PatchEmbedProj(torch.autograd.Function):
         lib.call("fiber_im2col_patch4", lib.ptr(img), lib.ptr(cols), B, H, W)
         key = ("pe", id(weight))
         hit = _wcache.get(key)
-        if hit is None or hit[0] != weight._version or hit[2] is not weight:
+        if hit is None or hit[0] != _stamp(weight) or hit[2] is not weight:
             wp = torch.zeros((Cout, 64), dtype=BF16, device=img.device)
             wp[:, :48] = weight.detach().reshape(Cout, 48).to(BF16)
-            _wcache[key] = (weight._version, wp, weight)
+            _wcache[key] = (_stamp(weight), wp, weight)
         wp = _wcache[key][1]
         y, _ = gemm_nt(cols, wp, bias)
         ctx.save_for_backward(cols)

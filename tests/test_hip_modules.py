@@ -262,4 +262,4 @@ def test_loss_curve_tracks_oracle_over_optimizer_steps():
     print("hip   :", [round(v, 4) for v in got])
     print("oracle:", [round(v, 4) for v in want])
     assert want[-1] < want[0] - 0.01, "oracle loss should fall on a fixed batch"
-    assert gap < 4e-3 and dgap < 3e-3, (gap, dgap, got, want)
+    assert gap < 4e-3 and dgap < 4e-3, (gap, dgap, got, want)
