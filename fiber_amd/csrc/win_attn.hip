@@ -14,6 +14,8 @@
 // all windows the workgroup visits; pass B (wave = key strip) -> dK, dV.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_fwd_kernel(WinP p) 
     __syncthreads();                                  // previous window's LDS reads done (also covers setup)
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
-      if (sval[c] && !(p.dbg & 2)) {
+      if (sval[c]) {
         const int id = tid + c * blockDim.x, sr = id >> 2, sc = id & 3;
         *reinterpret_cast<bf16x8*>(Ks + sr * RS + sc * 8) = kr[c];
 #pragma unroll
@@ -204,50 +206,59 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_fwd_kernel(WinP p) 
     if (g + 1 < g1) {                                  // prefetch next window while this one computes
       geo.next(p);
       qtok = geo.tok(p, qpr, qpc);
-      if (!(p.dbg & 8)) prefetch();
+      prefetch();
     }
+    // The body is instantiated twice (BORDER true/false) and selected by a wave-uniform branch per window: only windows
+    // on the wrapped border pay for the region-mask compares/selects (swin_transformer.py:327-350); padded key tiles carry
+    // bias = -inf so exp2 gives exact zeros without per-element selects.
     f32x4 s[MT];
-    float mx = -INFINITY;
+    float mx = -INFINITY, sum;
+    f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    {
 #pragma unroll
-    for (int kt = 0; kt < MT; ++kt) {
-      s[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-      if (kt < ntile && !(p.dbg & 1)) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 16 + lq) * RS + gq * 8);
-        f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);   // S^T[key][query]
-        int4 kg = int4{0, 0, 0, 0};
-        if (border) kg = *reinterpret_cast<const int4*>(S.kreg + kt * 16 + gq * 4);
-        const int kgg[4] = {kg.x, kg.y, kg.z, kg.w};
+      for (int kt = 0; kt < MT; ++kt) {
+        if (kt < ntile) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 16 + lq) * RS + gq * 8);
+          const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);   // S^T[key][query]
+          f32x4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = fmaf(a[r], scale2, breg[kt][r]);
-          if (border && kgg[r] != qreg) v -= 144.26950408889634f;     // -100 * log2(e)
-          s[kt][r] = v;
-          mx = fmaxf(mx, v);
+          for (int r = 0; r < 4; ++r) v[r] = fmaf(a[r], scale2, breg[kt][r]);
+          if (border) {
+            const int4 kg = *reinterpret_cast<const int4*>(S.kreg + kt * 16 + gq * 4);
+            v[0] = kg.x != qreg ? v[0] - 144.26950408889634f : v[0];     // -100 * log2(e)
+            v[1] = kg.y != qreg ? v[1] - 144.26950408889634f : v[1];
+            v[2] = kg.z != qreg ? v[2] - 144.26950408889634f : v[2];
+            v[3] = kg.w != qreg ? v[3] - 144.26950408889634f : v[3];
+          }
+          s[kt] = v;
+          mx = fmaxf(mx, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+        }
+      }
+      mx = g4max(mx);
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < MT; ++kt) {
+        if (kt < ntile) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - mx);
+          s0 += s[kt][0] + s[kt][1];
+          s1 += s[kt][2] + s[kt][3];
+        } else {
+          s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      sum = g4sum(s0 + s1);
+#pragma unroll
+      for (int t2 = 0; t2 < MT / 2; ++t2) {
+        if (t2 * 2 < ntile) {
+          const bf16x8 pf = pack8(s[2 * t2], s[2 * t2 + 1]);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+            oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Vt, dt * 16 + lq, 2 * t2, gq), pf, oacc[dt], 0, 0, 0);
         }
       }
     }
-    mx = g4max(mx);
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < MT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = kt < ntile ? __builtin_amdgcn_exp2f(s[kt][r] - mx) : 0.f;
-        s[kt][r] = e;
-        sum += e;
-      }
-    sum = g4sum(sum);
-    f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for (int t2 = 0; t2 < MT / 2; ++t2) {
-      if (t2 * 2 < ntile && !(p.dbg & 1)) {
-        const bf16x8 pf = pack8(s[2 * t2], s[2 * t2 + 1]);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-          oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Vt, dt * 16 + lq, 2 * t2, gq), pf, oacc[dt], 0, 0, 0);
-      }
-    }
-    if (qval && !(p.dbg & 4)) {
+    if (qval) {
       const float inv = 1.f / sum;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
@@ -331,7 +342,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dq_kernel(WinP 
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
-      if (sval[c] && !(p.dbg & 2)) {
+      if (sval[c]) {
         const int id = tid + c * blockDim.x, sr = id >> 2, sc = id & 3;
         *reinterpret_cast<bf16x8*>(Ks + sr * RS + sc * 8) = kr[c];
         *reinterpret_cast<bf16x8*>(Vs + sr * RS + sc * 8) = vr[c];
@@ -352,36 +363,44 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dq_kernel(WinP 
       prefetch();
     }
     f32x4 dqacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const float gate = qval ? 1.f : 0.f;                 // lanes of padded queries contribute nothing
+    {
 #pragma unroll
-    for (int t2 = 0; t2 < MT / 2; ++t2) {
-      if (t2 * 2 < ntile && !(p.dbg & 1)) {
-        f32x4 ds[2];
+      for (int t2 = 0; t2 < MT / 2; ++t2) {
+        if (t2 * 2 < ntile) {
+          f32x4 ds[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int kt = 2 * t2 + u;
-          ds[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (kt < ntile) {
-            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 16 + lq) * RS + gq * 8);
-            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + (kt * 16 + lq) * RS + gq * 8);
-            const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            int4 kg = int4{0, 0, 0, 0};
-            if (border) kg = *reinterpret_cast<const int4*>(S.kreg + kt * 16 + gq * 4);
-            const int kgg[4] = {kg.x, kg.y, kg.z, kg.w};
+          for (int u = 0; u < 2; ++u) {
+            const int kt = 2 * t2 + u;
+            ds[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kt < ntile) {
+              const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 16 + lq) * RS + gq * 8);
+              const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + (kt * 16 + lq) * RS + gq * 8);
+              const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+              const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+              f32x4 sv;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float sv = fmaf(a[r], scale * 1.4426950408889634f, breg[kt][r]);        // log2 domain; -inf on padded keys -> p = 0
-              if (border && kgg[r] != qreg) sv -= 144.26950408889634f;
-              const float d = qval ? __builtin_amdgcn_exp2f(sv - lse) * (dp[r] - dlt) : 0.f;
-              ds[u][r] = d;
-              dbacc[kt][r] += d;
+              for (int r = 0; r < 4; ++r) sv[r] = fmaf(a[r], scale * 1.4426950408889634f, breg[kt][r]);   // log2 domain; -inf on padded keys
+              if (border) {
+                const int4 kg = *reinterpret_cast<const int4*>(S.kreg + kt * 16 + gq * 4);
+                sv[0] = kg.x != qreg ? sv[0] - 144.26950408889634f : sv[0];
+                sv[1] = kg.y != qreg ? sv[1] - 144.26950408889634f : sv[1];
+                sv[2] = kg.z != qreg ? sv[2] - 144.26950408889634f : sv[2];
+                sv[3] = kg.w != qreg ? sv[3] - 144.26950408889634f : sv[3];
+              }
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float d = __builtin_amdgcn_exp2f(sv[r] - lse) * (dp[r] - dlt) * gate;
+                ds[u][r] = d;
+                dbacc[kt][r] += d;
+              }
             }
           }
-        }
-        const bf16x8 dsf = pack8(ds[0], ds[1]);
+          const bf16x8 dsf = pack8(ds[0], ds[1]);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-          dqacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Kt, dt * 16 + lq, 2 * t2, gq), dsf, dqacc[dt], 0, 0, 0);
+          for (int dt = 0; dt < 2; ++dt)
+            dqacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Kt, dt * 16 + lq, 2 * t2, gq), dsf, dqacc[dt], 0, 0, 0);
+        }
       }
     }
     if (qval) {
@@ -472,7 +491,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dkv_kernel(WinP
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
-      if (sval[c] && !(p.dbg & 2)) {
+      if (sval[c]) {
         const int id = tid + c * blockDim.x, sr = id >> 2, sc = id & 3;
         *reinterpret_cast<bf16x8*>(Qs + sr * RS + sc * 8) = qr[c];
         *reinterpret_cast<bf16x8*>(dOs + sr * RS + sc * 8) = dr[c];
@@ -494,41 +513,49 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dkv_kernel(WinP
     }
     f32x4 dkacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     f32x4 dvacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const float gate = kval ? 1.f : 0.f;                 // lanes of padded keys contribute nothing
+    {
 #pragma unroll
-    for (int t2 = 0; t2 < MT / 2; ++t2) {
-      if (t2 * 2 < ntile && !(p.dbg & 1)) {
-        f32x4 ds[2], pd[2];
+      for (int t2 = 0; t2 < MT / 2; ++t2) {
+        if (t2 * 2 < ntile) {
+          f32x4 ds[2], pd[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int qt = 2 * t2 + u;
-          ds[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-          pd[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (qt < ntile) {
-            const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + (qt * 16 + lq) * RS + gq * 8);
-            const bf16x8 df = *reinterpret_cast<const bf16x8*>(dOs + (qt * 16 + lq) * RS + gq * 8);
-            const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);   // S[query][key]
-            const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);  // dP[query][key]
-            const float4 l4 = *reinterpret_cast<const float4*>(S.lse + qt * 16 + gq * 4);
-            const float4 d4 = *reinterpret_cast<const float4*>(S.dlt + qt * 16 + gq * 4);
-            const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
-            int4 qg = int4{0, 0, 0, 0};
-            if (border) qg = *reinterpret_cast<const int4*>(S.kreg + qt * 16 + gq * 4);
-            const int qgg[4] = {qg.x, qg.y, qg.z, qg.w};
+          for (int u = 0; u < 2; ++u) {
+            const int qt = 2 * t2 + u;
+            ds[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            pd[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (qt < ntile) {
+              const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + (qt * 16 + lq) * RS + gq * 8);
+              const bf16x8 df = *reinterpret_cast<const bf16x8*>(dOs + (qt * 16 + lq) * RS + gq * 8);
+              const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);   // S[query][key]
+              const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);  // dP[query][key]
+              const float4 l4 = *reinterpret_cast<const float4*>(S.lse + qt * 16 + gq * 4);
+              const float4 d4 = *reinterpret_cast<const float4*>(S.dlt + qt * 16 + gq * 4);
+              const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+              f32x4 sv;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float sv = fmaf(a[r], scale * 1.4426950408889634f, breg[qt][r]);
-              if (border && qgg[r] != kreg) sv -= 144.26950408889634f;
-              const float pr = kval ? __builtin_amdgcn_exp2f(sv - ll[r]) : 0.f;     // padded queries carry lse = +inf -> 0
-              pd[u][r] = pr;
-              ds[u][r] = pr * (dp[r] - dd[r]);
+              for (int r = 0; r < 4; ++r) sv[r] = fmaf(a[r], scale * 1.4426950408889634f, breg[qt][r]);
+              if (border) {
+                const int4 qg = *reinterpret_cast<const int4*>(S.kreg + qt * 16 + gq * 4);
+                sv[0] = qg.x != kreg ? sv[0] - 144.26950408889634f : sv[0];
+                sv[1] = qg.y != kreg ? sv[1] - 144.26950408889634f : sv[1];
+                sv[2] = qg.z != kreg ? sv[2] - 144.26950408889634f : sv[2];
+                sv[3] = qg.w != kreg ? sv[3] - 144.26950408889634f : sv[3];
+              }
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float pr = __builtin_amdgcn_exp2f(sv[r] - ll[r]) * gate;     // padded queries carry lse = +inf -> 0
+                pd[u][r] = pr;
+                ds[u][r] = pr * (dp[r] - dd[r]);
+              }
             }
           }
-        }
-        const bf16x8 dsf = pack8(ds[0], ds[1]), pf = pack8(pd[0], pd[1]);
+          const bf16x8 dsf = pack8(ds[0], ds[1]), pf = pack8(pd[0], pd[1]);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Qt, dt * 16 + lq, 2 * t2, gq), dsf, dkacc[dt], 0, 0, 0);
-          dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(dOt, dt * 16 + lq, 2 * t2, gq), pf, dvacc[dt], 0, 0, 0);
+          for (int dt = 0; dt < 2; ++dt) {
+            dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Qt, dt * 16 + lq, 2 * t2, gq), dsf, dkacc[dt], 0, 0, 0);
+            dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(dOt, dt * 16 + lq, 2 * t2, gq), pf, dvacc[dt], 0, 0, 0);
+          }
         }
       }
     }

@@ -92,7 +92,11 @@ def test_c_abi_exports_every_declared_symbol():
     import re
     from fiber_amd import lib
     if not os.path.isfile(lib.LIB_PATH):
-        pytest.skip("libfiber_hip.so not built (run __graft_entry__.build())")
+        import shutil
+        if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+            pytest.skip("libfiber_hip.so not built and no hipcc here")
+        import __graft_entry__
+        __graft_entry__.build()          # cross-compiles for gfx950 without a GPU
     l = lib.load()
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "fiber_hip.h")).read()
     declared = set(re.findall(r"\bint\s+(fiber_\w+)\s*\(", hdr))
