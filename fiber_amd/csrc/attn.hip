@@ -155,11 +155,11 @@ __device__ __forceinline__ float win_bias(const AttnP& p, const float* btab, int
 }
 
 // ===================================================== forward =================================================
-template <int D>
+template <int D, bool WINDOW>
 __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = D / 32, DT = D / 16;
-  const int nb = p.window ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
+  const int nb = WINDOW ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
   Lds L = carve<D>(smem, nb, 1, 1);
   bf16* Ks = L.rm0; bf16* Vt = L.tr0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnP p) {
   int qtok = 0, qreg = 0;
   {
     const int ic = qvalid ? i : p.Lq - 1;
-    if (p.window) window_tok(p, g, ic, qtok, qreg); else qtok = g * p.Lq + ic;
+    if (WINDOW) window_tok(p, g, ic, qtok, qreg); else qtok = g * p.Lq + ic;
   }
   for (int t = threadIdx.x; t < nb; t += blockDim.x) L.btab[t] = p.bias_table[(size_t)t * p.H + h];
 
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnP p) {
         for (int r = 0; r < 4; ++r) {
           const int jl = kt * 16 + gq * 4 + r;
           float v = a[r] * p.scale + L.addmask[jl];
-          if (p.window) {
+          if (WINDOW) {
             v += win_bias(p, L.btab, qvalid ? i : 0, min(kbase + jl, p.Lk - 1));
             if (L.reg[jl] != qreg) v += -100.f;
           }
@@ -293,11 +293,11 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
 }
 
 // ===================================================== backward, pass A: dQ (+ dbias) ==========================
-template <int D>
+template <int D, bool WINDOW>
 __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = D / 32, DT = D / 16;
-  const int nb = p.window ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
+  const int nb = WINDOW ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
   Lds L = carve<D>(smem, nb, 2, 1);
   bf16* Ks = L.rm0; bf16* Vs = L.rm1; bf16* Kt = L.tr0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
     int qtok = 0, qreg = 0;
     {
       const int ic = qvalid ? i : p.Lq - 1;
-      if (p.window) window_tok(p, g, ic, qtok, qreg); else qtok = g * p.Lq + ic;
+      if (WINDOW) window_tok(p, g, ic, qtok, qreg); else qtok = g * p.Lq + ic;
     }
     bf16x8 qf[KS], dof[KS];
 #pragma unroll
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
               for (int r = 0; r < 4; ++r) {
                 const int jl = kt * 16 + gq * 4 + r;
                 float sv = a[r] * p.scale + L.addmask[jl];
-                if (p.window) {
+                if (WINDOW) {
                   sv += win_bias(p, L.btab, qvalid ? i : 0, min(kbase + jl, p.Lk - 1));
                   if (L.reg[jl] != qreg) sv += -100.f;
                 }
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
                 const float d = qvalid ? pr * (dpe - dlt) : 0.f;
                 ds[u][r] = d;
               }
-              if (p.window) {
+              if (WINDOW) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dbacc[kt][r] += ds[u][r];
               }
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
       }
     }
   }
-  if (p.window && p.dbias_part && qvalid) {           // single key chunk guaranteed by the host for WINDOW mode
+  if (WINDOW && p.dbias_part && qvalid) {           // single key chunk guaranteed by the host for WINDOW mode
     float* dst = p.dbias_part + (((size_t)blockIdx.z * p.H + h) * p.Lq + i) * p.Lk;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
@@ -417,11 +417,11 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
 }
 
 // ===================================================== backward, pass B: dK, dV ================================
-template <int D>
+template <int D, bool WINDOW>
 __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = D / 32, DT = D / 16;
-  const int nb = p.window ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
+  const int nb = WINDOW ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
   Lds L = carve<D>(smem, nb, 2, 2);
   bf16* Qs = L.rm0; bf16* dOs = L.rm1; bf16* Qt = L.tr0; bf16* dOt = L.tr1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnP p) {
   float kadd = 0.f;
   {
     const int jc = kvalid ? j : p.Lk - 1;
-    if (p.window) window_tok(p, g, jc, ktok, kreg);
+    if (WINDOW) window_tok(p, g, jc, ktok, kreg);
     else { ktok = g * p.Lk + jc; if (p.kmask) kadd = p.kmask[(size_t)g * p.Lk + jc]; }
   }
   for (int t = threadIdx.x; t < nb; t += blockDim.x) L.btab[t] = p.bias_table[(size_t)t * p.H + h];
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnP p) {
               const int il = qt * 16 + gq * 4 + r;      // chunk-local query
               const int ig = min(qbase + il, p.Lq - 1);
               float sv = a[r] * p.scale + kadd;
-              if (p.window) {
+              if (WINDOW) {
                 sv += win_bias(p, L.btab, ig, kvalid ? j : 0);
                 if (L.reg[il] != kreg) sv += -100.f;
               }
@@ -550,7 +550,8 @@ int launch_fwd(AttnP& p, hipStream_t st) {
   const int nstrips = cdiv(p.Lq, 16), nw = pick_waves(nstrips);
   const int nb = p.window ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
   const size_t sh = lds_bytes<D>(nb, 1, 1);
-  hipLaunchKernelGGL((attn_fwd_kernel<D>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), sh, st, p);
+  if (p.window) hipLaunchKernelGGL((attn_fwd_kernel<D, true>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), sh, st, p);
+  else hipLaunchKernelGGL((attn_fwd_kernel<D, false>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), sh, st, p);
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }
@@ -579,7 +580,8 @@ int launch_bwd(AttnP& p, float* delta, float* dbias_table, float* dbias_ws, int 
       gz = cdiv(p.G, p.groups_per_block);
       p.dbias_part = dbias_ws;
     }
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<D>), dim3(cdiv(nstrips, nw), p.H, gz), dim3(64 * nw), lds_bytes<D>(nb, 2, 1), st, p);
+    if (p.window) hipLaunchKernelGGL((attn_bwd_dq_kernel<D, true>), dim3(cdiv(nstrips, nw), p.H, gz), dim3(64 * nw), lds_bytes<D>(nb, 2, 1), st, p);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<D, false>), dim3(cdiv(nstrips, nw), p.H, gz), dim3(64 * nw), lds_bytes<D>(nb, 2, 1), st, p);
     FIBER_CHECK_LAUNCH();
     if (p.window) {
       if (hipMemsetAsync(dbias_table, 0, (size_t)nb * p.H * sizeof(float), st) != hipSuccess) return FIBER_ELAUNCH;
@@ -589,7 +591,8 @@ int launch_bwd(AttnP& p, float* delta, float* dbias_table, float* dbias_ws, int 
   }
   {
     const int nstrips = cdiv(p.Lk, 16), nw = pick_waves(nstrips);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<D>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), lds_bytes<D>(nb, 2, 2), st, p);
+    if (p.window) hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, true>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), lds_bytes<D>(nb, 2, 2), st, p);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, false>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), lds_bytes<D>(nb, 2, 2), st, p);
     FIBER_CHECK_LAUNCH();
   }
   return FIBER_OK;
@@ -599,12 +602,18 @@ bool attr_done = false;
 void ensure_attrs() {
   if (attr_done) return;
   const int big = 160 * 1024;
-  hipFuncSetAttribute((const void*)attn_fwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  hipFuncSetAttribute((const void*)attn_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)attn_fwd_kernel<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)attn_fwd_kernel<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)attn_fwd_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)attn_fwd_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   attr_done = true;
 }
 
