@@ -133,7 +133,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("FIBER_BENCH_BATCH", "128")), help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("FIBER_BENCH_BATCH", "256")), help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -192,7 +192,9 @@ def main():
         dt = t.item()
     ms = dt / args.steps * 1e3
     if rank == 0:
-        print(f"[bench] {ms:.2f} ms/step, {args.batch * world * args.steps / dt:.1f} images/s", file=sys.stderr, flush=True)
+        print(f"[bench] {ms:.2f} ms/step, {args.batch * world * args.steps / dt:.1f} images/s, peak HBM "
+              f"{torch.cuda.max_memory_allocated() / 2**30:.1f} GiB allocated / {torch.cuda.max_memory_reserved() / 2**30:.1f} GiB reserved",
+              file=sys.stderr, flush=True)
     ips = args.batch * world * args.steps / dt
     lossv = loss.item()
 
