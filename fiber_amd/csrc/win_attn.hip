@@ -30,7 +30,6 @@ struct WinP {
   float* lse; const float* delta; const float* bias_table; float* dbias_part;
   int B, Hres, Wres, C, heads, ws, shift, nWw, nWh, nW, G, N, gpb;
   int hmajor;   // qkv channel layout: 0 = [3][heads][32] (reference, swin_transformer.py:202), 1 = [heads][3][32] (q|k|v of a head adjacent)
-  int dbg;   // ablation switches (FIBER_WIN_DBG): 1 = skip the MFMA/softmax body, 2 = skip LDS staging writes
 };
 
 __device__ __forceinline__ int region_of(int x, int n, int ws, int shift) { return x < n - ws ? 0 : (x < n - shift ? 1 : 2); }
@@ -636,8 +635,6 @@ WinP make(const void* qkv, int B, int Hres, int Wres, int C, int heads, int ws, 
   p.nWw = Wres / ws; p.nWh = Hres / ws; p.nW = p.nWw * p.nWh; p.G = B * p.nW; p.N = ws * ws;
   const int nz = blocks_for(p.G, heads);
   p.gpb = cdiv(p.G, nz);
-  static const int dbg = getenv("FIBER_WIN_DBG") ? atoi(getenv("FIBER_WIN_DBG")) : 0;
-  p.dbg = dbg;
   return p;
 }
 

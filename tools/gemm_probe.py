@@ -1,4 +1,6 @@
-"""Ablation of the GEMM main loop (debug switches in act bits: 0x100 no DMA, 0x200 no MFMA, 0x400 no barrier)."""
+"""Ablation of the GEMM main loop: act bit 0x100 skips the in-loop DMA (operands stay whatever the prologue staged), which
+separates the MFMA + LDS-read ceiling from the L2->LDS DMA cost.  (Earlier builds also had no-MFMA / no-barrier switches;
+their results are recorded in profiles/r01_summary.md.)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,7 +19,7 @@ for M, N, K in ((18432, 512, 2048), (18432, 2048, 512), (4608, 4096, 1024), (737
     w = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
     fl = 2.0 * M * N * K
     row = f"M={M} N={N} K={K}:"
-    for name, flag in (("full", 0), ("noDMA", 0x100), ("noMFMA", 0x200), ("noDMA+noMFMA", 0x300), ("noDMA+nosync", 0x500), ("nosync(racy)", 0x400)):
+    for name, flag in (("full", 0), ("noDMA", 0x100)):
         t = timeit(lambda: ops.gemm_nt(x, w, None, None, flag, False))
         row += f"  {name} {t:7.1f}us ({fl / t / 1e6:6.0f}TF)"
     t = timeit(lambda: torch.nn.functional.linear(x, w))
