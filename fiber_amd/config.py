@@ -32,3 +32,22 @@ def make_config(**over):
         else:
             c[k] = v
     return c
+
+
+# Named task configs of the path built here (reference config.py:95-110 pre-training, :134-150 VQAv2 fine-tune).
+NAMED = {
+    "task_pretrain_mlm_itm": dict(
+        exp_name="mlm_itm", loss_names={"itm": 1, "mlm": 1}, draw_false_image=1, batch_size=4096, max_steps=100000,
+        warmup_steps=0.1, whole_word_masking=False, learning_rate=1e-5, lr_mult_cross_modal=5, lr_mult_head=5),
+    "task_finetune_vqa": dict(
+        exp_name="finetune_vqa", loss_names={"vqa": 1}, batch_size=512, max_epoch=10, max_steps=None, warmup_steps=0.1,
+        learning_rate=2e-5, lr_mult_cross_modal=5, lr_mult_head=50, max_text_len=50, image_size=576,
+        pretrained_vit=False, draw_false_image=0),
+}
+
+
+def named_config(name, **over):
+    """make_config(**NAMED[name], **over): the sacred `with <name> key=value` command line without sacred."""
+    kw = dict(NAMED[name])
+    kw.update(over)
+    return make_config(**kw)

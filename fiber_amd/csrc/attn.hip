@@ -311,11 +311,15 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
   const uint32_t thresh = (uint32_t)((double)p.p_drop * 4294967296.0);
   const float inv_keep = 1.f / (1.f - p.p_drop);
 
+  const int g0 = blockIdx.z * p.groups_per_block, g1 = min(p.G, g0 + p.groups_per_block);
+  // WINDOW mode walks key chunks outermost so that the per-lane dbias accumulator only ever spans one chunk
+  // (N = 324 at 576^2 needs three); dQ is then accumulated across chunk passes by the lane that owns it.
+  const int nouter = WINDOW ? nchunk : 1;
+  for (int co = 0; co < nouter; ++co) {
   f32x4 dbacc[NKT];
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt) dbacc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int g0 = blockIdx.z * p.groups_per_block, g1 = min(p.G, g0 + p.groups_per_block);
+  const int c_lo = WINDOW ? co : 0, c_hi = WINDOW ? co + 1 : nchunk;
   for (int g = g0; g < g1; ++g) {
     int qtok = 0, qreg = 0;
     {
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) dqacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int c = 0; c < nchunk; ++c) {
+    for (int c = c_lo; c < c_hi; ++c) {
       const int kbase = c * tpc * 16;
       __syncthreads();
       fill_rowmeta(p, L, g, kbase, tpc * 16, p.Lk, true);
@@ -394,25 +398,33 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
     if (qvalid) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
+        bf16x4* dst = reinterpret_cast<bf16x4*>(p.dq + (size_t)qtok * p.lddq + h * D + dt * 16 + gq * 4);
         bf16x4 o;
+        if (WINDOW && co > 0) {
+          const bf16x4 prev = *dst;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = f2bf(dqacc[dt][r] * p.scale);
-        *reinterpret_cast<bf16x4*>(p.dq + (size_t)qtok * p.lddq + h * D + dt * 16 + gq * 4) = o;
+          for (int r = 0; r < 4; ++r) o[r] = f2bf(bf2f(prev[r]) + dqacc[dt][r] * p.scale);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = f2bf(dqacc[dt][r] * p.scale);
+        }
+        *dst = o;
       }
     }
   }
-  if (WINDOW && p.dbias_part && qvalid) {           // single key chunk guaranteed by the host for WINDOW mode
-    float* dst = p.dbias_part + (((size_t)blockIdx.z * p.H + h) * p.Lq + i) * p.Lk;
+  if (WINDOW && p.dbias_part && qvalid) {
+    float* dst = p.dbias_part + (((size_t)blockIdx.z * p.H + h) * p.Lq + i) * p.Lk + co * tpc * 16;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       if (kt < tpc) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int j = kt * 16 + gq * 4 + r;
-          if (j < p.Lk) dst[j] = dbacc[kt][r];
+          if (co * tpc * 16 + j < p.Lk) dst[j] = dbacc[kt][r];
         }
       }
     }
+  }
   }
 }
 
@@ -574,7 +586,6 @@ int launch_bwd(AttnP& p, float* delta, float* dbias_table, float* dbias_ws, int 
     p.groups_per_block = 1;
     p.dbias_part = nullptr;
     if (p.window) {
-      if (p.Lk > CH) return FIBER_EINVAL;             // bias-gradient accumulation needs a single key chunk
       gz = nz;
       p.groups_per_block = cdiv(p.G, nz);
       gz = cdiv(p.G, p.groups_per_block);

@@ -3,7 +3,7 @@
 Mirrors coarse_grained/fiber/modules/fiber_module.py: constructor wiring (:27-179), infer() (:224-367, fused branch
 :310-367, image-only :279-308, text-only :247-277), forward() (:431-471), training_step (:473-478),
 configure_optimizers (:522).  Parameter names / shapes equal the reference's so a `fiber_pretrain.ckpt` state dict loads
-(`load_path`, ITC queue keys dropped as at :141-146).  Captioning / ITC-queue / VQA-test code is out of scope (SURVEY.md
+(`load_path`, ITC queue keys dropped as at :141-146).  Captioning / ITC-queue / NLVR2 code is out of scope (SURVEY.md
 section 2) and raises if requested.
 """
 import types
@@ -15,6 +15,7 @@ from .. import ops
 from ..lightning import LightningModule
 from . import fiber_utils, heads, objectives, roberta, swin_transformer
 from .roberta import RobertaModel
+from .swin_helpers import swin_adapt_position_encoding
 
 
 class FIBERTransformerSS(LightningModule):
@@ -86,21 +87,30 @@ class FIBERTransformerSS(LightningModule):
             self.rank_output.weight.data = self.itm_score.fc.weight.data[1:, :]
             self.rank_output.bias.data = self.itm_score.fc.bias.data[1:]
 
-        if config["load_path"] != "":
-            ckpt = torch.load(config["load_path"], map_location="cpu")
-            state_dict = ckpt["state_dict"]
-            for key in ["image_queue", "text_queue", "queue_ptr", "queue_total", "image_input_queue", "text_input_queue",
-                        "text_input_mask_queue"]:
-                state_dict.pop(key, None)
+        if config["load_path"] != "" and not config.get("test_only", False):   # pre-trained -> downstream (:138-147)
+            state_dict = self._read_checkpoint(config["load_path"])
+            state_dict = swin_adapt_position_encoding(state_dict, before=config["resolution_before"],
+                                                      after=config["image_size"])
             self.load_state_dict(state_dict, strict=False)
 
         if ln.get("vqa", 0) > 0:
             vs = config["vqav2_label_size"]
-            self.vqa_classifier = nn.Sequential(nn.Linear(hs * 2, hs * 2), nn.LayerNorm(hs * 2), nn.GELU(), nn.Linear(hs * 2, vs))
+            self.vqa_classifier = heads.VQAClassifier(hs * 2, vs)
             self.vqa_classifier.apply(objectives.init_weights)
 
         fiber_utils.set_metrics(self)
         self.current_tasks = list()
+
+        if config["load_path"] != "" and config.get("test_only", False):       # fine-tuned checkpoint, heads included (:173-180)
+            self.load_state_dict(self._read_checkpoint(config["load_path"]), strict=False)
+
+    @staticmethod
+    def _read_checkpoint(path):
+        state_dict = torch.load(path, map_location="cpu")["state_dict"]
+        for key in ["image_queue", "text_queue", "queue_ptr", "queue_total", "image_input_queue", "text_input_queue",
+                    "text_input_mask_queue"]:
+            state_dict.pop(key, None)
+        return state_dict
 
     # parameters that never receive a gradient on the fused MLM+ITM path (SURVEY.md section 7 "DDP unused parameters")
     def unused_parameter_names(self):
@@ -210,7 +220,7 @@ class FIBERTransformerSS(LightningModule):
             if "itm" in self.current_tasks:
                 ret.update(objectives.compute_itm(self, batch, batch.get("itm_labels_override")))
         if "vqa" in self.current_tasks:
-            raise NotImplementedError("VQA fine-tune head is SURVEY.md section 8(f) 'next'")
+            ret.update(objectives.compute_vqa(self, batch))
         return ret
 
     def training_step(self, batch, batch_idx):

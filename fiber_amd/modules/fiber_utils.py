@@ -43,10 +43,27 @@ class Accuracy(_Running):
         return self.last
 
 
+class VQAScore(_Running):
+    """my_metrics.py:49-69: soft VQA accuracy = score of the arg-max answer, averaged over questions."""
+
+    def __call__(self, logits, target):
+        with torch.no_grad():
+            pick = logits.detach().float().argmax(dim=1, keepdim=True)
+            self.last = target.detach().float().gather(1, pick).mean()
+        return self.last
+
+    def compute(self):
+        return self.last
+
+
 def set_metrics(pl_module):
     for split in ["train", "val"]:
         for k, v in pl_module.hparams.config["loss_names"].items():
             if v <= 0:
+                continue
+            if k == "vqa":                     # fiber_utils.py:19-21
+                setattr(pl_module, f"{split}_vqa_score", VQAScore())
+                setattr(pl_module, f"{split}_{k}_loss", Scalar())
                 continue
             setattr(pl_module, f"{split}_{k}_accuracy", Accuracy())
             setattr(pl_module, f"{split}_{k}_loss", Scalar())

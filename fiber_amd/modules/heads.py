@@ -1,4 +1,5 @@
-"""Pooler / ITMHead / MLMHead with the reference's parameter names (coarse_grained/fiber/modules/heads.py:8-43).
+"""Pooler / ITMHead / MLMHead / VQA classifier with the reference's parameter names
+(coarse_grained/fiber/modules/heads.py:8-43, fiber_module.py:149-157).
 
 Small caller-side GEMMs: the 768x768 dense layers use the HIP GEMM; the 2-way ITM classifier and the 50265-way
 vocabulary decoder are plain library GEMMs ("keep on library GEMM").
@@ -55,3 +56,18 @@ class MLMHead(nn.Module):
     def forward(self, x):
         h = self.transform(x)
         return F.linear(h, ops.cast_bf16(self.decoder.weight), ops.cast_bf16(self.bias))
+
+
+class VQAClassifier(nn.Sequential):
+    """fiber_module.py:149-157 `vqa_classifier` = Sequential(Linear, LayerNorm, GELU, Linear); the Sequential base keeps the
+    checkpoint keys (`vqa_classifier.0.weight`, `.1.weight`, `.3.weight`).  The 1536x1536 dense layer and the LayerNorm run
+    on the HIP kernels; the 3129-way answer classifier is a library GEMM like the other caller-side heads."""
+
+    def __init__(self, hidden, n_answers):
+        super().__init__(nn.Linear(hidden, hidden), nn.LayerNorm(hidden), nn.GELU(), nn.Linear(hidden, n_answers))
+
+    def forward(self, x):
+        fc0, ln, _, fc1 = self
+        h = ops.linear(x.to(torch.bfloat16), fc0.weight, fc0.bias)
+        h = ops.layernorm(h, ln.weight, ln.bias, ln.eps)
+        return F.linear(F.gelu(h.float()), fc1.weight, fc1.bias)

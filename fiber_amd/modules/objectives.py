@@ -1,5 +1,5 @@
-"""Loss functions on the metric path: compute_mlm / compute_itm / init_weights
-(reference coarse_grained/fiber/modules/objectives.py:17-75, 502-510).  Same call signatures and return keys."""
+"""Loss functions on the metric path: compute_mlm / compute_itm / compute_vqa / init_weights
+(reference coarse_grained/fiber/modules/objectives.py:17-75, 182-213, 502-510).  Same call signatures and return keys."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -81,6 +81,27 @@ def compute_mlm_itm_fused(pl_module, batch, itm_labels=None):
         acc = getattr(pl_module, f"{phase}_{task}_accuracy")(ret[f"{task}_logits"], ret[f"{task}_labels"])
         pl_module.log(f"{task}/{phase}/loss", loss)
         pl_module.log(f"{task}/{phase}/accuracy", acc)
+    return ret
+
+
+def compute_vqa(pl_module, batch):
+    """VQAv2 fine-tune head (objectives.py:182-213): soft-target BCE over the answer vocabulary, scaled by its size."""
+    infer = pl_module.infer(batch, mask_text=False, mask_image=False)
+    vqa_logits = pl_module.vqa_classifier(infer["cls_feats"])
+    n_ans = pl_module.hparams.config["vqav2_label_size"]
+    vqa_targets = torch.zeros(len(vqa_logits), n_ans, device=vqa_logits.device)
+    vqa_labels, vqa_scores = batch["vqa_labels"], batch["vqa_scores"]
+    for i, (_label, _score) in enumerate(zip(vqa_labels, vqa_scores)):
+        for lab, sc in zip(_label, _score):
+            vqa_targets[i, lab] = sc
+    vqa_loss = F.binary_cross_entropy_with_logits(vqa_logits.float(), vqa_targets) * vqa_targets.shape[1]
+    ret = {"vqa_loss": vqa_loss, "vqa_logits": vqa_logits, "vqa_targets": vqa_targets, "vqa_labels": vqa_labels,
+           "vqa_scores": vqa_scores}
+    phase = "train" if pl_module.training else "val"
+    loss = getattr(pl_module, f"{phase}_vqa_loss")(ret["vqa_loss"])
+    score = getattr(pl_module, f"{phase}_vqa_score")(ret["vqa_logits"], ret["vqa_targets"])
+    pl_module.log(f"vqa/{phase}/loss", loss)
+    pl_module.log(f"vqa/{phase}/score", score)
     return ret
 
 

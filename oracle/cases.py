@@ -58,6 +58,16 @@ PATH_CASES = {
 }
 
 
+# VQAv2 fine-tune head at 576^2 (BASELINE.json configs[3]; reference config.py:134-150): 18x18 windows (N = 324), 50 text
+# tokens, BCE over the answer vocabulary.  `vqa_tiny576` keeps the 576^2 geometry with shrunken widths so it runs anywhere.
+VQA_CASES = {
+    "vqa_tiny576": dict(config=dict(TINY, image_size=576, max_text_len=20, vqav2_label_size=97,
+                                    loss_names={"vqa": 1}), B=2),
+    "vqa_swin_b_576": dict(config=dict(SWIN_B, image_size=576, max_text_len=50, loss_names={"vqa": 1}), B=1),
+}
+ADAPT_CASE = dict(before=384, after=576, heads=4)       # swin_adapt_position_encoding: 23^2 -> 35^2 rows
+
+
 def randn(name, shape, seed=0, std=1.0):
     g = detgen._rng("input:" + name, seed)
     return torch.from_numpy((g.standard_normal(shape) * std).astype(np.float32))

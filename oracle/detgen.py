@@ -74,3 +74,15 @@ def synth_batch(B, image_size=384, max_text_len=40, vocab=50265, seed=0, min_len
         "text_ids": t(ids), "text_masks": t(masks), "text_labels": torch.full((B, max_text_len), -100, dtype=torch.long),
         "text_ids_mlm": t(ids_mlm), "text_labels_mlm": t(labels_mlm), "itm_labels": t(itm),
     }
+
+
+def synth_vqa(B, n_answers=3129, seed=0):
+    """Ragged soft VQA targets (schema: vqav2_dataset.py `vqa_labels` / `vqa_scores`): per question 0..4 distinct answer
+    ids with scores from the VQAv2 soft-accuracy set; question 1 (when present) has no answer at all."""
+    g = _rng("vqa", seed)
+    labels, scores = [], []
+    for b in range(B):
+        k = 0 if b == 1 else int(g.integers(1, 5))
+        labels.append([int(v) for v in g.choice(n_answers, size=k, replace=False)])
+        scores.append([float(v) for v in g.choice(np.array([0.3, 0.6, 0.9, 1.0]), size=k)])
+    return {"vqa_labels": labels, "vqa_scores": scores}

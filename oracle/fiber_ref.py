@@ -498,6 +498,9 @@ class FiberRef(nn.Module):
         if c["loss_names"].get("itm", 0) > 0:
             self.itm_score = ITMHead(hs * 2)
             self.rank_output = nn.Linear(hs, 1)
+        if c["loss_names"].get("vqa", 0) > 0:             # fiber_module.py:149-157
+            self.vqa_classifier = nn.Sequential(nn.Linear(hs * 2, hs * 2), nn.LayerNorm(hs * 2), nn.GELU(),
+                                                nn.Linear(hs * 2, c["vqav2_label_size"]))
         for name, m in self.named_children():
             if name not in ("vit_model", "text_transformer"):
                 m.apply(_init_head)
@@ -550,6 +553,18 @@ class FiberRef(nn.Module):
         out = self.infer(batch, img=imgs)
         logits = self.itm_score(out["cls_feats"])
         return {"itm_loss": F.cross_entropy(logits, itm_labels.long()), "itm_logits": logits, "itm_labels": itm_labels}
+
+    def compute_vqa(self, batch):
+        """objectives.py:182-213: dense soft targets from the ragged (labels, scores) lists; BCE * answer-vocabulary size."""
+        out = self.infer(batch)
+        logits = self.vqa_classifier(out["cls_feats"])
+        targets = torch.zeros_like(logits)
+        for i, (labs, scs) in enumerate(zip(batch["vqa_labels"], batch["vqa_scores"])):
+            for lab, sc in zip(labs, scs):
+                targets[i, lab] = sc
+        loss = F.binary_cross_entropy_with_logits(logits, targets) * targets.shape[1]
+        return {"vqa_loss": loss, "vqa_logits": logits, "vqa_targets": targets, "cls_feats": out["cls_feats"],
+                "text_feats": out["text_feats"], "image_feats": out["image_feats"]}
 
     def training_loss(self, batch, itm_labels):
         return self.compute_mlm(batch)["mlm_loss"] + self.compute_itm(batch, itm_labels)["itm_loss"]

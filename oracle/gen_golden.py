@@ -158,11 +158,17 @@ class RefFused(nn.Module):
         self.cross_modal_image_pooler_itc = heads.Pooler(hs)
         self.cross_modal_text_pooler_itc = heads.Pooler(hs)
         hcfg = shim.roberta_config(vocab_size=c["vocab_size"], hidden_size=hs, layer_norm_eps=1e-12)
-        self.mlm_score = heads.MLMHead(hcfg)
-        self.itm_score = heads.ITMHead(hs * 2)
-        self.rank_output = nn.Linear(hs, 1)
+        ln = c["loss_names"]
+        if ln.get("mlm", 0) > 0:
+            self.mlm_score = heads.MLMHead(hcfg)
+        if ln.get("itm", 0) > 0:
+            self.itm_score = heads.ITMHead(hs * 2)
+            self.rank_output = nn.Linear(hs, 1)
+        if ln.get("vqa", 0) > 0:                           # wiring of fiber_module.py:149-157
+            self.vqa_classifier = nn.Sequential(nn.Linear(hs * 2, hs * 2), nn.LayerNorm(hs * 2), nn.GELU(),
+                                                nn.Linear(hs * 2, c["vqav2_label_size"]))
 
-    def infer(self, batch, mask_text=False, img=None):
+    def infer(self, batch, mask_text=False, img=None, mask_image=False):
         c = self.c
         img = batch["image"][0] if img is None else img
         sfx = "_mlm" if mask_text else ""
@@ -237,6 +243,74 @@ def gen_paths(sw, rb, heads):
         save(name, d)
 
 
+class _Metric:
+    def __call__(self, *a):
+        return a[0].detach() if len(a) == 1 else torch.zeros(())
+
+
+def gen_vqa(sw, rb, heads):
+    """The reference's own objectives.compute_vqa driven over the reference modules (pl_module duck-typed)."""
+    obj = shim._load("objectives", os.path.join(shim.MODS, "objectives.py"), "_fiber_reference_modules")
+    for name, pc in cases.VQA_CASES.items():
+        torch.manual_seed(0)
+        m = RefFused(sw, rb, heads, pc["config"]).eval()
+        detgen.fill_(m)
+        c = m.c
+        m.hparams = type("H", (), {"config": c})()
+        m.device = torch.device("cpu")
+        m.log = lambda *a, **k: None
+        for ph in ("train", "val"):
+            setattr(m, f"{ph}_vqa_loss", _Metric())
+            setattr(m, f"{ph}_vqa_score", _Metric())
+        b = detgen.synth_batch(pc["B"], c["image_size"], c["max_text_len"], c["vocab_size"], seed=2,
+                               min_len=min(8, c["max_text_len"] // 2))
+        b.update(detgen.synth_vqa(pc["B"], c["vqav2_label_size"], seed=2))
+        d = {}
+        feats = {}
+        inner = m.infer
+        m.infer = lambda batch, **kw: feats.setdefault("o", inner(batch, **kw))
+        ret = obj.compute_vqa(m, b)
+        for k in ("text_feats", "image_feats", "cls_feats"):
+            cases.flatten_summary(k, feats["o"][k], d)
+        cases.flatten_summary("vqa_logits", ret["vqa_logits"], d)
+        cases.flatten_summary("vqa_targets", ret["vqa_targets"], d)
+        d["vqa_loss"] = np.float64(ret["vqa_loss"].item())
+        ret["vqa_loss"].backward()
+        unused = []
+        for n, p in m.named_parameters():
+            if p.grad is None:
+                unused.append(n)
+            else:
+                d[f"gradnorm/{n}"] = np.float64(p.grad.double().norm().item())
+        d["unused_params"] = np.array(unused)
+        for n in ("vit_model.patch_embed.proj.weight", "vit_model.layers.2.blocks.15.attn.relative_position_bias_table",
+                  "vit_model.layers.0.blocks.1.attn.relative_position_bias_table",
+                  "vit_model.layers.3.blocks.1.attn.alpha_i2t", "vqa_classifier.3.bias"):
+            cases.flatten_summary("grad/" + n, dict(m.named_parameters())[n].grad, d)
+        print(f"  {name}: vqa_loss {ret['vqa_loss'].item():.6f}")
+        save(name, d)
+
+
+def gen_adapt():
+    """swin_helpers.swin_adapt_position_encoding run on a seeded fake state dict."""
+    hp = sys.modules["_fiber_reference_modules.swin_helpers"]
+    ac = cases.ADAPT_CASE
+    side = 2 * (ac["before"] // 32) - 1
+    sd = {
+        "vit_model.layers.0.blocks.0.attn.relative_position_bias_table": cases.randn("adapt.t0", (side * side, ac["heads"])),
+        "vit_model.layers.2.blocks.3.attn.relative_position_bias_table": cases.randn("adapt.t1", (side * side, 2 * ac["heads"])),
+        "vit_model.layers.0.blocks.0.attn.relative_position_index": torch.zeros(4, 4, dtype=torch.long),
+        "vit_model.layers.0.blocks.1.attn_mask": torch.zeros(2, 4, 4),
+        "vit_model.layers.0.blocks.0.norm1.weight": torch.ones(8),
+    }
+    out = hp.swin_adapt_position_encoding(dict(sd), before=ac["before"], after=ac["after"])
+    d = {"keys": np.array(sorted(out.keys()))}
+    for k, v in out.items():
+        if k.endswith("relative_position_bias_table"):
+            d["table/" + k] = v.numpy()
+    save("adapt_pos", d)
+
+
 def main():
     torch.set_num_threads(8)
     sw, rb = shim.load_reference()
@@ -252,6 +326,10 @@ def main():
         gen_roberta(rb)
     if not only or "paths" in only:
         gen_paths(sw, rb, heads)
+    if not only or "vqa" in only:
+        gen_vqa(sw, rb, heads)
+    if not only or "adapt" in only:
+        gen_adapt()
 
 
 if __name__ == "__main__":

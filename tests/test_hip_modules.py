@@ -166,6 +166,53 @@ def test_fused_path(name, golden):
                     _sub_close("grad " + n, params[n].grad, gold, "grad/" + n, 0.15 if "alpha_" in n else 6e-2)
 
 
+@pytest.mark.parametrize("name", list(cases.VQA_CASES))
+def test_vqa_finetune_path(name, golden):
+    """BASELINE.json configs[3] (VQAv2 head at 576^2, 18x18 windows, 50 text tokens) against the reference's compute_vqa."""
+    from fiber_amd.config import make_config
+    from fiber_amd.modules import FIBERTransformerSS, fiber_utils
+    pc, gold = cases.VQA_CASES[name], golden(name)
+    ref = detgen.fill_(R.FiberRef(pc["config"]).eval())
+    c = ref.config
+    model = FIBERTransformerSS(make_config(**pc["config"])).eval()
+    load_from_oracle(model, ref)
+    model.to(DEV)
+    b = detgen.synth_batch(pc["B"], c["image_size"], c["max_text_len"], c["vocab_size"], seed=2,
+                           min_len=min(8, c["max_text_len"] // 2))
+    b.update(detgen.synth_vqa(pc["B"], c["vqav2_label_size"], seed=2))
+    bd = _to_dev(b)
+    fiber_utils.set_task(model)
+    assert model.current_tasks == ["vqa"]
+    out = model(bd)
+    _sub_close("vqa_logits", out["vqa_logits"], gold, "vqa_logits", 3e-2)
+    assert np.array_equal(cases.summarize(out["vqa_targets"])["sub"], gold["vqa_targets/sub"])
+    gl = float(gold["vqa_loss"])
+    assert abs(out["vqa_loss"].item() - gl) < 5e-3 * gl, (out["vqa_loss"].item(), gl)
+    out["vqa_loss"].backward()
+    unused_gold = set(gold["unused_params"].tolist())
+    unused_prod = set(model.unused_parameter_names())
+    params = dict(model.named_parameters())
+    bad = []
+    for n, p in params.items():
+        if n in unused_gold:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, f"{n} should get no gradient"
+            assert n in unused_prod, f"{n} missing from unused_parameter_names()"
+        else:
+            assert n not in unused_prod, f"{n} wrongly listed unused"
+            gn = float(gold[f"gradnorm/{n}"])
+            got = p.grad.double().norm().item()
+            if gn < 1e-6:
+                assert got < 1e-2 * max(1.0, gl), (n, got)
+                continue
+            if abs(got - gn) > 0.08 * gn + 1e-6:
+                bad.append((n, got, gn))
+    assert len(bad) <= max(2, len(params) // 50), bad[:10]
+    for key in gold:
+        if key.startswith("grad/") and key.endswith("/sub"):
+            n = key[len("grad/"):-len("/sub")]
+            _sub_close("grad " + n, params[n].grad, gold, "grad/" + n, 0.15 if "alpha_" in n else 6e-2)
+
+
 def test_training_mode_runs_with_dropout():
     """Training mode with the reference defaults (text dropout 0.1, DropPath linspace(0,0.1)) runs end to end and
     produces finite losses / gradients; two steps with the same seed are bit-identical (counter-based RNG)."""

@@ -120,7 +120,7 @@ def _window_ref(qkv, table, B, H, W, heads, ws, shift):
 
 @pytest.mark.parametrize("B,H,W,heads,ws,shift", [
     (2, 6, 6, 1, 3, 0), (2, 6, 6, 2, 3, 1), (2, 8, 8, 2, 4, 2), (2, 14, 14, 3, 7, 3), (1, 24, 24, 4, 12, 6),
-    (2, 12, 12, 8, 12, 0), (1, 48, 48, 4, 12, 6), (1, 36, 36, 2, 18, 9),
+    (2, 12, 12, 8, 12, 0), (1, 48, 48, 4, 12, 6), (1, 36, 36, 2, 18, 9), (2, 18, 18, 4, 18, 0),
 ])
 def test_window_attention(ops, B, H, W, heads, ws, shift):
     C = heads * 32
@@ -131,8 +131,6 @@ def test_window_attention(ops, B, H, W, heads, ws, shift):
     tr = table.detach().clone().requires_grad_(True)
     oref = _window_ref(qr, tr, B, H, W, heads, ws, shift)
     assert_close("o", o, oref, 5e-3)
-    if ws * ws > 160:
-        return                                     # N=324 backward (576^2 config) is SURVEY 8(f) 'next'
     do = bf(rnd(B, H * W, C, seed=5))
     o.backward(do)
     oref.backward(do.float())

@@ -133,6 +133,35 @@ def test_fused_path(name, golden):
                     cases.check_summary("grad/" + n, params[n].grad, gold, 2e-3, 1e-6)
 
 
+@pytest.mark.parametrize("name", list(cases.VQA_CASES))
+def test_vqa_finetune_path(name, golden):
+    """VQAv2 head at 576^2 (N = 324 windows, 50 text tokens): oracle vs the reference's own compute_vqa."""
+    pc, gold = cases.VQA_CASES[name], golden(name)
+    m = detgen.fill_(R.FiberRef(pc["config"]).eval())
+    c = m.config
+    b = detgen.synth_batch(pc["B"], c["image_size"], c["max_text_len"], c["vocab_size"], seed=2,
+                           min_len=min(8, c["max_text_len"] // 2))
+    b.update(detgen.synth_vqa(pc["B"], c["vqav2_label_size"], seed=2))
+    out = m.compute_vqa(b)
+    for k in ("text_feats", "image_feats", "cls_feats", "vqa_logits", "vqa_targets"):
+        cases.check_summary(k, out[k], gold, 1e-4, 1e-5)
+    gl = float(gold["vqa_loss"])
+    assert abs(out["vqa_loss"].item() - gl) < 1e-5 * gl + 1e-4
+    out["vqa_loss"].backward()
+    unused = set(gold["unused_params"].tolist())
+    for n, p in m.named_parameters():
+        if n in unused:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, f"{n} should be unused"
+        else:
+            gn = float(gold[f"gradnorm/{n}"])
+            assert abs(p.grad.double().norm().item() - gn) <= 2e-3 * gn + 1e-7, n
+    params = dict(m.named_parameters())
+    for key in gold:
+        if key.startswith("grad/") and key.endswith("/sub"):
+            n = key[len("grad/"):-len("/sub")]
+            cases.check_summary("grad/" + n, params[n].grad, gold, 2e-3, 1e-6)
+
+
 def test_state_dict_keys_match_reference_layout():
     """Key names of the oracle tree follow the reference's checkpoint layout."""
     m = R.FiberRef(cases.SWIN_T)
