@@ -169,13 +169,165 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Epilogue shared by the LDS-DMA kernels: accumulators -> LDS tile (bf16, in ROUNDS row slabs) -> coalesced 16-byte rows.
+// Everything that selects code is a template parameter: with the variants as run-time flags the unrolled store passes
+// compiled to ~560 instructions each and the epilogue of a 256x256 tile cost 7 us *without* its stores (ablation in
+// tools/gemm_dbg.py) -- as much as the tile's MFMAs at K = 512.
+//   EPI 0: Y = rowscale * (acc + bias) + R          (HAS_RS / HAS_R)
+//   EPI 1: Ypre = acc + bias (optional);  Y = rowscale * gelu(bf16(acc + bias))
+//   EPI 2: Y = acc * gelu'(aux);  optional per-row-tile column sums of Y (colpart)
+//   FULL:  the tile lies entirely inside [M, N] (no row / column predicates)
+template <int BM, int BN, int WM, int WN, int ROUNDS, int EPI, bool HAS_R, bool HAS_RS, bool FULL>
+__device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], bf16* Cs,
+                                              const float* bias_s, int tm0, int tn0) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int CLD = BN + 8;
+  constexpr int HM = BM / ROUNDS;                       // rows staged per round
+  constexpr int CPR = BN / 8;                           // 16-byte chunks per tile row
+  constexpr int RPP = NT / CPR;                         // rows per store pass
+  constexpr int NPH = HM / RPP;                         // store passes per round
+  static_assert(WM % ROUNDS == 0 && HM % RPP == 0, "epilogue geometry");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int erow = tid / CPR, echunk = tid % CPR;
+  const int n_out = tn0 + echunk * 8;
+  const bool col_ok = FULL || n_out < a.N;
+  constexpr bool SIDE = HAS_R || EPI == 2;
+  const bf16* sidep = EPI == 2 ? a.aux : a.R;
+  const size_t sideld = EPI == 2 ? a.ldaux : a.ldr;
+  const bool has_bias = a.bias != nullptr;
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int h = 0; h < ROUNDS; ++h) {
+    const int mbase = tm0 + h * HM + erow;              // this thread's first output row in the round
+    // side rows / DropPath scales are requested BEFORE the staging pass so their latency hides behind it
+    bf16x8 side[SIDE ? NPH : 1];
+    float prs[(EPI == 1 && HAS_RS) ? NPH : 1];
+    if constexpr (SIDE) {
+      const bf16* sp = sidep + (size_t)mbase * sideld + n_out;
+#pragma unroll
+      for (int pp = 0; pp < NPH; ++pp)
+        if (FULL || (mbase + pp * RPP < a.M && col_ok)) side[pp] = *reinterpret_cast<const bf16x8*>(sp + (size_t)pp * RPP * sideld);
+    }
+    if constexpr (EPI == 1 && HAS_RS) {
+#pragma unroll
+      for (int pp = 0; pp < NPH; ++pp) prs[pp] = a.rowscale[min(mbase + pp * RPP, a.M - 1) / a.rows_per_sample];
+    }
+    if (ROUNDS == 1 || wm / (WM / ROUNDS) == h) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int ml = wm * WTM + i * 32 + (lane & 31);
+        float rsc = 1.f;
+        if constexpr (EPI == 0 && HAS_RS) rsc = a.rowscale[min(tm0 + ml, a.M - 1) / a.rows_per_sample];
+        bf16* crow = Cs + (ml - h * HM) * CLD + wn * WTN + (lane >> 5) * 4;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int nl = wn * WTN + j * 32 + q * 8 + (lane >> 5) * 4;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
+            if (EPI != 2 && has_bias) {
+              const float4 bb = *reinterpret_cast<const float4*>(bias_s + nl);
+              v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+            }
+            if constexpr (EPI == 0 && HAS_RS) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] *= rsc;
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+            *reinterpret_cast<bf16x4*>(crow + j * 32 + q * 8) = o;
+          }
+      }
+    }
+    __syncthreads();
+    {
+      bf16* yp = a.Y + (size_t)mbase * a.ldy + n_out;
+      bf16* prep = (EPI == 1 && a.Ypre) ? a.Ypre + (size_t)mbase * a.ldy + n_out : nullptr;
+      const size_t ystep = (size_t)RPP * a.ldy;
+      const bf16* cp = Cs + erow * CLD + echunk * 8;
+#pragma unroll
+      for (int pp = 0; pp < NPH; ++pp) {
+        if (FULL || (mbase + pp * RPP < a.M && col_ok)) {
+          bf16x8 v = *reinterpret_cast<const bf16x8*>(cp + pp * RPP * CLD);
+          if constexpr (EPI == 1) {
+            if (prep) *reinterpret_cast<bf16x8*>(prep + pp * ystep) = v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float g = gelu_erf(bf2f(v[e]));
+              if constexpr (HAS_RS) g *= prs[pp];
+              v[e] = f2bf(g);
+            }
+          } else if constexpr (EPI == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) * gelu_erf_grad(bf2f(side[pp][e])));
+          }
+          if constexpr (HAS_R) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(side[pp][e]));
+          }
+          *reinterpret_cast<bf16x8*>(yp + pp * ystep) = v;
+          if constexpr (EPI == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) csum[e] += bf2f(v[e]);
+          }
+        }
+      }
+    }
+    if (h + 1 < ROUNDS || EPI == 2) __syncthreads();     // staged slab fully read before it is overwritten / re-used
+  }
+  if constexpr (EPI == 2) {
+    if (a.colpart) {                                    // column sums of the stored tile: bias gradient of the fused backward
+      float* red = reinterpret_cast<float*>(Cs);
+      constexpr int LPC = 64 / (CPR < 64 ? CPR : 64);   // lanes of one wave that share a column chunk
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = csum[e];
+        if constexpr (LPC >= 2 && CPR <= 32) t += __shfl_xor(t, 32);
+        if constexpr (LPC >= 4 && CPR <= 16) t += __shfl_xor(t, 16);
+        if constexpr (LPC >= 8 && CPR <= 8) t += __shfl_xor(t, 8);
+        csum[e] = t;
+      }
+      static_assert(CPR == 8 || CPR == 16 || CPR == 32, "column-sum shuffle tree");
+      if (lane < CPR) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wave * BN + lane * 8 + e] = csum[e];
+      }
+      __syncthreads();
+      for (int c = tid; c < BN; c += NT) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM * WN; ++w) t += red[w * BN + c];
+        if (tn0 + c < a.N) a.colpart[(size_t)(tm0 / BM) * a.N + tn0 + c] = t;
+      }
+    }
+  }
+}
+
+// bias slice of the tile -> LDS once per workgroup (read by the staging pass many barriers later)
+template <int BN>
+__device__ __forceinline__ void stage_bias(const GemmArgs& a, float* bias_s, int tn0) {
+  if (a.bias && threadIdx.x < BN / 4) {
+    const int n = min(tn0 + (int)threadIdx.x * 4, a.N - 4);
+    *reinterpret_cast<float4*>(bias_s + threadIdx.x * 4) = *reinterpret_cast<const float4*>(a.bias + n);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // v2: same tile / MFMA structure, but (1) operands go global -> LDS directly (global_load_lds_dwordx4: no VGPR round
 // trip, no ds_write issue cost -- rocprof + the LDS budget showed v1 LDS-bound: 32 KB of ds_write_b128 per K tile cost
 // ~415 LDS cycles next to 512 MFMA cycles); the XOR swizzle moves to the per-lane SOURCE address because the DMA writes
 // lane-linear (wave base + lane*16 B); (2) the epilogue is staged through LDS so that every global store / residual
 // load is a full 16-byte, row-contiguous access (v1's per-lane 8-byte stores touched 32 rows per instruction and held
 // the HBM-bound stage-0/1 GEMMs at ~50 % of the bandwidth roofline).  Requires K % 64 == 0 and N % 8 == 0.
-template <int BM, int BN, int WM, int WN, int NS>
+template <int BM, int BN, int WM, int WN, int NS, int EPI, bool HAS_R, bool HAS_RS>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_glds_kernel(GemmArgs a) {
   constexpr int NT = 64 * WM * WN;                     // threads per workgroup
   constexpr int WTM = BM / WM, WTN = BN / WN;          // per-wave tile
@@ -184,9 +336,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_glds_kernel(GemmArgs a) 
   constexpr int PA = BM / RPD, PB = BN / RPD;
   constexpr int CLD = BN + 8;                          // epilogue tile row stride (elements)
   static_assert(BM * CLD <= NS * (BM + BN) * BK, "epilogue tile must fit in the operand buffers");
-  __shared__ __attribute__((aligned(16))) bf16 smem[NS * (BM + BN) * BK];
+  // operand ring + 1 KB for the bias slice.  ONE LDS object on purpose: with a second __shared__ array next to LDS-DMA
+  // traffic the compiler's waitcnt pass starts guarding ds_reads with vmcnt(0), which drains the ring.
+  __shared__ __attribute__((aligned(16))) bf16 smem[NS * (BM + BN) * BK + 512];
   bf16* As = smem;                                     // [NS][BM*BK]
   bf16* Bs = smem + NS * BM * BK;                      // [NS][BN*BK]
+  float* bias_s = reinterpret_cast<float*>(smem + NS * (BM + BN) * BK);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -239,6 +394,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_glds_kernel(GemmArgs a) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  stage_bias<BN>(a, bias_s, tn0);
   const int nk = a.K / BK;
   const int frow = lane & 31, fk = lane >> 5;
   const bool dbg_nodma = a.act & 0x100;                // ablation switch (tools/gemm_probe.py)
@@ -308,88 +464,160 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_glds_kernel(GemmArgs a) 
   }
 
   // ---- epilogue: registers -> LDS tile (bf16) -> coalesced 16-byte rows ------------------------------------------
-  bf16* Cs = smem;
-  constexpr int CPR = BN / 8;                           // 16-byte chunks per tile row
-  constexpr int RPP = NT / CPR;                         // tile rows per store pass
-  const int erow = tid / CPR, echunk = tid % CPR;
-  auto stage_tile = [&](bool pre) {
+  if (tm0 + BM <= a.M && tn0 + BN <= a.N)
+    tile_epilogue<BM, BN, WM, WN, 1, EPI, HAS_R, HAS_RS, true>(a, acc, smem, bias_s, tm0, tn0);
+  else
+    tile_epilogue<BM, BN, WM, WN, 1, EPI, HAS_R, HAS_RS, false>(a, acc, smem, bias_s, tm0, tn0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// v3 ("wide"): 256x256 output tile, K step 32, 8 waves as 2(M) x 4(N) -> 128x64 per wave, 4-stage LDS-DMA ring.
+// Measured (tools/gemm_ab.py, M = 295k): both the 256x128 kernel above and the library sit at ~7.5-8 TB/s of
+// L2 -> LDS fill, i.e. throughput = (flop per staged byte) x fill rate: 85 flop/B -> 650-700 TFLOP/s for 256x128,
+// 128 flop/B -> 860-1300 for the library's 256x256 macro tile.  This kernel takes the 256x256 tile; three stages of
+// 64-deep K tiles would not fit the 160-KB LDS, so the K step drops to 32 and the ring gets four 32-KB stages with up to
+// three K tiles in flight behind counted vmcnt waits.  Rows are 64 B in LDS: the XOR swizzle becomes
+// chunk ^= (row>>2)&3 (four rows share one 256-B bank window).
+__device__ __forceinline__ int swz32(int row, int chunk) { return (row * 4 + (chunk ^ ((row >> 2) & 3))) * 8; }
+
+template <int WM, int WN, int EPI, bool HAS_R, bool HAS_RS>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_wide_kernel(GemmArgs a) {
+  constexpr int BM = 256, BN = 256, BKS = 32, NS = 4;
+  constexpr int NT = 64 * WM * WN;
+  static_assert(NT == 512, "DMA pass geometry below is written for 8 waves");
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int RPD = NT / 4;                          // 128 tile rows per DMA pass (4 lanes x 16 B per 64-B row)
+  constexpr int PA = BM / RPD, PB = BN / RPD;          // 2 + 2 DMA instructions per wave per K tile
+  constexpr int NDMA = PA + PB;
+  constexpr int STAGE = (BM + BN) * BKS;
+  constexpr int CLD = BN + 8;
+  constexpr int HM = BM / 2;
+  static_assert((size_t)HM * CLD * 2 <= (size_t)NS * STAGE * 2, "epilogue half tile must fit in the ring");
+  // ring stages + 1 KB of bias (ONE LDS object: a second __shared__ array next to LDS-DMA makes the compiler's waitcnt
+  // pass guard ds_reads with vmcnt(0))
+  __shared__ __attribute__((aligned(16))) bf16 smem[NS * STAGE + 512];
+  float* bias_s = reinterpret_cast<float*>(smem + NS * STAGE);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tilesN = (a.N + BN - 1) / BN, tilesM = (a.M + BM - 1) / BM;
+  const int nblk = tilesM * tilesN;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm0 = (bid / tilesN) * BM, tn0 = (bid % tilesN) * BN;
+
+  const int srow = wave * 16 + (lane >> 2), spc = lane & 3;
+  const bf16* xsrc[PA];
+  const bf16* wsrc[PB];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int ml = wm * WTM + i * 32 + (lane & 31);
-      const int m = tm0 + ml;
-      const float rsc = (!pre && a.rowscale && m < a.M) ? a.rowscale[m / a.rows_per_sample] : 1.f;
+  for (int p = 0; p < PA; ++p) {
+    const int row = srow + p * RPD;
+    const int r = min(tm0 + row, a.M - 1);
+    xsrc[p] = a.X + (size_t)r * a.ldx + ((spc ^ ((row >> 2) & 3)) << 3);
+  }
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+  for (int p = 0; p < PB; ++p) {
+    const int row = srow + p * RPD;
+    const int r = min(tn0 + row, a.N - 1);
+    wsrc[p] = a.W + (size_t)r * a.ldw + ((spc ^ ((row >> 2) & 3)) << 3);
+  }
+  auto dma1 = [&](int d, int kt, int buf) {
+    bf16* st = smem + buf * STAGE;
+    if (d < PA)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[d < PA ? d : 0] + kt * BKS),
+                                       (__attribute__((address_space(3))) void*)(st + (d * RPD + wave * 16) * BKS), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[d >= PA ? d - PA : 0] + kt * BKS),
+                                       (__attribute__((address_space(3))) void*)(st + BM * BKS + ((d - PA) * RPD + wave * 16) * BKS), 16, 0, 0);
+  };
+  auto dma = [&](int kt, int buf) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int nl = wn * WTN + j * 32 + q * 8 + (lane >> 5) * 4;
-          const int n = tn0 + nl;
-          float v[4];
+    for (int d = 0; d < NDMA; ++d) dma1(d, kt, buf);
+  };
+
+  f32x16 acc[TM][TN];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
-          if (a.bias && n < a.N) {
-            const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
-            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-          }
-          if (!pre) {
-            if ((a.act & 0xff) == 1) {
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-            }
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= rsc;
-          }
-          bf16x4 o;
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = a.K / BKS;
+  const int frow = lane & 31, fk = lane >> 5;
+  constexpr int KS = BKS / 16;                           // 2 MFMA k-steps per K tile
+  // The eight waves form two groups (wm = 0 / 1: one wave of each per SIMD) that run the same K loop HALF A TILE APART:
+  // each K tile is a load phase (12 fragment ds_reads, 4 DMA requests for tile k+3) and a math phase (16 MFMAs), with a
+  // workgroup barrier after each; group 1 enters the loop one barrier late, so on every SIMD one wave feeds the matrix
+  // pipe while its partner fetches.  (Ablation of the lock-step version, all eight waves in the same phase: MFMA-only
+  // 1640 TFLOP/s, +DMA 1016, +ds_read 1150, all three 830 -- the phases simply added up.)
+  bf16x8 fa[KS][TM], fb[KS][TN];
+  auto load_phase = [&](int kt) {
+    const bf16* Ac = smem + (kt & 3) * STAGE;
+    const bf16* Bc = Ac + BM * BKS;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-          *reinterpret_cast<bf16x4*>(Cs + ml * CLD + nl) = o;
-        }
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8*>(Ac + swz32(wm * WTM + i * 32 + frow, ks * 2 + fk));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[ks][j] = *reinterpret_cast<const bf16x8*>(Bc + swz32(wn * WTN + j * 32 + frow, ks * 2 + fk));
+    }
+    if (kt + 3 < nk) {
+#pragma unroll
+      for (int d = 0; d < NDMA; ++d) dma1(d, kt + 3, (kt + 3) & 3);
     }
   };
-  // Single staging pass: the tile staged in LDS is the PRE-activation when act=GELU; the coalesced store pass writes it
-  // to Ypre (if requested), applies GELU / DropPath scale / residual on 8-wide vectors and writes Y.  (GELU is evaluated
-  // on the bf16-rounded pre-activation, i.e. exactly the value the backward pass will differentiate at.)
-  const bool gelu = (a.act & 0xff) == 1, gelu_grad = (a.act & 0xff) == 2;
-  stage_tile(gelu);
+  auto math_phase = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // Barrier preceded by the counted wait that makes this wave's share of K tile kt+1 resident (its requests for tiles
+  // kt+2 / kt+3, 4 instructions each, may stay in flight).  Executed at the end of BOTH phases of tile kt: the first reader
+  // of tile kt+1 (group 0) starts right after the barrier that ends its math phase, which is the barrier that ends group
+  // 1's load phase.
+  auto phase_barrier = [&](int kt) {
+    if (kt + 3 < nk) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  static_assert(NDMA == 4, "counted waits above");
+
+  stage_bias<BN>(a, bias_s, tn0);
+  dma(0, 0);
+  if (nk > 1) dma(1, 1);
+  if (nk > 2) dma(2, 2);
+  phase_barrier(-1);                                      // tile 0 resident for everyone
+  if (wm == 1) phase_barrier(-1);                         // stagger: group 1 runs one phase behind
+  for (int kt = 0; kt < nk; ++kt) {
+    load_phase(kt);
+    phase_barrier(kt);
+    math_phase();
+    phase_barrier(kt);
+  }
+  if (wm == 0) phase_barrier(nk);                         // re-align the barrier count of the two groups
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
-  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int r0 = 0; r0 < BM; r0 += RPP) {
-    const int ml = r0 + erow, m = tm0 + ml, n = tn0 + echunk * 8;
-    if (m < a.M && n < a.N) {
-      bf16x8 v = *reinterpret_cast<const bf16x8*>(Cs + ml * CLD + echunk * 8);
-      if (gelu) {
-        if (a.Ypre) *reinterpret_cast<bf16x8*>(a.Ypre + (size_t)m * a.ldy + n) = v;
-        const float rsc = a.rowscale ? a.rowscale[m / a.rows_per_sample] : 1.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = f2bf(gelu_erf(bf2f(v[e])) * rsc);
-      } else if (gelu_grad) {
-        const bf16x8 h = *reinterpret_cast<const bf16x8*>(a.aux + (size_t)m * a.ldaux + n);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) * gelu_erf_grad(bf2f(h[e])));
-      }
-      if (a.R) {
-        const bf16x8 r = *reinterpret_cast<const bf16x8*>(a.R + (size_t)m * a.ldr + n);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(r[e]));
-      }
-      *reinterpret_cast<bf16x8*>(a.Y + (size_t)m * a.ldy + n) = v;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) csum[e] += bf2f(v[e]);
-    }
-  }
-  if (a.colpart) {                                      // column sums of this tile: RPP row-lanes -> one row, via LDS
-    float* red = reinterpret_cast<float*>(Cs + BM * CLD);          // free LDS behind the staged tile
-    static_assert((size_t)BM * CLD * 2 + (size_t)RPP * BN * 4 <= sizeof(smem), "no LDS room for the column-sum reduction");
-#pragma unroll
-    for (int e = 0; e < 8; ++e) red[erow * BN + echunk * 8 + e] = csum[e];
-    __syncthreads();
-    for (int c = tid; c < BN; c += NT) {
-      float t = 0.f;
-      for (int r = 0; r < RPP; ++r) t += red[r * BN + c];
-      if (tn0 + c < a.N) a.colpart[(size_t)(tm0 / BM) * a.N + tn0 + c] = t;
-    }
-  }
+
+  // ---- epilogue: two 128-row slabs through the (now idle) ring -------------------------------------------------
+  if (tm0 + BM <= a.M && tn0 + BN <= a.N)
+    tile_epilogue<BM, BN, WM, WN, 2, EPI, HAS_R, HAS_RS, true>(a, acc, smem, bias_s, tm0, tn0);
+  else
+    tile_epilogue<BM, BN, WM, WN, 2, EPI, HAS_R, HAS_RS, false>(a, acc, smem, bias_s, tm0, tn0);
 }
 
 }  // namespace
@@ -399,6 +627,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_glds_kernel(GemmArgs a) 
 extern "C" int fiber_gemm_row_tile(int M, int N, int K) {
   const long big = (long)cdiv(M, 128) * cdiv(N, 128), huge = (long)cdiv(M, 256) * cdiv(N, 128);
   static const int force = getenv("FIBER_GEMM_TILE") ? atoi(getenv("FIBER_GEMM_TILE")) : 0;
+  static const int nowide = getenv("FIBER_GEMM_NOWIDE") ? atoi(getenv("FIBER_GEMM_NOWIDE")) : 0;
+  const long wide = (long)cdiv(M, 256) * cdiv(N, 256);
+  if (!nowide && force == 0 && wide >= 200 && N % 256 == 0 && K >= 128 && K % 64 == 0) return 256;
   if ((huge >= 400 && K >= 256 && force == 0) || force == 256) return 256;
   if (big >= 192 || force == 128) return 128;
   return 64;
@@ -420,21 +651,40 @@ extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bia
              (const bf16*)aux, colpart, M, N, K, ldx, ldw, ldy, ldr, act, rows_per_sample, ldaux};
   const long big = (long)cdiv(M, 128) * cdiv(N, 128);
   const long huge = (long)cdiv(M, 256) * cdiv(N, 128);
-  if (((act & 0xff) == 2 || colpart) && !((K % 64 == 0) && (N % 8 == 0) && (ldy % 8 == 0))) return FIBER_EINVAL;   // glds kernels only
+  const long wide = (long)cdiv(M, 256) * cdiv(N, 256);
+  const int mode = act & 0xff;
+  if ((mode == 2 || colpart) && !((K % 64 == 0) && (N % 8 == 0) && (ldy % 8 == 0))) return FIBER_EINVAL;   // LDS-DMA kernels only
+  if (mode == 2 && (residual || rowscale)) return FIBER_EINVAL;
+  if (colpart && mode != 2) return FIBER_EINVAL;
   const bool v2 = (K % 64 == 0) && (N % 8 == 0) && (ldy % 8 == 0) && (!residual || ldr % 8 == 0) && !getenv("FIBER_GEMM_V1");
-  // Tile choice: the 128x128 tile is L2->LDS bandwidth bound (64 flop per staged byte, ~10 TB/s fabric => ~650 TFLOP/s,
-  // measured with tools/gemm_probe.py); 256x128 (8 waves, 85 flop/B) lifts that ceiling when there are enough tiles.
+  // Tile choice.  256x256 (K step 32, two wave groups half a tile apart) whenever N is a multiple of 256 and there are
+  // enough tiles; otherwise 256x128 / 128x128 / 64x64 on the 64-deep ring.  FIBER_GEMM_TILE / FIBER_GEMM_NOWIDE force a
+  // choice for A/B runs (tools/gemm_ab.py).
   static const int force = getenv("FIBER_GEMM_TILE") ? atoi(getenv("FIBER_GEMM_TILE")) : 0;
-  if (v2 && ((huge >= 400 && K >= 256 && force == 0) || force == 256)) {
-    hipLaunchKernelGGL((gemm_nt_glds_kernel<256, 128, 4, 2, 3>), dim3((unsigned)huge), dim3(512), 0, stream, a);
-  } else if (big >= 192 || force == 128) {
-    if (v2) hipLaunchKernelGGL((gemm_nt_glds_kernel<128, 128, 2, 2, 2>), dim3((unsigned)big), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), dim3((unsigned)big), dim3(256), 0, stream, a);
-  } else {
-    const long small = (long)cdiv(M, 64) * cdiv(N, 64);
-    if (v2) hipLaunchKernelGGL((gemm_nt_glds_kernel<64, 64, 2, 2, 2>), dim3((unsigned)small), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), dim3((unsigned)small), dim3(256), 0, stream, a);
-  }
+  static const int nowide = getenv("FIBER_GEMM_NOWIDE") ? atoi(getenv("FIBER_GEMM_NOWIDE")) : 0;
+  int shape;                                             // 0 wide, 1 256x128, 2 128x128, 3 64x64, 4/5 register-staged
+  if (v2 && !nowide && force == 0 && wide >= 200 && N % 256 == 0 && K >= 128) shape = 0;
+  else if (v2 && ((huge >= 400 && K >= 256 && force == 0) || force == 256)) shape = 1;
+  else if (big >= 192 || force == 128) shape = v2 ? 2 : 4;
+  else shape = v2 ? 3 : 5;
+  const long small = (long)cdiv(M, 64) * cdiv(N, 64);
+#define FIBER_LAUNCH_EPI(EPI, R, RS)                                                                                          \
+  do {                                                                                                                        \
+    if (shape == 0) hipLaunchKernelGGL((gemm_nt_wide_kernel<2, 4, EPI, R, RS>), dim3((unsigned)wide), dim3(512), 0, stream, a);   \
+    else if (shape == 1) hipLaunchKernelGGL((gemm_nt_glds_kernel<256, 128, 4, 2, 3, EPI, R, RS>), dim3((unsigned)huge), dim3(512), 0, stream, a); \
+    else if (shape == 2) hipLaunchKernelGGL((gemm_nt_glds_kernel<128, 128, 2, 2, 2, EPI, R, RS>), dim3((unsigned)big), dim3(256), 0, stream, a);  \
+    else hipLaunchKernelGGL((gemm_nt_glds_kernel<64, 64, 2, 2, 2, EPI, R, RS>), dim3((unsigned)small), dim3(256), 0, stream, a);                   \
+  } while (0)
+  if (shape == 4) hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), dim3((unsigned)big), dim3(256), 0, stream, a);
+  else if (shape == 5) hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), dim3((unsigned)small), dim3(256), 0, stream, a);
+  else if (mode == 2) FIBER_LAUNCH_EPI(2, false, false);
+  else if (mode == 1 && residual) { if (rowscale) FIBER_LAUNCH_EPI(1, true, true); else FIBER_LAUNCH_EPI(1, true, false); }
+  else if (mode == 1) { if (rowscale) FIBER_LAUNCH_EPI(1, false, true); else FIBER_LAUNCH_EPI(1, false, false); }
+  else if (residual && rowscale) FIBER_LAUNCH_EPI(0, true, true);
+  else if (residual) FIBER_LAUNCH_EPI(0, true, false);
+  else if (rowscale) FIBER_LAUNCH_EPI(0, false, true);
+  else FIBER_LAUNCH_EPI(0, false, false);
+#undef FIBER_LAUNCH_EPI
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }

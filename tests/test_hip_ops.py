@@ -58,6 +58,48 @@ def test_gemm_nt(ops, M, N, K, act, res):
     assert_close("db", b.grad, br.grad, 8e-3)
 
 
+@pytest.mark.parametrize("M,N,K", [(33000, 2048, 512), (70001, 1024, 256), (40960, 1536, 1024), (52000, 512, 2048),
+                                   (33000, 2056, 512)])
+@pytest.mark.parametrize("mode", ["plain", "bias", "gelu_pre", "res_rowscale", "gelu_grad_colsum"])
+def test_gemm_large_tiles(ops, M, N, K, mode):
+    """Shapes with >= 200 256x256 tiles and N % 256 == 0 take the wide kernel (4-stage K=32 ring, epilogue in two halves);
+    the ragged-N case stays on the 256x128 ring kernel.  Ragged M, every epilogue variant, and two runs must agree bit for
+    bit (race screen for the counted-vmcnt ring)."""
+    x, wb = bf(rnd(M, K)), bf(rnd(N, K, std=K ** -0.5))
+    b = rnd(N, seed=1).to(DEV)
+    ref = x.float() @ wb.float().t()
+    kw, want = {}, None
+    if mode == "bias":
+        kw, want = dict(bias=b), ref + b
+    elif mode == "gelu_pre":
+        kw = dict(bias=b, act=1, want_pre=True)
+        pre = (ref + b).to(BF).float()
+        want = F.gelu(pre)
+    elif mode == "res_rowscale":
+        rps = 1000
+        r = bf(rnd(M, N, seed=2))
+        rs = (torch.arange(-(-M // rps), device=DEV) % 3).float() * 0.5
+        kw = dict(bias=b, residual=r, rowscale=rs, rows_per_sample=rps)
+        want = (ref + b) * rs.repeat_interleave(rps)[:M, None] + r.float()
+    elif mode == "gelu_grad_colsum":
+        h = bf(rnd(M, N, seed=4))
+        kw = dict(act=2, aux=h, want_colsum=True)
+        hf = h.float().requires_grad_(True)
+        F.gelu(hf).sum().backward()
+        want = ref * hf.grad
+    else:
+        want = ref
+    y1, e1 = ops.gemm_nt(x, wb, **kw)
+    y2, e2 = ops.gemm_nt(x, wb, **kw)
+    assert torch.equal(y1, y2)
+    assert_close("y", y1, want, 5e-3)
+    if mode == "gelu_pre":
+        assert_close("pre", e1, ref + b, 4e-3)
+        assert torch.equal(e1, e2)
+    if mode == "gelu_grad_colsum":
+        assert_close("colsum", e1, y1.float().sum(0), 2e-3)
+
+
 @pytest.mark.parametrize("rows,C", [(1000, 128), (77, 32), (513, 96), (1280, 768), (300, 2048), (9216, 256)])
 def test_layernorm(ops, rows, C):
     x = bf(rnd(rows, C) * 1.5 + 0.3).requires_grad_(True)
