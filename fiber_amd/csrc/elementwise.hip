@@ -15,10 +15,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16* __restrict__ 
                                                        bf16* __restrict__ dh, size_t nvec) {
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
     const bf16x8 a = reinterpret_cast<const bf16x8*>(dg)[i], b = reinterpret_cast<const bf16x8*>(h)[i];
-    bf16x8 o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(a[e]) * gelu_erf_grad(bf2f(b[e])));
-    reinterpret_cast<bf16x8*>(dh)[i] = o;
+    reinterpret_cast<bf16x8*>(dh)[i] = gelu_grad_mul8(a, b);
   }
 }
 
@@ -106,9 +103,9 @@ __global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(const bf16* __rest
     for (int r = r0 + rl; r < r1; r += 8) {
       const size_t off = (size_t)r * N + col;
       const bf16x8 a = *reinterpret_cast<const bf16x8*>(dg + off), b = *reinterpret_cast<const bf16x8*>(h + off);
-      bf16x8 o;
+      const bf16x8 o = gelu_grad_mul8(a, b);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { o[e] = f2bf(bf2f(a[e]) * gelu_erf_grad(bf2f(b[e]))); s[e] += bf2f(o[e]); }
+      for (int e = 0; e < 8; ++e) s[e] += bf2f(o[e]);
       *reinterpret_cast<bf16x8*>(dh + off) = o;
     }
   }

@@ -258,15 +258,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x16 (&acc)[B
           bf16x8 v = *reinterpret_cast<const bf16x8*>(cp + pp * RPP * CLD);
           if constexpr (EPI == 1) {
             if (prep) *reinterpret_cast<bf16x8*>(prep + pp * ystep) = v;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              float g = gelu_erf(bf2f(v[e]));
-              if constexpr (HAS_RS) g *= prs[pp];
-              v[e] = f2bf(g);
-            }
+            v = gelu8(v, HAS_RS ? prs[pp] : 1.f);
           } else if constexpr (EPI == 2) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) * gelu_erf_grad(bf2f(side[pp][e])));
+            v = gelu_grad_mul8(v, side[pp]);
           }
           if constexpr (HAS_R) {
 #pragma unroll
