@@ -177,6 +177,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 //   EPI 1: Ypre = acc + bias (optional);  Y = rowscale * gelu(bf16(acc + bias))
 //   EPI 2: Y = acc * gelu'(aux);  optional per-row-tile column sums of Y (colpart)
 //   FULL:  the tile lies entirely inside [M, N] (no row / column predicates)
+// Y is read by the next kernel and is stored normally: marking it non-temporal made the isolated GEMM faster (fc1 845 ->
+// 772 us at M = 295k, less L2 pollution) but the whole step slower (670 -> 658 images/s, the consumer then misses the
+// Infinity Cache).  The pre-activation copy is only read again in the backward pass, so it does stream past the caches.
+__device__ __forceinline__ void st_out(bf16x8* p, bf16x8 v) { *p = v; }
+__device__ __forceinline__ void st_stream(bf16x8* p, bf16x8 v) { __builtin_nontemporal_store(v, p); }
+
 template <int BM, int BN, int WM, int WN, int ROUNDS, int EPI, bool HAS_R, bool HAS_RS, bool FULL>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], bf16* Cs,
                                               const float* bias_s, int tm0, int tn0) {
@@ -257,7 +263,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x16 (&acc)[B
         if (FULL || (mbase + pp * RPP < a.M && col_ok)) {
           bf16x8 v = *reinterpret_cast<const bf16x8*>(cp + pp * RPP * CLD);
           if constexpr (EPI == 1) {
-            if (prep) *reinterpret_cast<bf16x8*>(prep + pp * ystep) = v;
+            if (prep) st_stream(reinterpret_cast<bf16x8*>(prep + pp * ystep), v);
             v = gelu8(v, HAS_RS ? prs[pp] : 1.f);
           } else if constexpr (EPI == 2) {
             v = gelu_grad_mul8(v, side[pp]);
@@ -266,7 +272,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x16 (&acc)[B
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(side[pp][e]));
           }
-          *reinterpret_cast<bf16x8*>(yp + pp * ystep) = v;
+          st_out(reinterpret_cast<bf16x8*>(yp + pp * ystep), v);
           if constexpr (EPI == 2) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) csum[e] += bf2f(v[e]);

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfiber_hip.so")
+LIB_PATH = os.environ.get("FIBER_HIP_LIB") or os.path.join(_HERE, "libfiber_hip.so")   # env: A/B builds (tools/)
 
 P, I, F, L, U64 = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_uint64
 
