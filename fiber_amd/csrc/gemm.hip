@@ -471,29 +471,32 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_glds_kernel(GemmArgs a) 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// v3 ("wide"): 256x256 output tile, K step 32, 8 waves as 2(M) x 4(N) -> 128x64 per wave, 4-stage LDS-DMA ring.
-// Measured (tools/gemm_ab.py, M = 295k): both the 256x128 kernel above and the library sit at ~7.5-8 TB/s of
-// L2 -> LDS fill, i.e. throughput = (flop per staged byte) x fill rate: 85 flop/B -> 650-700 TFLOP/s for 256x128,
-// 128 flop/B -> 860-1300 for the library's 256x256 macro tile.  This kernel takes the 256x256 tile; three stages of
-// 64-deep K tiles would not fit the 160-KB LDS, so the K step drops to 32 and the ring gets four 32-KB stages with up to
-// three K tiles in flight behind counted vmcnt waits.  Rows are 64 B in LDS: the XOR swizzle becomes
-// chunk ^= (row>>2)&3 (four rows share one 256-B bank window).
-__device__ __forceinline__ int swz32(int row, int chunk) { return (row * 4 + (chunk ^ ((row >> 2) & 3))) * 8; }
-
-template <int WM, int WN, int EPI, bool HAS_R, bool HAS_RS>
+// v3 ("wide"): 256x256 output tile, 8 waves as 2(M) x 4(N) -> 128x64 per wave, two 64-KB LDS stages of 64-deep K tiles.
+//
+// What the measurements said (tools/gemm_ab.py / gemm_dbg.py / gemm_trace.py, rocprofv3 PMC, M = 295k..74k):
+//  * lock-step waves (all eight in the same phase) add their phases up: MFMA-only 1640 TFLOP/s, +DMA 1016, +ds_read
+//    1150, all three 830.  So the eight waves form two groups (wm = 0 / 1: one wave of each per SIMD) that run the same K
+//    loop HALF A SUB-TILE APART: a load phase (12 fragment ds_reads) and a math phase (16 MFMAs) per 32-deep sub-tile,
+//    a workgroup barrier after each; group 1 enters the loop one barrier late, so on every SIMD one wave feeds the matrix
+//    pipe while its partner fetches.
+//  * with a 32-deep K tile (64-byte rows) every LDS-DMA instruction costs the texture addresser ~31 cycles (TA_BUSY 54 %,
+//    one request per 64-B half line): 1024 TA cycles per 1024 MFMA cycles, and the load phase (670-730 cycles) outlasts
+//    the math phase (512).  128-byte rows halve the requests per byte, hence K tiles of 64 and only two stages (three do not
+//    fit the 160-KB LDS): the whole next K tile is requested in the first load phase of the current one and has 2.5 phases
+//    to land.
+template <int WM, int WN, int EPI, bool HAS_R, bool HAS_RS, bool TRACE = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_wide_kernel(GemmArgs a) {
-  constexpr int BM = 256, BN = 256, BKS = 32, NS = 4;
+  constexpr int BM = 256, BN = 256, NS = 2;
   constexpr int NT = 64 * WM * WN;
-  static_assert(NT == 512, "DMA pass geometry below is written for 8 waves");
+  static_assert(NT == 512 && WM == 2, "two wave groups of four; DMA pass geometry for 8 waves");
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int RPD = NT / 4;                          // 128 tile rows per DMA pass (4 lanes x 16 B per 64-B row)
-  constexpr int PA = BM / RPD, PB = BN / RPD;          // 2 + 2 DMA instructions per wave per K tile
+  constexpr int RPD = NT / 8;                          // 64 tile rows per DMA pass (8 lanes x 16 B per 128-B row)
+  constexpr int PA = BM / RPD, PB = BN / RPD;          // 4 + 4 DMA instructions per wave per K tile
   constexpr int NDMA = PA + PB;
-  constexpr int STAGE = (BM + BN) * BKS;
+  constexpr int STAGE = (BM + BN) * BK;
   constexpr int CLD = BN + 8;
-  constexpr int HM = BM / 2;
-  static_assert((size_t)HM * CLD * 2 <= (size_t)NS * STAGE * 2, "epilogue half tile must fit in the ring");
+  static_assert((size_t)(BM / 2) * CLD * 2 <= (size_t)NS * STAGE * 2, "epilogue half tile must fit in the ring");
   // ring stages + 1 KB of bias (ONE LDS object: a second __shared__ array next to LDS-DMA makes the compiler's waitcnt
   // pass guard ds_reads with vmcnt(0))
   __shared__ __attribute__((aligned(16))) bf16 smem[NS * STAGE + 512];
@@ -510,33 +513,29 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_wide_kernel(GemmArgs a) 
   }
   const int tm0 = (bid / tilesN) * BM, tn0 = (bid % tilesN) * BN;
 
-  const int srow = wave * 16 + (lane >> 2), spc = lane & 3;
+  const int srow = wave * 8 + (lane >> 3), spc = lane & 7;
   const bf16* xsrc[PA];
   const bf16* wsrc[PB];
 #pragma unroll
   for (int p = 0; p < PA; ++p) {
     const int row = srow + p * RPD;
-    const int r = min(tm0 + row, a.M - 1);
-    xsrc[p] = a.X + (size_t)r * a.ldx + ((spc ^ ((row >> 2) & 3)) << 3);
+    xsrc[p] = a.X + (size_t)min(tm0 + row, a.M - 1) * a.ldx + ((spc ^ ((row >> 1) & 7)) << 3);
   }
 #pragma unroll
   for (int p = 0; p < PB; ++p) {
     const int row = srow + p * RPD;
-    const int r = min(tn0 + row, a.N - 1);
-    wsrc[p] = a.W + (size_t)r * a.ldw + ((spc ^ ((row >> 2) & 3)) << 3);
+    wsrc[p] = a.W + (size_t)min(tn0 + row, a.N - 1) * a.ldw + ((spc ^ ((row >> 1) & 7)) << 3);
   }
-  auto dma1 = [&](int d, int kt, int buf) {
-    bf16* st = smem + buf * STAGE;
-    if (d < PA)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[d < PA ? d : 0] + kt * BKS),
-                                       (__attribute__((address_space(3))) void*)(st + (d * RPD + wave * 16) * BKS), 16, 0, 0);
-    else
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[d >= PA ? d - PA : 0] + kt * BKS),
-                                       (__attribute__((address_space(3))) void*)(st + BM * BKS + ((d - PA) * RPD + wave * 16) * BKS), 16, 0, 0);
-  };
-  auto dma = [&](int kt, int buf) {
+  auto dma = [&](int kt) {
+    bf16* st = smem + (kt & 1) * STAGE;
 #pragma unroll
-    for (int d = 0; d < NDMA; ++d) dma1(d, kt, buf);
+    for (int p = 0; p < PA; ++p)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[p] + kt * BK),
+                                       (__attribute__((address_space(3))) void*)(st + (p * RPD + wave * 8) * BK), 16, 0, 0);
+#pragma unroll
+    for (int p = 0; p < PB; ++p)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[p] + kt * BK),
+                                       (__attribute__((address_space(3))) void*)(st + BM * BK + (p * RPD + wave * 8) * BK), 16, 0, 0);
   };
 
   f32x16 acc[TM][TN];
@@ -547,34 +546,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_wide_kernel(GemmArgs a) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = a.K / BKS;
+  const int nk = a.K / BK;
   const int frow = lane & 31, fk = lane >> 5;
-  constexpr int KS = BKS / 16;                           // 2 MFMA k-steps per K tile
-  // The eight waves form two groups (wm = 0 / 1: one wave of each per SIMD) that run the same K loop HALF A TILE APART:
-  // each K tile is a load phase (12 fragment ds_reads, 4 DMA requests for tile k+3) and a math phase (16 MFMAs), with a
-  // workgroup barrier after each; group 1 enters the loop one barrier late, so on every SIMD one wave feeds the matrix
-  // pipe while its partner fetches.  (Ablation of the lock-step version, all eight waves in the same phase: MFMA-only
-  // 1640 TFLOP/s, +DMA 1016, +ds_read 1150, all three 830 -- the phases simply added up.)
-  bf16x8 fa[KS][TM], fb[KS][TN];
-  auto load_phase = [&](int kt) {
-    const bf16* Ac = smem + (kt & 3) * STAGE;
-    const bf16* Bc = Ac + BM * BKS;
+  bf16x8 fa[2][TM], fb[2][TN];
+  // fragments of the 32-deep sub-tile `sub` of K tile kt (two MFMA k-steps)
+  auto load_phase = [&](int kt, int sub) {
+    const bf16* Ac = smem + (kt & 1) * STAGE;
+    const bf16* Bc = Ac + BM * BK;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+    for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8*>(Ac + swz32(wm * WTM + i * 32 + frow, ks * 2 + fk));
+      for (int i = 0; i < TM; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8*>(Ac + swz(wm * WTM + i * 32 + frow, sub * 4 + ks * 2 + fk));
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[ks][j] = *reinterpret_cast<const bf16x8*>(Bc + swz32(wn * WTN + j * 32 + frow, ks * 2 + fk));
-    }
-    if (kt + 3 < nk) {
-#pragma unroll
-      for (int d = 0; d < NDMA; ++d) dma1(d, kt + 3, (kt + 3) & 3);
+      for (int j = 0; j < TN; ++j) fb[ks][j] = *reinterpret_cast<const bf16x8*>(Bc + swz(wn * WTN + j * 32 + frow, sub * 4 + ks * 2 + fk));
     }
   };
   auto math_phase = [&]() {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -582,34 +572,68 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_wide_kernel(GemmArgs a) 
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
   };
-  // Barrier preceded by the counted wait that makes this wave's share of K tile kt+1 resident (its requests for tiles
-  // kt+2 / kt+3, 4 instructions each, may stay in flight).  Executed at the end of BOTH phases of tile kt: the first reader
-  // of tile kt+1 (group 0) starts right after the barrier that ends its math phase, which is the barrier that ends group
-  // 1's load phase.
-  auto phase_barrier = [&](int kt) {
-    if (kt + 3 < nk) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-    else if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  // workgroup barrier closing a phase; `landed`: first make this wave's share of the next K tile resident (all of its
+  // requests were issued two or more phases ago, nothing newer is in flight, so the wait is a plain vmcnt(0))
+  auto phase_barrier = [&](bool landed) {
+    if (landed) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
-  static_assert(NDMA == 4, "counted waits above");
 
   stage_bias<BN>(a, bias_s, tn0);
-  dma(0, 0);
-  if (nk > 1) dma(1, 1);
-  if (nk > 2) dma(2, 2);
-  phase_barrier(-1);                                      // tile 0 resident for everyone
-  if (wm == 1) phase_barrier(-1);                         // stagger: group 1 runs one phase behind
+  dma(0);
+  phase_barrier(true);                                    // K tile 0 resident for everyone
+  if (wm == 1) phase_barrier(false);                      // stagger: group 1 runs one phase behind
+  // TRACE build (tools/gemm_trace.py): s_memtime deltas of the segments of a K tile, summed per wave
+  unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t0 = 0;
+  if constexpr (TRACE) t0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long tstart = t0;
+  auto mark = [&](int i) {
+    if constexpr (TRACE) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      tr[i] += t - t0;
+      t0 = t;
+    }
+  };
+  // Global phase p of group 0 = 4 kt + {0: load sub 0, 1: math, 2: load sub 1, 3: math}; group 1 does the same at p + 1.
+  // Stage (kt+1)&1 was last read in phase 4 kt - 1 (group 1, sub-tile 1 of K tile kt-1), so the requests for K tile kt+1
+  // go out in the first load phase of K tile kt; every wave makes its share resident before the barrier that closes global
+  // phase 4 kt + 3 -- the end of math(sub 1) for group 0, of load(sub 1) for group 1 -- after which group 0 reads it.
   for (int kt = 0; kt < nk; ++kt) {
-    load_phase(kt);
-    phase_barrier(kt);
+    load_phase(kt, 0);
+    if (kt + 1 < nk) dma(kt + 1);
+    if constexpr (TRACE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    mark(0);
+    phase_barrier(false);
+    mark(1);
     math_phase();
-    phase_barrier(kt);
+    mark(2);
+    phase_barrier(false);
+    mark(3);
+    load_phase(kt, 1);
+    if constexpr (TRACE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    mark(4);
+    phase_barrier(wm == 1);
+    mark(5);
+    math_phase();
+    mark(6);
+    phase_barrier(wm == 0);
+    mark(7);
   }
-  if (wm == 0) phase_barrier(nk);                         // re-align the barrier count of the two groups
+  if (wm == 0) phase_barrier(false);                      // re-align the barrier count of the two groups
+  if constexpr (TRACE) {
+    if (lane == 0 && blockIdx.x < 8) {
+      float* o = a.colpart + (blockIdx.x * 8 + wave) * 16;
+      for (int i = 0; i < 8; ++i) o[i] = (float)tr[i];
+      o[8] = (float)(__builtin_amdgcn_s_memtime() - tstart);
+      o[9] = (float)nk;
+    }
+    return;
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -655,7 +679,7 @@ extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bia
   const int mode = act & 0xff;
   if ((mode == 2 || colpart) && !((K % 64 == 0) && (N % 8 == 0) && (ldy % 8 == 0))) return FIBER_EINVAL;   // LDS-DMA kernels only
   if (mode == 2 && (residual || rowscale)) return FIBER_EINVAL;
-  if (colpart && mode != 2) return FIBER_EINVAL;
+  if (colpart && mode != 2 && !(act & 0x200)) return FIBER_EINVAL;
   const bool v2 = (K % 64 == 0) && (N % 8 == 0) && (ldy % 8 == 0) && (!residual || ldr % 8 == 0) && !getenv("FIBER_GEMM_V1");
   // Tile choice.  256x256 (K step 32, two wave groups half a tile apart) whenever N is a multiple of 256 and there are
   // enough tiles; otherwise 256x128 / 128x128 / 64x64 on the 64-deep ring.  FIBER_GEMM_TILE / FIBER_GEMM_NOWIDE force a
@@ -675,6 +699,11 @@ extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bia
     else if (shape == 2) hipLaunchKernelGGL((gemm_nt_glds_kernel<128, 128, 2, 2, 2, EPI, R, RS>), dim3((unsigned)big), dim3(256), 0, stream, a);  \
     else hipLaunchKernelGGL((gemm_nt_glds_kernel<64, 64, 2, 2, 2, EPI, R, RS>), dim3((unsigned)small), dim3(256), 0, stream, a);                   \
   } while (0)
+  if (shape == 0 && (act & 0x200)) {                      // tools/gemm_trace.py: per-segment timing build of the wide kernel
+    hipLaunchKernelGGL((gemm_nt_wide_kernel<2, 4, 0, false, false, true>), dim3((unsigned)wide), dim3(512), 0, stream, a);
+    FIBER_CHECK_LAUNCH();
+    return FIBER_OK;
+  }
   if (shape == 4) hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), dim3((unsigned)big), dim3(256), 0, stream, a);
   else if (shape == 5) hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), dim3((unsigned)small), dim3(256), 0, stream, a);
   else if (mode == 2) FIBER_LAUNCH_EPI(2, false, false);

@@ -61,10 +61,7 @@ def main():
             t_f = timeit(lambda: ops.gemm_nt(dy, wt, None, None, 2, False, aux=h, want_colsum=True))
             t_p = timeit(lambda: ops.gemm_nt(dy, wt, None, None, 0, False))
             def unf():
-                dg = torch.matmul(dy, wb)
-                dh = torch.empty_like(dg)
-                lib.call("fiber_gelu_bwd_bf16", lib.ptr(dg), lib.ptr(h), lib.ptr(dh), dg.numel())
-                return ops.colsum(dh)
+                return ops.gelu_bwd_colsum(torch.matmul(dy, wb), h)
             t_u = timeit(unf)
             t_l = timeit(lambda: torch.matmul(dy, wb))
             print(f"{name} M={M} C={C}: fused {t_f:8.1f}us | hip plain {t_p:8.1f} | unfused total {t_u:8.1f} (lib gemm {t_l:8.1f})")
