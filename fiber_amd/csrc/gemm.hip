@@ -183,7 +183,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 __device__ __forceinline__ void st_out(bf16x8* p, bf16x8 v) { *p = v; }
 __device__ __forceinline__ void st_stream(bf16x8* p, bf16x8 v) { __builtin_nontemporal_store(v, p); }
 
-template <int BM, int BN, int WM, int WN, int ROUNDS, int EPI, bool HAS_R, bool HAS_RS, bool FULL>
+//   RAWBAR: barriers are s_waitcnt lgkmcnt(0) + s_barrier instead of __syncthreads() -- for the persistent kernel, where a
+//          __syncthreads() fence would drain the next tile's LDS-DMA and this tile's own stores (vmcnt(0)).
+template <bool RAWBAR>
+__device__ __forceinline__ void epi_barrier() {
+  if constexpr (RAWBAR) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  } else {
+    __syncthreads();
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int ROUNDS, int EPI, bool HAS_R, bool HAS_RS, bool FULL, bool RAWBAR = false>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], bf16* Cs,
                                               const float* bias_s, int tm0, int tn0) {
   constexpr int NT = 64 * WM * WN;
@@ -194,7 +207,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x16 (&acc)[B
   constexpr int CPR = BN / 8;                           // 16-byte chunks per tile row
   constexpr int RPP = NT / CPR;                         // rows per store pass
   constexpr int NPH = HM / RPP;                         // store passes per round
-  static_assert(WM % ROUNDS == 0 && HM % RPP == 0, "epilogue geometry");
+  static_assert(HM % 32 == 0 && HM % RPP == 0, "epilogue geometry");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int erow = tid / CPR, echunk = tid % CPR;
@@ -222,9 +235,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x16 (&acc)[B
 #pragma unroll
       for (int pp = 0; pp < NPH; ++pp) prs[pp] = a.rowscale[min(mbase + pp * RPP, a.M - 1) / a.rows_per_sample];
     }
-    if (ROUNDS == 1 || wm / (WM / ROUNDS) == h) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i) {
+      if (ROUNDS == 1 || (wm * WTM + i * 32) / HM == h) {          // this wave's 32-row slab i belongs to round h
         const int ml = wm * WTM + i * 32 + (lane & 31);
         float rsc = 1.f;
         if constexpr (EPI == 0 && HAS_RS) rsc = a.rowscale[min(tm0 + ml, a.M - 1) / a.rows_per_sample];
@@ -252,7 +265,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x16 (&acc)[B
           }
       }
     }
-    __syncthreads();
+    epi_barrier<RAWBAR>();
     {
       bf16* yp = a.Y + (size_t)mbase * a.ldy + n_out;
       bf16* prep = (EPI == 1 && a.Ypre) ? a.Ypre + (size_t)mbase * a.ldy + n_out : nullptr;
@@ -280,7 +293,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x16 (&acc)[B
         }
       }
     }
-    if (h + 1 < ROUNDS || EPI == 2) __syncthreads();     // staged slab fully read before it is overwritten / re-used
+    if (h + 1 < ROUNDS || EPI == 2 || RAWBAR) epi_barrier<RAWBAR>();     // staged slab fully read before it is overwritten / re-used
   }
   if constexpr (EPI == 2) {
     if (a.colpart) {                                    // column sums of the stored tile: bias gradient of the fused backward
@@ -299,13 +312,14 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x16 (&acc)[B
 #pragma unroll
         for (int e = 0; e < 8; ++e) red[wave * BN + lane * 8 + e] = csum[e];
       }
-      __syncthreads();
+      epi_barrier<RAWBAR>();
       for (int c = tid; c < BN; c += NT) {
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < WM * WN; ++w) t += red[w * BN + c];
         if (tn0 + c < a.N) a.colpart[(size_t)(tm0 / BM) * a.N + tn0 + c] = t;
       }
+      if constexpr (RAWBAR) epi_barrier<RAWBAR>();
     }
   }
 }
@@ -644,6 +658,164 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_wide_kernel(GemmArgs a) 
     tile_epilogue<BM, BN, WM, WN, 2, EPI, HAS_R, HAS_RS, false>(a, acc, smem, bias_s, tm0, tn0);
 }
 
+
+// One LDS-DMA instruction (64 lanes x 16 B -> 1 KB at `lds_wave_base`, lane-linear) issued from inline asm.  The builtin
+// form tells the compiler that LDS is being written behind the vmcnt counter, and its waitcnt pass then guards LDS reads
+// with vmcnt(0) wherever it loses count (after branches, around other VMEM traffic): in the persistent kernel that put a
+// full drain -- including the previous round's output stores -- in front of every staging ds_read.  All ordering of these
+// transfers is done by hand (counted s_waitcnt + s_barrier), so the compiler does not need to know.  M0 is written and
+// consumed inside the block; nothing else in these kernels uses it.
+// Address = wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset: no 64-bit VGPR address arithmetic.
+__device__ __forceinline__ void lds_dma16(const void* base, unsigned lane_byte_off, void* lds_wave_base) {
+  const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)(char*)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m), "v"(lane_byte_off), "s"(base) : "memory");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// v3 persistent: the wide kernel walking a run of output tiles per workgroup (one workgroup per CU).  At K = 512 the
+// non-persistent kernel spends ~9 of 23 us per tile outside the K loop, most of it waiting for its 128 KB of output to drain
+// to HBM before the workgroup may retire and the next one may even start fetching.  Here the K-tile stream simply continues
+// across tiles (the last K tile of tile t requests the first of tile t+1), the epilogue goes through the stage that tile's
+// last K tile just vacated (four 64-row rounds of 33 KB), its stores drain under the next tile's MFMAs, and the bias slice
+// arrives by LDS-DMA ahead of the tile's first K tile (double-buffered by tile parity).
+template <int WM, int WN, int EPI, bool HAS_R, bool HAS_RS>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_wide_persist_kernel(GemmArgs a) {
+  constexpr int BM = 256, BN = 256, NS = 2;
+  constexpr int NT = 64 * WM * WN;
+  static_assert(NT == 512 && WM == 2, "two wave groups of four; DMA pass geometry for 8 waves");
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int RPD = NT / 8;
+  constexpr int PA = BM / RPD, PB = BN / RPD;
+  constexpr int STAGE = (BM + BN) * BK;
+  constexpr int CLD = BN + 8;
+  constexpr int ROUNDS = 4;
+  static_assert((size_t)(BM / ROUNDS) * CLD * 2 <= (size_t)STAGE * 2, "an epilogue round must fit one ring stage");
+  __shared__ __attribute__((aligned(16))) bf16 smem[NS * STAGE + 1024];          // + two 1-KB bias slices (ONE LDS object)
+  float* bias_s = reinterpret_cast<float*>(smem + NS * STAGE);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tilesN = (a.N + BN - 1) / BN, tilesM = (a.M + BM - 1) / BM;
+  const int nblk = tilesM * tilesN;
+  // XCD x owns a contiguous range of tile ids; its P workgroups stride through it together, so one XCD's L2 serves P
+  // neighbouring tiles at any moment (shared X row panels / W column panels)
+  const int P = gridDim.x >> 3, xcd = blockIdx.x & 7, widx = blockIdx.x >> 3;
+  const int q8 = nblk >> 3, r8 = nblk & 7;
+  const int first = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + widx;
+  const int count = q8 + (xcd < r8 ? 1 : 0);
+  const int T = widx < count ? (count - widx + P - 1) / P : 0;
+  if (T == 0) return;
+
+  const int srow = wave * 8 + (lane >> 3), spc = lane & 7;
+  const bf16* xbase; const bf16* wbase;                  // wave-uniform tile origins (SGPRs)
+  unsigned xo[PA], wo[PB];                               // per-lane byte offsets inside the tile (swizzled chunk, clamped row)
+  // point the DMA addressing at tile `seq` and request its bias slice (every wave writes the same 1 KB; lanes past the
+  // slice fetch a clamped address); ordered before the tile's first K-tile request, so the same waits cover it
+  auto aim = [&](int seq) {
+    const int id = first + seq * P;
+    const int m0 = (id / tilesN) * BM, n0 = (id % tilesN) * BN;
+    xbase = a.X + (size_t)m0 * a.ldx;
+    wbase = a.W + (size_t)n0 * a.ldw;
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      const int row = srow + p * RPD;
+      xo[p] = (unsigned)(min(row, a.M - 1 - m0) * a.ldx + ((spc ^ ((row >> 1) & 7)) << 3)) * 2u;
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      const int row = srow + p * RPD;
+      wo[p] = (unsigned)(min(row, a.N - 1 - n0) * a.ldw + ((spc ^ ((row >> 1) & 7)) << 3)) * 2u;
+    }
+    if (a.bias)
+      lds_dma16(a.bias, (unsigned)min(n0 + lane * 4, a.N - 4) * 4u, bias_s + (seq & 1) * 256);
+  };
+  auto dma = [&](int g, int kt) {
+    bf16* st = smem + (g & 1) * STAGE;
+#pragma unroll
+    for (int p = 0; p < PA; ++p)
+      lds_dma16(xbase + kt * BK, xo[p], st + (p * RPD + wave * 8) * BK);
+#pragma unroll
+    for (int p = 0; p < PB; ++p)
+      lds_dma16(wbase + kt * BK, wo[p], st + BM * BK + (p * RPD + wave * 8) * BK);
+  };
+
+  f32x16 acc[TM][TN];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  zero_acc();
+
+  const int nk = a.K / BK;
+  const int frow = lane & 31, fk = lane >> 5;
+  bf16x8 fa[2][TM], fb[2][TN];
+  auto load_phase = [&](int g, int sub) {
+    const bf16* Ac = smem + (g & 1) * STAGE;
+    const bf16* Bc = Ac + BM * BK;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8*>(Ac + swz(wm * WTM + i * 32 + frow, sub * 4 + ks * 2 + fk));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[ks][j] = *reinterpret_cast<const bf16x8*>(Bc + swz(wn * WTN + j * 32 + frow, sub * 4 + ks * 2 + fk));
+    }
+  };
+  auto math_phase = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto phase_barrier = [&](bool landed) {
+    if (landed) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  aim(0);
+  dma(0, 0);
+  phase_barrier(true);
+  int g = 0;                                              // K tiles consumed so far (selects the ring stage)
+  for (int seq = 0; seq < T; ++seq) {
+    const int id = first + seq * P;
+    const int tm0 = (id / tilesN) * BM, tn0 = (id % tilesN) * BN;
+    if (wm == 1) phase_barrier(false);                    // stagger: group 1 runs one phase behind (see the wide kernel)
+    for (int kt = 0; kt < nk; ++kt, ++g) {
+      load_phase(g, 0);
+      if (kt + 1 < nk) dma(g + 1, kt + 1);
+      else if (seq + 1 < T) { aim(seq + 1); dma(g + 1, 0); }     // the stream continues into the next output tile
+      phase_barrier(false);
+      math_phase();
+      phase_barrier(false);
+      load_phase(g, 1);
+      phase_barrier(wm == 1);
+      math_phase();
+      phase_barrier(wm == 0);
+    }
+    if (wm == 0) phase_barrier(false);                    // re-align the barrier count of the two groups
+    bf16* Cs = smem + ((g - 1) & 1) * STAGE;              // the stage the last K tile just vacated
+    const float* bias_c = bias_s + (seq & 1) * 256;
+    if (tm0 + BM <= a.M && tn0 + BN <= a.N)
+      tile_epilogue<BM, BN, WM, WN, ROUNDS, EPI, HAS_R, HAS_RS, true, true>(a, acc, Cs, bias_c, tm0, tn0);
+    else
+      tile_epilogue<BM, BN, WM, WN, ROUNDS, EPI, HAS_R, HAS_RS, false, true>(a, acc, Cs, bias_c, tm0, tn0);
+    zero_acc();
+  }
+}
+
 }  // namespace
 
 // C ABI ---------------------------------------------------------------------------------------------------------
@@ -692,9 +864,12 @@ extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bia
   else if (big >= 192 || force == 128) shape = v2 ? 2 : 4;
   else shape = v2 ? 3 : 5;
   const long small = (long)cdiv(M, 64) * cdiv(N, 64);
+  static const int persist_env = getenv("FIBER_GEMM_PERSIST") ? atoi(getenv("FIBER_GEMM_PERSIST")) : 1;
+  const bool persist = persist_env && wide >= 512;        // at least two tiles per CU
 #define FIBER_LAUNCH_EPI(EPI, R, RS)                                                                                          \
   do {                                                                                                                        \
-    if (shape == 0) hipLaunchKernelGGL((gemm_nt_wide_kernel<2, 4, EPI, R, RS>), dim3((unsigned)wide), dim3(512), 0, stream, a);   \
+    if (shape == 0 && persist) hipLaunchKernelGGL((gemm_nt_wide_persist_kernel<2, 4, EPI, R, RS>), dim3(256), dim3(512), 0, stream, a); \
+    else if (shape == 0) hipLaunchKernelGGL((gemm_nt_wide_kernel<2, 4, EPI, R, RS>), dim3((unsigned)wide), dim3(512), 0, stream, a);   \
     else if (shape == 1) hipLaunchKernelGGL((gemm_nt_glds_kernel<256, 128, 4, 2, 3, EPI, R, RS>), dim3((unsigned)huge), dim3(512), 0, stream, a); \
     else if (shape == 2) hipLaunchKernelGGL((gemm_nt_glds_kernel<128, 128, 2, 2, 2, EPI, R, RS>), dim3((unsigned)big), dim3(256), 0, stream, a);  \
     else hipLaunchKernelGGL((gemm_nt_glds_kernel<64, 64, 2, 2, 2, EPI, R, RS>), dim3((unsigned)small), dim3(256), 0, stream, a);                   \
