@@ -6,6 +6,7 @@ configure_optimizers (:522).  Parameter names / shapes equal the reference's so 
 (`load_path`, ITC queue keys dropped as at :141-146).  Captioning / ITC-queue / NLVR2 code is out of scope (SURVEY.md
 section 2) and raises if requested.
 """
+import os
 import types
 
 import torch
@@ -169,34 +170,78 @@ class FIBERTransformerSS(LightningModule):
                     "text_masks": None, "image": None}
 
         # ---- fused branch (fiber_module.py:310-367) ------------------------------------------------------------
+        # The text stack below the first fusion block (embeddings + layers 0..5: 20k-row GEMMs, 80-240 tiles for 256 CUs)
+        # does not depend on the image stack below it (stages 0-1 and stage-2 blocks 0..13, mostly HBM-bound kernels), so it
+        # is issued on a second HIP stream and joined where the reference first mixes the two; autograd replays every
+        # node on its forward stream, so the two backward halves overlap the same way.
+        num_pre_text = self.num_text_layer - self.num_fuse_block
+
+        def text_prefix():
+            t = txt.embeddings(input_ids=text_ids)
+            e = txt.get_extended_attention_mask(text_masks, text_masks.size(), t.device)
+            for layer in txt.encoder.layer[:num_pre_text]:
+                t = layer(t, e)[0]
+            return t, e
+
+        side = None
+        if self.config.get("overlap_text_stream", True) and not os.environ.get("FIBER_NO_OVERLAP"):
+            side = self._text_stream(text_ids)
+        if side is not None:
+            main = torch.cuda.current_stream(text_ids.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                text_embeds, ext = text_prefix()
+        else:
+            text_embeds, ext = text_prefix()
+
         image_embeds = vit.patch_embed(img)
         for layer in vit.layers[:2]:
             image_embeds = layer(image_embeds)
 
-        text_embeds = txt.embeddings(input_ids=text_ids)
-        ext = txt.get_extended_attention_mask(text_masks, text_masks.size(), text_embeds.device)
-        num_pre_text = self.num_text_layer - self.num_fuse_block
-        for layer in txt.encoder.layer[:num_pre_text]:
-            text_embeds = layer(text_embeds, ext)[0]
+        # Fusion blocks: image block (reads the text tokens) and text layer (reads the image tokens) of one step are
+        # independent of each other (fiber_module.py:327-346 evaluates both from the previous step's pair), so the text layer
+        # runs on the second stream next to the much larger image block; two event waits per step keep the pair in lock step.
+        prefix_only = self.config.get("overlap_text_stream", True) == "prefix" or bool(os.environ.get("FIBER_OVERLAP_PREFIX_ONLY"))
+
+        def fused_step(blk, layer, image_embeds, text_embeds, **kw):
+            nonlocal side
+            if side is not None and prefix_only:             # join once, then single-stream
+                main.wait_stream(side)
+                text_embeds.record_stream(main)
+                ext.record_stream(main)
+                side = None
+            if side is None:
+                fuse_image_embeds = blk(image_embeds, text_embeds, ext)
+                text_embeds = layer(text_embeds, ext, encoder_hidden_states=image_embeds, **kw)[0]
+                return fuse_image_embeds, text_embeds
+            main.wait_stream(side)                           # text tokens of the previous step (produced on `side`)
+            side.wait_stream(main)                           # image tokens of the previous step (produced on `main`)
+            text_embeds.record_stream(main)
+            image_embeds.record_stream(side)
+            with torch.cuda.stream(side):
+                new_text = layer(text_embeds, ext, encoder_hidden_states=image_embeds, **kw)[0]
+            return blk(image_embeds, text_embeds, ext), new_text
 
         num_pre_block = 8 + num_pre_text
         for blk_cnt, blk in enumerate(vit.layers[2].blocks):
+            if blk_cnt == num_pre_block and side is not None:
+                ext.record_stream(main)
             if blk_cnt < num_pre_block:
                 image_embeds = blk(image_embeds)
             else:
-                fuse_image_embeds = blk(image_embeds, text_embeds, ext)
-                text_embeds = txt.encoder.layer[blk_cnt - 8](text_embeds, ext, encoder_hidden_states=image_embeds)[0]
-                image_embeds = fuse_image_embeds
+                image_embeds, text_embeds = fused_step(blk, txt.encoder.layer[blk_cnt - 8], image_embeds, text_embeds)
         if vit.layers[2].downsample is not None:
             image_embeds = vit.layers[2].downsample(image_embeds)
 
         for blk_cnt, blk in enumerate(vit.layers[3].blocks):
-            fuse_image_embeds = blk(image_embeds, text_embeds, ext)
-            text_embeds = txt.encoder.layer[blk_cnt + 10](text_embeds, ext, encoder_hidden_states=image_embeds,
-                                                          last_norm=(blk_cnt == 0))[0]
-            image_embeds = fuse_image_embeds
+            image_embeds, text_embeds = fused_step(blk, txt.encoder.layer[blk_cnt + 10], image_embeds, text_embeds,
+                                                   last_norm=(blk_cnt == 0))
         if vit.layers[3].downsample is not None:
             image_embeds = vit.layers[3].downsample(image_embeds)
+        if side is not None:
+            main.wait_stream(side)
+            text_embeds.record_stream(main)
+            ext.record_stream(main)
 
         text_embeds = ops.linear(text_embeds, self.cross_modal_text_transform.weight, self.cross_modal_text_transform.bias)
         image_embeds = ops.linear(image_embeds, self.cross_modal_image_transform.weight, self.cross_modal_image_transform.bias)
@@ -206,6 +251,16 @@ class FIBERTransformerSS(LightningModule):
         cls_feats = torch.cat([cls_feats_text, cls_feats_image], dim=-1)
         return {"text_feats": text_embeds, "image_feats": image_embeds, "cls_feats": cls_feats, "text_labels": text_labels,
                 "text_ids": text_ids, "text_masks": text_masks, "image": img}
+
+    def _text_stream(self, ref):
+        """Second HIP stream for the text prefix (one per module, created on first use)."""
+        if not ref.is_cuda:
+            return None
+        st = getattr(self, "_side_stream", None)
+        if st is None or st.device != ref.device:
+            st = torch.cuda.Stream(device=ref.device)
+            object.__setattr__(self, "_side_stream", st)
+        return st
 
     def forward(self, batch):
         ret = dict()
