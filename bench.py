@@ -116,7 +116,7 @@ def time_dominant_kernel(B, device):
     us = e0.elapsed_time(e1) * 1e3 / reps
     tf = 2.0 * M * N * K / (us * 1e-6) / 1e12
     alg_bytes = 2 * (M * K + N * K + 2 * M * N)          # X, W in; Y and the saved pre-activation out
-    out = {"kernel": "gemm_nt_glds_kernel<256,128,4,2,3> (stage-2 fc1: bias + GELU + pre-activation store)", "shape": [M, N, K], "us": round(us, 2),
+    out = {"kernel": "gemm_nt_wide_persist_kernel<2,4,1,false,false> (stage-2 fc1: bias + GELU + pre-activation store)", "shape": [M, N, K], "us": round(us, 2),
            "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
            "algorithmic_bytes": alg_bytes, "algorithmic_GBps": round(alg_bytes / us / 1e3, 1), "traffic": None}
     try:   # HBM bytes per launch from the committed PMC pass (profiles/, collected with rocprofv3 --pmc on this same shape)
