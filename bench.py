@@ -22,6 +22,20 @@ FLOP_FWD_PAIR = 111.07e9          # fused fwd per image-text pair incl. transfor
 FLOP_MLM_HEAD = 3.14e9
 FLOP_STEP_PER_IMAGE = 3 * (2 * FLOP_FWD_PAIR + FLOP_MLM_HEAD)   # = 675.8 GFLOP (fwd + 2x bwd, two passes)
 PEAK_BF16_TFLOPS = 2500.0         # dense MFMA bf16, MI355X_MICROARCH.md
+# Other task configurations of the same path (extras; the default line stays on BASELINE.json's metric).  Algorithmic
+# GFLOP per image per optimizer step, from SURVEY.md section 8(d): image-only Swin 94.16, text-only RoBERTa 6.85, fused 111.07
+# per pair at 384^2 / 40 tokens; 256.51 per pair at 576^2 / 50 tokens.
+TASKS = {
+    "mlm_itm": dict(named="task_pretrain_mlm_itm", flop=FLOP_STEP_PER_IMAGE,
+                    workload="FIBER-Base (Swin-B 384^2 + RoBERTa-base S=40) MLM+ITM pretrain step, fused backbone "
+                             "fwd+bwd x2 + heads + AdamW"),
+    "mlm_itm_itc": dict(named="task_pretrain_mlm_itm_itc", flop=3 * ((111.07e9 + FLOP_MLM_HEAD) + (94.16e9 + 6.85e9 + 0.27e9) + 3 * 111.07e9),
+                        workload="FIBER-Base 384^2 S=40 MLM + ITC (4096-deep queues) + hard-negative ITM (3B pairs) pretrain "
+                                 "step: 1 + 3 fused passes, image-only and text-only passes, heads, AdamW"),
+    "vqa": dict(named="task_finetune_vqa", flop=3 * 256.51e9,
+                workload="FIBER-Base VQAv2 fine-tune step, Swin-B 576^2 (18x18 windows) + RoBERTa-base S=50, BCE over 3129 "
+                         "answers, AdamW"),
+}
 
 
 def synth_batch(B, image_size, S, vocab, device, seed):
@@ -135,6 +149,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("FIBER_BENCH_BATCH", "256")), help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--task", choices=sorted(TASKS), default="mlm_itm",
+                    help="default = BASELINE.json's metric; the others are extra configurations of the same path")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,7 +169,10 @@ def main():
     lib.load()
     torch.manual_seed(0)
     ops.manual_seed(rank)
-    cfg = make_config(per_gpu_batchsize=args.batch, num_gpus=world, max_steps=100000, warmup_steps=10000)
+    from fiber_amd.config import named_config
+    task = TASKS[args.task]
+    cfg = named_config(task["named"], per_gpu_batchsize=args.batch, num_gpus=world, max_steps=100000, warmup_steps=10000,
+                       draw_false_image=1 if args.task == "mlm_itm" else 0)
     model = FIBERTransformerSS(cfg)
     for n, p in model.named_parameters():
         if "alpha_" in n:
@@ -164,6 +183,11 @@ def main():
     (opt,), (sched,) = model.configure_optimizers()
     net = parallel.wrap_ddp(model, device)
     batch = synth_batch(args.batch, cfg["image_size"], cfg["max_text_len"], cfg["vocab_size"], device, seed=rank)
+    if args.task == "vqa":                                   # 1-3 soft answers per question (vqav2_dataset schema)
+        gq = torch.Generator().manual_seed(rank)
+        ks = torch.randint(1, 4, (args.batch,), generator=gq).tolist()
+        batch["vqa_labels"] = [torch.randperm(cfg["vqav2_label_size"], generator=gq)[:k].tolist() for k in ks]
+        batch["vqa_scores"] = [[(0.3, 0.6, 0.9, 1.0)[int(torch.randint(0, 4, (1,), generator=gq))] for _ in range(k)] for k in ks]
 
     def step():
         out = net(batch)
@@ -199,22 +223,24 @@ def main():
     lossv = loss.item()
 
     if rank == 0:
-        tf_per_gpu = ips / world * FLOP_STEP_PER_IMAGE / 1e12
+        tf_per_gpu = ips / world * task["flop"] / 1e12
         res = {
-            "metric": "train-step images/sec (384^2, seq40) FIBER-Base", "value": round(ips, 2), "unit": "images/s",
+            "metric": "train-step images/sec (384^2, seq40) FIBER-Base" if args.task == "mlm_itm" else
+                      f"train-step images/sec FIBER-Base, task {args.task}", "value": round(ips, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "FIBER-Base (Swin-B 384^2 + RoBERTa-base S=40) MLM+ITM pretrain step, fused backbone "
-                                   "fwd+bwd x2 + heads + AdamW", "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+            "config": {"workload": task["workload"], "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "dropout": "reference defaults (text 0.1, DropPath linspace 0..0.1)"},
             "loss": round(lossv, 4),
             "roofline": {"bound": "mfma", "achieved": round(tf_per_gpu, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tf_per_gpu / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                         "basis": "675.8 GFLOP algorithmic per image per step (BASELINE.md section 3) / measured step time, per GPU"},
+                         "basis": f"{task['flop'] / 1e9:.1f} GFLOP algorithmic per image per step (BASELINE.md section 3 / SURVEY.md "
+                                  "section 8d) / measured step time, per GPU"},
         }
-        res["roofline"]["dominant_kernel"] = time_dominant_kernel(args.batch, device)
-        res["roofline"]["traffic"] = res["roofline"]["dominant_kernel"]["traffic"]
-        if world == 1 and not args.no_cpu_baseline:
+        if args.task == "mlm_itm":
+            res["roofline"]["dominant_kernel"] = time_dominant_kernel(args.batch, device)
+            res["roofline"]["traffic"] = res["roofline"]["dominant_kernel"]["traffic"]
+        if world == 1 and not args.no_cpu_baseline and args.task == "mlm_itm":
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
     if world > 1:

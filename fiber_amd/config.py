@@ -34,11 +34,15 @@ def make_config(**over):
     return c
 
 
-# Named task configs of the path built here (reference config.py:95-110 pre-training, :134-150 VQAv2 fine-tune).
+# Named task configs of the path built here (reference config.py:95-110 pre-training with / without ITC, :134-150 VQAv2).
 NAMED = {
     "task_pretrain_mlm_itm": dict(
         exp_name="mlm_itm", loss_names={"itm": 1, "mlm": 1}, draw_false_image=1, batch_size=4096, max_steps=100000,
         warmup_steps=0.1, whole_word_masking=False, learning_rate=1e-5, lr_mult_cross_modal=5, lr_mult_head=5),
+    "task_pretrain_mlm_itm_itc": dict(
+        exp_name="mlm_itm_itc", loss_names={"itm": 1, "mlm": 1, "itc": 1}, draw_false_image=0, batch_size=4096,
+        max_steps=100000, warmup_steps=0.1, whole_word_masking=False, learning_rate=1e-5, lr_mult_cross_modal=5,
+        lr_mult_head=5),
     "task_finetune_vqa": dict(
         exp_name="finetune_vqa", loss_names={"vqa": 1}, batch_size=512, max_epoch=10, max_steps=None, warmup_steps=0.1,
         learning_rate=2e-5, lr_mult_cross_modal=5, lr_mult_head=50, max_text_len=50, image_size=576,

@@ -80,10 +80,19 @@ def ptr(t):
     return t.data_ptr()
 
 
+_TRACE = [] if os.environ.get("FIBER_TRACE_LAUNCHES") else None     # debug: (stream, entry point, scalar args, event after launch)
+
+
 def call(name, *args):
     lib = load()
-    stream = torch.cuda.current_stream().cuda_stream
+    cur = torch.cuda.current_stream()
+    stream = cur.cuda_stream
     rc = getattr(lib, name)(*args, stream)
+    if _TRACE is not None:
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        _TRACE.append((stream, name, [a for a in args if isinstance(a, (int, float))], ev))
+        del _TRACE[:-4000]
     if rc != 0:
         raise FiberHipError(f"{name} failed with code {rc} ({ {1: 'invalid argument', 2: 'launch failure'}.get(rc, '?')})")
 

@@ -19,13 +19,24 @@ from .roberta import RobertaModel
 from .swin_helpers import swin_adapt_position_encoding
 
 
+@torch.no_grad()
+def concat_all_gather(tensor):
+    """fiber_module.py:12-24 (torch.distributed.all_gather, no gradient); the identity in a single-process run."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return tensor
+    out = [torch.empty_like(tensor) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, tensor.contiguous(), async_op=False)
+    return torch.cat(out, dim=0)
+
+
 class FIBERTransformerSS(LightningModule):
     def __init__(self, config):
         super().__init__()
         self.save_hyperparameters()
         self.config = config
         ln = config["loss_names"]
-        for k in ("itc", "caption_mle", "caption_gold", "caption_cider", "nlvr2"):
+        for k in ("caption_mle", "caption_gold", "caption_cider", "nlvr2"):
             if ln.get(k, 0) > 0:
                 raise NotImplementedError(f"loss '{k}' is outside the fused-backbone hot path built here")
 
@@ -47,6 +58,17 @@ class FIBERTransformerSS(LightningModule):
         for m in (self.cross_modal_text_transform, self.cross_modal_image_transform,
                   self.cross_modal_text_transform_itc, self.cross_modal_image_transform_itc):
             m.apply(objectives.init_weights)
+
+        if ln.get("itc", 0) > 0:                                         # ALBEF-style queues (fiber_module.py:56-67)
+            self.temp = nn.Parameter(torch.ones([]) * 0.07)
+            self.queue_size = qs = config.get("itc_queue_size", 4096)
+            self.register_buffer("image_queue", torch.randn(hs, qs))
+            self.register_buffer("text_queue", torch.randn(hs, qs))
+            self.register_buffer("image_input_queue", torch.randn(qs, 3, config["image_size"], config["image_size"]))
+            self.register_buffer("text_input_queue", torch.zeros(qs, config["max_text_len"], dtype=torch.long))
+            self.register_buffer("text_input_mask_queue", torch.zeros(qs, config["max_text_len"], dtype=torch.long))
+            self.register_buffer("queue_ptr", torch.zeros(1, dtype=torch.long))
+            self.register_buffer("queue_total", torch.zeros(1, dtype=torch.long))
 
         if "swin_arch" in config:                                        # test-only: explicit (embed_dim, depths, heads)
             dim, depths, nh = config["swin_arch"]
@@ -105,6 +127,23 @@ class FIBERTransformerSS(LightningModule):
         if config["load_path"] != "" and config.get("test_only", False):       # fine-tuned checkpoint, heads included (:173-180)
             self.load_state_dict(self._read_checkpoint(config["load_path"]), strict=False)
 
+    @torch.no_grad()
+    def _dequeue_and_enqueue(self, image_feat, text_feat, image_input, text_input, text_input_mask):
+        """fiber_module.py:181-222: the (all-gathered) batch overwrites the oldest queue slots, wrapping at queue_size;
+        queue_total counts every sample ever enqueued (it bounds the hard-negative pool, objectives.py:143-155)."""
+        image_feats, text_feats = concat_all_gather(image_feat), concat_all_gather(text_feat)
+        image_input, text_input = concat_all_gather(image_input), concat_all_gather(text_input)
+        text_input_mask = concat_all_gather(text_input_mask)
+        n = image_feats.shape[0]
+        slot = (int(self.queue_ptr) + torch.arange(n, device=image_feats.device)) % self.queue_size
+        self.image_queue[:, slot] = image_feats.T.to(self.image_queue.dtype)
+        self.text_queue[:, slot] = text_feats.T.to(self.text_queue.dtype)
+        self.image_input_queue[slot] = image_input.to(self.image_input_queue.dtype)
+        self.text_input_queue[slot] = text_input
+        self.text_input_mask_queue[slot] = text_input_mask
+        self.queue_ptr[0] = (int(self.queue_ptr) + n) % self.queue_size
+        self.queue_total[0] = int(self.queue_total) + n
+
     @staticmethod
     def _read_checkpoint(path):
         state_dict = torch.load(path, map_location="cpu")["state_dict"]
@@ -113,16 +152,21 @@ class FIBERTransformerSS(LightningModule):
             state_dict.pop(key, None)
         return state_dict
 
-    # parameters that never receive a gradient on the fused MLM+ITM path (SURVEY.md section 7 "DDP unused parameters")
+    # parameters that never receive a gradient for the configured losses (SURVEY.md section 7 "DDP unused parameters");
+    # with ITC the image-only / text-only passes also exercise vit_model.norm, the *_itc transforms / poolers and layer 11's
+    # output LayerNorm
     def unused_parameter_names(self):
+        itc = self.config["loss_names"].get("itc", 0) > 0
         names = []
         for n, _ in self.named_parameters():
-            if (n.startswith("vit_model.norm.") or n.startswith("text_transformer.pooler.") or "_itc." in n
-                    or n.startswith("rank_output.") or ("crossattention_t2i.output.LayerNorm" in n)):
+            if (n.startswith("text_transformer.pooler.") or n.startswith("rank_output.")
+                    or ("crossattention_t2i.output.LayerNorm" in n)
+                    or (not itc and (n.startswith("vit_model.norm.") or "_itc." in n))):
                 names.append(n)
         last = self.num_text_layer - 1                  # layer 11 runs with last_norm=False on the fused path (:342)
-        names += [f"text_transformer.encoder.layer.{last}.output.LayerNorm.weight",
-                  f"text_transformer.encoder.layer.{last}.output.LayerNorm.bias"]
+        if not itc:
+            names += [f"text_transformer.encoder.layer.{last}.output.LayerNorm.weight",
+                      f"text_transformer.encoder.layer.{last}.output.LayerNorm.bias"]
         stage2 = self.vit_model.layers[2].blocks
         if len(stage2) < 8 + self.num_text_layer - self.num_fuse_block + 1:      # Swin-T quirk: text layers 6..9 never run
             for i in range(self.num_text_layer - self.num_fuse_block, 10):
@@ -152,7 +196,7 @@ class FIBERTransformerSS(LightningModule):
             for layer in txt.encoder.layer:
                 text_embeds = layer(text_embeds, ext)[0]
             text_embeds = ops.linear(text_embeds, self.cross_modal_text_transform_itc.weight, self.cross_modal_text_transform_itc.bias)
-            cls = self.cross_modal_text_pooler_itc(text_embeds) if self.itc_pooler else text_embeds[:, 0]
+            cls = (self.cross_modal_text_pooler_itc(text_embeds) if self.itc_pooler else text_embeds[:, 0]).float()
             cls = cls / cls.norm(dim=-1, keepdim=True)
             return {"text_feats": text_embeds, "image_feats": None, "cls_feats": cls, "text_labels": text_labels,
                     "text_ids": text_ids, "text_masks": text_masks, "image": None}
@@ -164,7 +208,7 @@ class FIBERTransformerSS(LightningModule):
             x = ops.layernorm(x, vit.norm.weight, vit.norm.bias, vit.norm.eps)
             x = ops.linear(x, self.cross_modal_image_transform_itc.weight, self.cross_modal_image_transform_itc.bias)
             avg = x.float().mean(1, keepdim=True)
-            cls = self.cross_modal_image_pooler_itc(avg) if self.itc_pooler else avg[:, 0]
+            cls = (self.cross_modal_image_pooler_itc(avg) if self.itc_pooler else avg[:, 0]).float()
             cls = cls / cls.norm(dim=-1, keepdim=True)
             return {"text_feats": None, "image_feats": x, "cls_feats": cls, "text_labels": None, "text_ids": None,
                     "text_masks": None, "image": None}
@@ -260,6 +304,9 @@ class FIBERTransformerSS(LightningModule):
         if st is None or st.device != ref.device:
             st = torch.cuda.Stream(device=ref.device)
             object.__setattr__(self, "_side_stream", st)
+            quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+            if quiet is not None:                            # parameters of the text stack accumulate on the second stream by design
+                quiet(False)
         return st
 
     def forward(self, batch):
@@ -267,7 +314,14 @@ class FIBERTransformerSS(LightningModule):
         if len(self.current_tasks) == 0:
             ret.update(self.infer(batch))
             return ret
-        if ("mlm" in self.current_tasks and "itm" in self.current_tasks and self.config.get("fuse_mlm_itm", True)):
+        if "itc" in self.current_tasks:                       # task_pretrain_mlm_itm_itc (reference forward :437-451)
+            if "mlm" in self.current_tasks:
+                ret.update(objectives.compute_mlm(self, batch))
+            ret_itc, image_neg, text_neg, text_mask_neg = objectives.compute_itc(self, batch, batch.get("itc_neg_override"))
+            ret.update(ret_itc)
+            if "itm" in self.current_tasks:
+                ret.update(objectives.compute_itm_hardneg(self, batch, image_neg, text_neg, text_mask_neg))
+        elif ("mlm" in self.current_tasks and "itm" in self.current_tasks and self.config.get("fuse_mlm_itm", True)):
             ret.update(objectives.compute_mlm_itm_fused(self, batch, batch.get("itm_labels_override")))
         else:
             if "mlm" in self.current_tasks:

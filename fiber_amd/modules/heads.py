@@ -28,7 +28,7 @@ class ITMHead(nn.Module):
         self.fc = nn.Linear(hidden_size, 2)
 
     def forward(self, x):
-        return F.linear(x.float(), self.fc.weight, self.fc.bias)
+        return ops.lib_linear(x.float(), self.fc.weight, self.fc.bias)
 
 
 class BertPredictionHeadTransform(nn.Module):
@@ -55,7 +55,7 @@ class MLMHead(nn.Module):
 
     def forward(self, x):
         h = self.transform(x)
-        return F.linear(h, ops.cast_bf16(self.decoder.weight), ops.cast_bf16(self.bias))
+        return ops.lib_linear(h, ops.cast_bf16(self.decoder.weight), ops.cast_bf16(self.bias))
 
 
 class VQAClassifier(nn.Sequential):
@@ -70,4 +70,4 @@ class VQAClassifier(nn.Sequential):
         fc0, ln, _, fc1 = self
         h = ops.linear(x.to(torch.bfloat16), fc0.weight, fc0.bias)
         h = ops.layernorm(h, ln.weight, ln.bias, ln.eps)
-        return F.linear(F.gelu(h.float()), fc1.weight, fc1.bias)
+        return ops.lib_linear(F.gelu(h.float()), fc1.weight, fc1.bias)

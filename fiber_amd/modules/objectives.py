@@ -1,8 +1,10 @@
-"""Loss functions on the metric path: compute_mlm / compute_itm / compute_vqa / init_weights
-(reference coarse_grained/fiber/modules/objectives.py:17-75, 182-213, 502-510).  Same call signatures and return keys."""
+"""Loss functions on the metric path: compute_mlm / compute_itm / compute_itm_hardneg / compute_itc / compute_vqa /
+init_weights (reference coarse_grained/fiber/modules/objectives.py:17-213, 502-510).  Same call signatures and return keys."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from .. import ops
 
 
 def compute_mlm(pl_module, batch):
@@ -81,6 +83,78 @@ def compute_mlm_itm_fused(pl_module, batch, itm_labels=None):
         acc = getattr(pl_module, f"{phase}_{task}_accuracy")(ret[f"{task}_logits"], ret[f"{task}_labels"])
         pl_module.log(f"{task}/{phase}/loss", loss)
         pl_module.log(f"{task}/{phase}/accuracy", acc)
+    return ret
+
+
+def compute_itc(pl_module, batch, neg_override=None):
+    """Image-text contrastive loss against the local batch + the feature queues, and the hard-negative draw that feeds
+    compute_itm_hardneg (objectives.py:119-180, after ALBEF).  The reference draws one negative per row with a Python loop
+    of `torch.multinomial(...).item()` (2B host syncs); here both draws are one batched multinomial each and the gathers stay
+    on the device -- the same distribution, a different consumption of the RNG stream.  `neg_override = (image_idx, text_idx)`
+    pins the draw for parity tests."""
+    with torch.no_grad():
+        pl_module.temp.clamp_(0.001, 1.0)
+    infer_image = pl_module.infer(batch, mask_image=False, mask_text=False, image_only=True)
+    infer_text = pl_module.infer(batch, mask_image=False, mask_text=False, text_only=True)
+    image_feat, text_feat = infer_image["cls_feats"].float(), infer_text["cls_feats"].float()
+    image_feat_all = torch.cat([image_feat.t().detach(), pl_module.image_queue.detach().float()], dim=1)
+    text_feat_all = torch.cat([text_feat.t().detach(), pl_module.text_queue.detach().float()], dim=1)
+    sim_i2t = ops.lib_linear(image_feat, text_feat_all.t().contiguous()) / pl_module.temp
+    sim_t2i = ops.lib_linear(text_feat, image_feat_all.t().contiguous()) / pl_module.temp
+    bs = image_feat.size(0)
+    diag = torch.arange(bs, device=sim_i2t.device)
+    loss_i2t = -F.log_softmax(sim_i2t, dim=1)[diag, diag].mean()         # sim_targets = identity on the first bs columns
+    loss_t2i = -F.log_softmax(sim_t2i, dim=1)[diag, diag].mean()
+    loss_itc = (loss_i2t + loss_t2i) / 2.0
+
+    total = int(pl_module.queue_total)      # NB as in the reference this may exceed queue_size once the queue has wrapped
+    pool = min(bs + total, sim_i2t.shape[1])
+    tot_image = torch.cat([batch["image"][0], pl_module.image_input_queue[:total].to(batch["image"][0].dtype)], dim=0)
+    tot_text = torch.cat([batch["text_ids"], pl_module.text_input_queue[:total]], dim=0)
+    tot_text_mask = torch.cat([batch["text_masks"], pl_module.text_input_mask_queue[:total]], dim=0)
+    if neg_override is not None:
+        img_idx, txt_idx = (torch.as_tensor(v, device=sim_i2t.device) for v in neg_override)
+    else:
+        with torch.no_grad():
+            w_i2t = F.softmax(sim_i2t[:, :pool], dim=1)
+            w_t2i = F.softmax(sim_t2i[:, :pool], dim=1)
+            w_i2t[diag, diag] = 0
+            w_t2i[diag, diag] = 0
+            img_idx = torch.multinomial(w_t2i + 1e-9, 1).squeeze(1)
+            txt_idx = torch.multinomial(w_i2t + 1e-9, 1).squeeze(1)
+    image_neg, text_neg, text_mask_neg = tot_image[img_idx], tot_text[txt_idx], tot_text_mask[txt_idx]
+
+    if pl_module.training:
+        pl_module._dequeue_and_enqueue(infer_image["cls_feats"].detach().clone(), infer_text["cls_feats"].detach().clone(),
+                                       batch["image"][0].clone(), batch["text_ids"].clone(), batch["text_masks"].clone())
+    ret = {"itc_loss": loss_itc}
+    phase = "train" if pl_module.training else "val"
+    loss = getattr(pl_module, f"{phase}_itc_loss")(ret["itc_loss"])
+    pl_module.log(f"itc/{phase}/loss", loss)
+    return ret, image_neg, text_neg, text_mask_neg
+
+
+def compute_itm_hardneg(pl_module, batch, image_neg, text_neg, text_mask_neg):
+    """ITM over 3B pairs: the B true pairs, (image, hard-negative text) and (hard-negative image, text)
+    (objectives.py:78-116).  The reference overwrites batch["image"/"text_ids"/"text_masks"] in place; a shallow copy is
+    used here so later objectives still see the loader's batch."""
+    pos_len = len(batch["text"])
+    itm_labels = torch.cat([torch.ones(pos_len), torch.zeros(2 * pos_len)]).to(pl_module.device)
+    img = batch["image"][0]
+    b3 = {k: v for k, v in batch.items()}
+    b3["image"] = [torch.cat([img, img, image_neg.to(img.dtype)], dim=0)]
+    b3["text_ids"] = torch.cat([batch["text_ids"], text_neg, batch["text_ids"]], dim=0)
+    b3["text_masks"] = torch.cat([batch["text_masks"], text_mask_neg, batch["text_masks"]], dim=0)
+    b3["text_labels"] = torch.cat([batch["text_labels"]] * 3, dim=0)
+    infer = pl_module.infer(b3, mask_text=False, mask_image=False)
+    itm_logits = pl_module.itm_score(infer["cls_feats"])
+    itm_loss = F.cross_entropy(itm_logits, itm_labels.long())
+    ret = {"itm_loss": itm_loss, "itm_logits": itm_logits, "itm_labels": itm_labels}
+    phase = "train" if pl_module.training else "val"
+    loss = getattr(pl_module, f"{phase}_itm_loss")(ret["itm_loss"])
+    acc = getattr(pl_module, f"{phase}_itm_accuracy")(ret["itm_logits"], ret["itm_labels"])
+    pl_module.log(f"itm/{phase}/loss", loss)
+    pl_module.log(f"itm/{phase}/accuracy", acc)
     return ret
 
 

@@ -117,6 +117,65 @@ def colsum(x2):
 
 _bmm_fp32 = [None]
 
+# ---- library GEMMs are kept in ONE global order across HIP streams ------------------------------------------------
+# hipBLASLt picks stream-K kernels for many of these shapes (…_SK3_… in the rocprof traces): persistent grids whose
+# workgroups spin on each other's partial tiles and therefore assume they are all resident.  Two of them in flight on two
+# streams (the fused branch runs the text stack on a second stream) can each hold half the CUs and wait for the other half
+# forever -- observed as a 100 %-busy GPU with both streams parked behind a library GEMM.  Every library GEMM issued from
+# this package therefore waits for the previous one, whichever stream it was issued on (one event wait, only when the stream
+# changes); library GEMMs still overlap with every other kernel.
+_lib_gemm_last = {"event": None, "stream": None}
+
+
+class lib_gemm:
+    def __enter__(self):
+        self.cur = torch.cuda.current_stream()
+        last = _lib_gemm_last
+        if last["event"] is not None and last["stream"] != self.cur.cuda_stream:
+            self.cur.wait_event(last["event"])
+        return self
+
+    def __exit__(self, *exc):
+        ev = torch.cuda.Event()
+        ev.record(self.cur)
+        _lib_gemm_last["event"], _lib_gemm_last["stream"] = ev, self.cur.cuda_stream
+        return False
+
+
+def lib_matmul(a, b):
+    with lib_gemm():
+        return torch.matmul(a, b)
+
+
+class _LibLinear(torch.autograd.Function):
+    """y = x.W^T + b on the library GEMM (caller-side heads: vocabulary decoder, ITM / VQA classifiers), forward and both
+    backward GEMMs inside the global library-GEMM order."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        with lib_gemm():
+            return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
+        dx = dw = db = None
+        with lib_gemm():
+            if ctx.needs_input_grad[0]:
+                dx = torch.matmul(dy2, w).view(x.shape)
+            if ctx.needs_input_grad[1]:
+                dw = torch.matmul(dy2.t(), x2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.sum(0)
+        return dx, dw, db
+
+
+def lib_linear(x, w, b=None):
+    return _LibLinear.apply(x, w, b)
+
 
 def wgrad(dh, x2):
     """dW[N,K] = dh[M,N]^T . x2[M,K] in fp32.  The library TN GEMM does not split the (huge) M reduction, so for
@@ -129,7 +188,7 @@ def wgrad(dh, x2):
     while S < 64 and tiles * S < 512 and M % (2 * S) == 0 and M // (2 * S) >= 1024:
         S *= 2
     if S == 1:
-        return torch.matmul(dh.t(), x2).float()
+        return lib_matmul(dh.t(), x2).float()
     a = dh.view(S, M // S, N).transpose(1, 2)
     b = x2.view(S, M // S, K)
     if _bmm_fp32[0] is None:
@@ -138,9 +197,12 @@ def wgrad(dh, x2):
             _bmm_fp32[0] = True
         except Exception:  # noqa: BLE001
             _bmm_fp32[0] = False
-    if _bmm_fp32[0]:
-        return torch.bmm(a, b, out_dtype=torch.float32).sum(0)
-    return torch.bmm(a, b).float().sum(0)
+    with lib_gemm():
+        if _bmm_fp32[0]:
+            out = torch.bmm(a, b, out_dtype=torch.float32)
+        else:
+            out = torch.bmm(a, b).float()
+    return out.sum(0)
 
 
 class _Linear(torch.autograd.Function):
@@ -173,7 +235,7 @@ class _Linear(torch.autograd.Function):
         else:
             dh = dy2
         wb = bf16_weight(weight)
-        dx = torch.matmul(dh, wb).view(ctx.shp) if ctx.needs_input_grad[0] else None
+        dx = lib_matmul(dh, wb).view(ctx.shp) if ctx.needs_input_grad[0] else None
         dw = wgrad(dh, x2) if ctx.needs_input_grad[1] else None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = db if db is not None else colsum(dh)
@@ -229,10 +291,10 @@ class _MLP(torch.autograd.Function):
         if C % 64 == 0 and C4 % 8 == 0 and _FUSED_MLP_BWD:
             dh, db1 = gemm_nt(dy2, bf16_weight_t(w2), None, None, 2, False, aux=h, want_colsum=True)
         else:                                         # shapes the DMA kernel does not cover (e.g. Swin-T C=96)
-            dh, db1 = gelu_bwd_colsum(torch.matmul(dy2, bf16_weight(w2)), h)
+            dh, db1 = gelu_bwd_colsum(lib_matmul(dy2, bf16_weight(w2)), h)
         dw2 = wgrad(dy2, g)
         db2 = colsum(dy2)
-        dx = torch.matmul(dh, bf16_weight(w1)).view(ctx.shp)
+        dx = lib_matmul(dh, bf16_weight(w1)).view(ctx.shp)
         dw1 = wgrad(dh, x2)
         return dx, dw1, db1, dw2, db2, dres, None
 
@@ -425,7 +487,7 @@ class _LinearQKVHeadMajor(torch.autograd.Function):
         dy2 = _c(dy).view(-1, weight.shape[0])
         perm, inv = _qkv_perm(weight.shape[1], ctx.heads, dy.device)
         wp = _wcache[("HM", id(weight))][1][0]
-        dx = torch.matmul(dy2, wp).view(ctx.shp)
+        dx = lib_matmul(dy2, wp).view(ctx.shp)
         dw = wgrad(dy2, x2)[inv]
         db = colsum(dy2)[inv]
         return dx, dw, db, None

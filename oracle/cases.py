@@ -65,6 +65,12 @@ VQA_CASES = {
                                     loss_names={"vqa": 1}), B=2),
     "vqa_swin_b_576": dict(config=dict(SWIN_B, image_size=576, max_text_len=50, loss_names={"vqa": 1}), B=1),
 }
+# task_pretrain_mlm_itm_itc (reference config.py:95-110): MLM + ITC against feature queues + ITM on
+# hard negatives drawn from batch + raw-input queues.  Two consecutive training steps on different batches, so the second
+# step sees a non-empty queue, a wrapped queue pointer (queue_size 6 < 2 * B) and queue-drawn negatives.
+ITC_CASES = {
+    "itc_tiny": dict(config=dict(TINY, loss_names={"mlm": 1, "itm": 1, "itc": 1}, itc_queue_size=6, draw_false_image=0), B=4),
+}
 ADAPT_CASE = dict(before=384, after=576, heads=4)       # swin_adapt_position_encoding: 23^2 -> 35^2 rows
 
 

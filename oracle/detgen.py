@@ -21,6 +21,8 @@ def tensor_for(name, shape, seed=0, alpha=0.5):
     leaf = name.rsplit(".", 1)[-1]
     if "alpha_" in name:
         return torch.full(shape, alpha, dtype=torch.float32)
+    if leaf == "temp":                                   # ITC temperature keeps its initial value (fiber_module.py:58)
+        return torch.full(shape, 0.07, dtype=torch.float32)
     if "relative_position_bias_table" in name:
         return n(0.5)
     is_norm = ("norm" in name.lower()) and leaf in ("weight", "bias")

@@ -498,6 +498,17 @@ class FiberRef(nn.Module):
         if c["loss_names"].get("itm", 0) > 0:
             self.itm_score = ITMHead(hs * 2)
             self.rank_output = nn.Linear(hs, 1)
+        if c["loss_names"].get("itc", 0) > 0:             # fiber_module.py:56-67
+            qs = c.get("itc_queue_size", 4096)
+            self.queue_size = qs
+            self.temp = nn.Parameter(torch.ones([]) * 0.07)
+            self.register_buffer("image_queue", torch.randn(hs, qs))
+            self.register_buffer("text_queue", torch.randn(hs, qs))
+            self.register_buffer("image_input_queue", torch.randn(qs, 3, c["image_size"], c["image_size"]))
+            self.register_buffer("text_input_queue", torch.zeros(qs, c["max_text_len"], dtype=torch.long))
+            self.register_buffer("text_input_mask_queue", torch.zeros(qs, c["max_text_len"], dtype=torch.long))
+            self.register_buffer("queue_ptr", torch.zeros(1, dtype=torch.long))
+            self.register_buffer("queue_total", torch.zeros(1, dtype=torch.long))
         if c["loss_names"].get("vqa", 0) > 0:             # fiber_module.py:149-157
             self.vqa_classifier = nn.Sequential(nn.Linear(hs * 2, hs * 2), nn.LayerNorm(hs * 2), nn.GELU(),
                                                 nn.Linear(hs * 2, c["vqav2_label_size"]))
@@ -539,6 +550,74 @@ class FiberRef(nn.Module):
         cls_i = self.cross_modal_image_pooler(x.mean(1, keepdim=True))
         return {"text_feats": t, "image_feats": x, "cls_feats": torch.cat([cls_t, cls_i], -1),
                 "text_labels": labels, "text_ids": ids, "text_masks": masks, "image": img}
+
+    def infer_text_only(self, batch):
+        """fiber_module.py:247-277: all 12 layers without cross-attention, ITC transform + pooler, L2-normalised."""
+        txt = self.text_transformer
+        t = txt.embeddings(batch["text_ids"])
+        ext = txt.get_extended_attention_mask(batch["text_masks"])
+        for lyr in txt.encoder.layer:
+            t = lyr(t, ext)[0]
+        t = self.cross_modal_text_transform_itc(t)
+        cls = self.cross_modal_text_pooler_itc(t) if self.config["itc_pooler"] else t[:, 0]
+        return {"text_feats": t, "cls_feats": cls / cls.norm(dim=-1, keepdim=True)}
+
+    def infer_image_only(self, batch):
+        """fiber_module.py:279-308: every Swin block without the text input, final norm, ITC transform + pooler."""
+        vit = self.vit_model
+        x = vit.patch_embed(batch["image"][0])
+        for layer in vit.layers:
+            x = layer(x)
+        x = self.cross_modal_image_transform_itc(vit.norm(x))
+        avg = x.mean(1, keepdim=True)
+        cls = self.cross_modal_image_pooler_itc(avg) if self.config["itc_pooler"] else avg[:, 0]
+        return {"image_feats": x, "cls_feats": cls / cls.norm(dim=-1, keepdim=True)}
+
+    def compute_itc(self, batch, neg_idx):
+        """objectives.py:119-180 with the hard-negative indices `neg_idx = (image_idx, text_idx)` supplied by the caller
+        (the reference draws them with torch.multinomial; fixtures record the draw).  Returns (dict, negatives)."""
+        with torch.no_grad():
+            self.temp.clamp_(0.001, 1.0)
+        fi, ft = self.infer_image_only(batch)["cls_feats"], self.infer_text_only(batch)["cls_feats"]
+        fi_all = torch.cat([fi.t().detach(), self.image_queue.detach()], dim=1)
+        ft_all = torch.cat([ft.t().detach(), self.text_queue.detach()], dim=1)
+        sim_i2t, sim_t2i = fi @ ft_all / self.temp, ft @ fi_all / self.temp
+        tgt = torch.zeros_like(sim_i2t)
+        tgt.fill_diagonal_(1)
+        loss = (-(F.log_softmax(sim_i2t, 1) * tgt).sum(1).mean() - (F.log_softmax(sim_t2i, 1) * tgt).sum(1).mean()) / 2.0
+        total = int(self.queue_total)
+        tot_image = torch.cat([batch["image"][0], self.image_input_queue[:total]], 0)
+        tot_text = torch.cat([batch["text_ids"], self.text_input_queue[:total]], 0)
+        tot_mask = torch.cat([batch["text_masks"], self.text_input_mask_queue[:total]], 0)
+        ii, ti = neg_idx
+        out = {"itc_loss": loss, "sim_i2t": sim_i2t, "sim_t2i": sim_t2i, "image_cls": fi, "text_cls": ft}
+        return out, (tot_image[ii], tot_text[ti], tot_mask[ti])
+
+    def dequeue_and_enqueue(self, image_feat, text_feat, image_input, text_input, text_mask):
+        """fiber_module.py:181-222, single process (all_gather = identity)."""
+        n = image_feat.shape[0]
+        with torch.no_grad():
+            slot = (int(self.queue_ptr) + torch.arange(n)) % self.queue_size
+            self.image_queue[:, slot] = image_feat.detach().T
+            self.text_queue[:, slot] = text_feat.detach().T
+            self.image_input_queue[slot] = image_input
+            self.text_input_queue[slot] = text_input
+            self.text_input_mask_queue[slot] = text_mask
+            self.queue_ptr[0] = (int(self.queue_ptr) + n) % self.queue_size
+            self.queue_total[0] = int(self.queue_total) + n
+
+    def compute_itm_hardneg(self, batch, image_neg, text_neg, text_mask_neg):
+        """objectives.py:78-116."""
+        B = batch["text_ids"].shape[0]
+        img = batch["image"][0]
+        b3 = {"image": [torch.cat([img, img, image_neg], 0)],
+              "text_ids": torch.cat([batch["text_ids"], text_neg, batch["text_ids"]], 0),
+              "text_masks": torch.cat([batch["text_masks"], text_mask_neg, batch["text_masks"]], 0),
+              "text_labels": torch.cat([batch["text_labels"]] * 3, 0)}
+        labels = torch.cat([torch.ones(B), torch.zeros(2 * B)])
+        out = self.infer(b3)
+        logits = self.itm_score(out["cls_feats"])
+        return {"itm_loss": F.cross_entropy(logits, labels.long()), "itm_logits": logits, "itm_labels": labels}
 
     def compute_mlm(self, batch):
         out = self.infer(batch, mask_text=True)

@@ -159,6 +159,19 @@ class RefFused(nn.Module):
         self.cross_modal_text_pooler_itc = heads.Pooler(hs)
         hcfg = shim.roberta_config(vocab_size=c["vocab_size"], hidden_size=hs, layer_norm_eps=1e-12)
         ln = c["loss_names"]
+        self.avgpool = nn.AdaptiveAvgPool1d(1)
+        self.itc_pooler = c["itc_pooler"]
+        if ln.get("itc", 0) > 0:                           # wiring of fiber_module.py:56-67
+            qs = c.get("itc_queue_size", 4096)
+            self.queue_size = qs
+            self.temp = nn.Parameter(torch.ones([]) * 0.07)
+            self.register_buffer("image_queue", torch.randn(hs, qs))
+            self.register_buffer("text_queue", torch.randn(hs, qs))
+            self.register_buffer("image_input_queue", torch.randn(qs, 3, c["image_size"], c["image_size"]))
+            self.register_buffer("text_input_queue", torch.zeros(qs, c["max_text_len"], dtype=torch.long))
+            self.register_buffer("text_input_mask_queue", torch.zeros(qs, c["max_text_len"], dtype=torch.long))
+            self.register_buffer("queue_ptr", torch.zeros(1, dtype=torch.long))
+            self.register_buffer("queue_total", torch.zeros(1, dtype=torch.long))
         if ln.get("mlm", 0) > 0:
             self.mlm_score = heads.MLMHead(hcfg)
         if ln.get("itm", 0) > 0:
@@ -168,11 +181,27 @@ class RefFused(nn.Module):
             self.vqa_classifier = nn.Sequential(nn.Linear(hs * 2, hs * 2), nn.LayerNorm(hs * 2), nn.GELU(),
                                                 nn.Linear(hs * 2, c["vqav2_label_size"]))
 
-    def infer(self, batch, mask_text=False, img=None, mask_image=False):
+    def infer(self, batch, mask_text=False, img=None, mask_image=False, image_only=False, text_only=False):
         c = self.c
         img = batch["image"][0] if img is None else img
         sfx = "_mlm" if mask_text else ""
         ids, masks = batch["text_ids" + sfx], batch["text_masks"]
+        if text_only:                                      # sequencing of fiber_module.py:247-277
+            t = self.text_transformer.embeddings(input_ids=ids)
+            ext = (1.0 - masks[:, None, None, :].float()) * -10000.0
+            for layer in self.text_transformer.encoder.layer:
+                t = layer(t, ext)[0]
+            t = self.cross_modal_text_transform_itc(t)
+            cls = self.cross_modal_text_pooler_itc(t) if self.itc_pooler else t[:, 0]
+            return {"text_feats": t, "image_feats": None, "cls_feats": cls / cls.norm(dim=-1, keepdim=True)}
+        if image_only:                                     # sequencing of fiber_module.py:279-308
+            x = self.vit_model.patch_embed(img)
+            for layer in self.vit_model.layers:
+                x = layer(x)
+            x = self.cross_modal_image_transform_itc(self.vit_model.norm(x))
+            avg = self.avgpool(x.transpose(1, 2)).view(x.size(0), 1, -1)
+            cls = self.cross_modal_image_pooler_itc(avg) if self.itc_pooler else avg[:, 0]
+            return {"text_feats": None, "image_feats": x, "cls_feats": cls / cls.norm(dim=-1, keepdim=True)}
         x = self.vit_model.patch_embed(img)
         for layer in self.vit_model.layers[:2]:
             x = layer(x)
@@ -197,7 +226,8 @@ class RefFused(nn.Module):
         x = self.cross_modal_image_transform(x)
         ct = self.cross_modal_text_pooler(t)
         ci = self.cross_modal_image_pooler(x.mean(1, keepdim=True))
-        return {"text_feats": t, "image_feats": x, "cls_feats": torch.cat([ct, ci], -1)}
+        return {"text_feats": t, "image_feats": x, "cls_feats": torch.cat([ct, ci], -1),
+                "text_labels": batch.get("text_labels" + sfx), "text_ids": ids, "text_masks": masks}
 
 
 def gen_paths(sw, rb, heads):
@@ -291,6 +321,85 @@ def gen_vqa(sw, rb, heads):
         save(name, d)
 
 
+def _reference_functions(path, names):
+    """Compile the named top-level functions / methods straight out of a reference source file (no copy is kept)."""
+    import ast
+    tree = ast.parse(open(path).read())
+    found = {n.name: n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name in names}
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=[found[n] for n in names], type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def gen_itc(sw, rb, heads):
+    """task_pretrain_mlm_itm_itc: the reference's compute_mlm / compute_itc / compute_itm_hardneg and its queue update
+    (`_dequeue_and_enqueue`, `concat_all_gather`, compiled from fiber_module.py) over two consecutive training steps."""
+    import torch.distributed as dist
+    obj = shim._load("objectives", os.path.join(shim.MODS, "objectives.py"), "_fiber_reference_modules")
+    fm = _reference_functions(os.path.join(shim.MODS, "fiber_module.py"), ["concat_all_gather", "_dequeue_and_enqueue"])
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
+    for name, pc in cases.ITC_CASES.items():
+        torch.manual_seed(0)
+        m = RefFused(sw, rb, heads, pc["config"]).train()
+        detgen.fill_(m)
+        with torch.no_grad():
+            m.temp.fill_(0.07)
+            for bn in ("image_queue", "text_queue", "image_input_queue"):
+                getattr(m, bn).copy_(cases.randn("itcq." + bn, tuple(getattr(m, bn).shape)))
+        c = m.c
+        m.hparams = type("H", (), {"config": c})()
+        m.device = torch.device("cpu")
+        m.log = lambda *a, **k: None
+        m._dequeue_and_enqueue = lambda *a: fm["_dequeue_and_enqueue"](m, *a)
+        for ph in ("train", "val"):
+            for t in ("mlm", "itc", "itm"):
+                setattr(m, f"{ph}_{t}_loss", _Metric())
+                setattr(m, f"{ph}_{t}_accuracy", _Metric())
+        d = {}
+        real_multinomial = torch.multinomial
+        for step, seed in enumerate((3, 4)):
+            b = detgen.synth_batch(pc["B"], c["image_size"], c["max_text_len"], c["vocab_size"], seed=seed,
+                                   min_len=min(8, c["max_text_len"] // 2))
+            draws = []
+
+            def recording(w, n, *a, **k):
+                r = real_multinomial(w, n, *a, **k)
+                draws.append(int(r.reshape(-1)[0]))
+                return r
+            torch.manual_seed(100 + step)
+            m.zero_grad(set_to_none=True)
+            mlm = obj.compute_mlm(m, b)
+            torch.multinomial = recording
+            try:
+                ret_itc, image_neg, text_neg, text_mask_neg = obj.compute_itc(m, b)
+            finally:
+                torch.multinomial = real_multinomial
+            itm = obj.compute_itm_hardneg(m, dict(b), image_neg, text_neg, text_mask_neg)
+            B = pc["B"]
+            d[f"s{step}/image_neg_idx"], d[f"s{step}/text_neg_idx"] = np.array(draws[:B]), np.array(draws[B:])
+            for k, v in (("mlm_loss", mlm["mlm_loss"]), ("itc_loss", ret_itc["itc_loss"]), ("itm_loss", itm["itm_loss"])):
+                d[f"s{step}/{k}"] = np.float64(v.item())
+            cases.flatten_summary(f"s{step}/itm_logits", itm["itm_logits"], d)
+            d[f"s{step}/queue_ptr"], d[f"s{step}/queue_total"] = np.int64(int(m.queue_ptr)), np.int64(int(m.queue_total))
+            for bn in ("image_queue", "text_queue", "image_input_queue", "text_input_queue", "text_input_mask_queue"):
+                cases.flatten_summary(f"s{step}/{bn}", getattr(m, bn).float(), d)
+            print(f"  {name} step {step}: mlm {mlm['mlm_loss'].item():.5f} itc {ret_itc['itc_loss'].item():.5f} "
+                  f"itm {itm['itm_loss'].item():.5f}  neg {draws}")
+        (mlm["mlm_loss"] + ret_itc["itc_loss"] + itm["itm_loss"]).backward()
+        unused = []
+        for n, p in m.named_parameters():
+            if p.grad is None:
+                unused.append(n)
+            else:
+                d[f"gradnorm/{n}"] = np.float64(p.grad.double().norm().item())
+        d["unused_params"] = np.array(unused)
+        for n in ("temp", "vit_model.norm.weight", "cross_modal_text_pooler_itc.dense.weight",
+                  "vit_model.layers.3.blocks.1.attn.alpha_i2t", "vit_model.patch_embed.proj.weight"):
+            cases.flatten_summary("grad/" + n, dict(m.named_parameters())[n].grad, d)
+        save(name, d)
+
+
 def gen_adapt():
     """swin_helpers.swin_adapt_position_encoding run on a seeded fake state dict."""
     hp = sys.modules["_fiber_reference_modules.swin_helpers"]
@@ -328,6 +437,8 @@ def main():
         gen_paths(sw, rb, heads)
     if not only or "vqa" in only:
         gen_vqa(sw, rb, heads)
+    if not only or "itc" in only:
+        gen_itc(sw, rb, heads)
     if not only or "adapt" in only:
         gen_adapt()
 

@@ -104,3 +104,52 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(l, name), f"{name} declared in fiber_hip.h but not exported"
     assert declared == set(lib.exported_symbols()), declared ^ set(lib.exported_symbols())
+
+
+def _queue_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from fiber_amd import parallel
+    from fiber_amd.config import make_config
+    from fiber_amd.modules import FIBERTransformerSS
+    from oracle import cases
+    parallel.init_distributed("gloo")
+    cfg = dict(cases.TINY, loss_names={"mlm": 1, "itm": 1, "itc": 1}, itc_queue_size=10, image_size=32)
+    torch.manual_seed(0)
+    m = FIBERTransformerSS(make_config(**cfg))
+    hs, S, B = cfg["hidden_size"], cfg["max_text_len"], 3
+    for step in range(2):                               # 2 steps x 2 ranks x 3 samples = 12 > queue_size 10: wraps
+        g = torch.Generator().manual_seed(10 * step + rank)
+        m._dequeue_and_enqueue(torch.randn(B, hs, generator=g), torch.randn(B, hs, generator=g),
+                               torch.randn(B, 3, 32, 32, generator=g), torch.randint(0, 99, (B, S), generator=g),
+                               torch.randint(0, 2, (B, S), generator=g))
+    state = {k: getattr(m, k).clone() for k in ("image_queue", "text_queue", "image_input_queue", "text_input_queue",
+                                                "text_input_mask_queue", "queue_ptr", "queue_total")}
+    torch.save(state, f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_itc_queue_all_gather_world2(tmp_path):
+    """fiber_module.py:181-222 under 2 ranks: every rank enqueues the all-gathered batch in rank order, so the queues stay
+    identical across ranks; queue_ptr wraps, queue_total keeps counting."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "q")
+    mp.spawn(_queue_worker, args=(2, port, out), nprocs=2, join=True)
+    a, b = torch.load(out + ".0"), torch.load(out + ".1")
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert int(a["queue_ptr"]) == 2 and int(a["queue_total"]) == 12
+    # slot contents: step 0 fills slots 0..5 (rank 0 then rank 1), step 1 fills 6..9 and wraps into 0..1
+    hs, B = 64, 3
+    feats = {}
+    for step in range(2):
+        for rank in range(2):
+            g = torch.Generator().manual_seed(10 * step + rank)
+            feats[(step, rank)] = torch.randn(B, hs, generator=g)
+    assert torch.equal(a["image_queue"][:, 6:9], feats[(1, 0)].T)          # step 1, rank 0 -> slots 6, 7, 8
+    assert torch.equal(a["image_queue"][:, 9], feats[(1, 1)][0])           # step 1, rank 1 -> slots 9, 0, 1
+    assert torch.equal(a["image_queue"][:, 0:2], feats[(1, 1)][1:].T)
+    assert torch.equal(a["image_queue"][:, 2:6], torch.cat([feats[(0, 0)], feats[(0, 1)]])[2:6].T)   # survivors of step 0

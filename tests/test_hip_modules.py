@@ -213,6 +213,67 @@ def test_vqa_finetune_path(name, golden):
             _sub_close("grad " + n, params[n].grad, gold, "grad/" + n, 0.15 if "alpha_" in n else 6e-2)
 
 
+@pytest.mark.parametrize("name", list(cases.ITC_CASES))
+def test_itc_pretrain_steps(name, golden):
+    """task_pretrain_mlm_itm_itc: MLM + ITC against the feature queues + ITM on hard negatives, two
+    consecutive training steps (second one draws negatives from the queue and wraps the queue pointer), against the
+    reference's own compute_itc / compute_itm_hardneg / _dequeue_and_enqueue with the negative draws replayed."""
+    from fiber_amd.config import make_config
+    from fiber_amd.modules import FIBERTransformerSS, fiber_utils
+    pc, gold = cases.ITC_CASES[name], golden(name)
+    ref = detgen.fill_(R.FiberRef(pc["config"]).train())
+    c = ref.config
+    model = FIBERTransformerSS(make_config(**pc["config"])).train()
+    load_from_oracle(model, ref)
+    with torch.no_grad():
+        for bn in ("image_queue", "text_queue", "image_input_queue"):
+            getattr(model, bn).copy_(cases.randn("itcq." + bn, tuple(getattr(model, bn).shape)))
+    model.to(DEV)
+    fiber_utils.set_task(model)
+    assert set(model.current_tasks) == {"mlm", "itm", "itc"}
+    for step, seed in enumerate((3, 4)):
+        b = detgen.synth_batch(pc["B"], c["image_size"], c["max_text_len"], c["vocab_size"], seed=seed,
+                               min_len=min(8, c["max_text_len"] // 2))
+        bd = _to_dev(b)
+        bd["itc_neg_override"] = (gold[f"s{step}/image_neg_idx"], gold[f"s{step}/text_neg_idx"])
+        model.zero_grad(set_to_none=True)
+        out = model(bd)
+        for k, tol in (("mlm_loss", 2e-2), ("itc_loss", 3e-2), ("itm_loss", 2e-2)):
+            g = float(gold[f"s{step}/{k}"])
+            assert abs(out[k].item() - g) < tol * max(1.0, abs(g)), (step, k, out[k].item(), g)
+        _sub_close("itm_logits", out["itm_logits"], gold, f"s{step}/itm_logits", 5e-2)
+        assert int(model.queue_ptr) == int(gold[f"s{step}/queue_ptr"]) and int(model.queue_total) == int(gold[f"s{step}/queue_total"])
+        for bn, tol in (("image_queue", 2e-2), ("text_queue", 2e-2), ("image_input_queue", 1e-6)):
+            _sub_close(bn, getattr(model, bn).float(), gold, f"s{step}/{bn}", tol)
+        for bn in ("text_input_queue", "text_input_mask_queue"):
+            assert np.array_equal(cases.summarize(getattr(model, bn).float())["sub"], gold[f"s{step}/{bn}/sub"])
+    sum(v for k, v in out.items() if "loss" in k).backward()
+    unused_gold = set(gold["unused_params"].tolist())
+    unused_prod = set(model.unused_parameter_names())
+    params = dict(model.named_parameters())
+    bad = []
+    for n, p in params.items():
+        if n.startswith("rank_output."):
+            continue
+        if n in unused_gold:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, f"{n} should get no gradient"
+            assert n in unused_prod, f"{n} missing from unused_parameter_names()"
+        else:
+            assert n not in unused_prod, f"{n} wrongly listed unused"
+            gn = float(gold[f"gradnorm/{n}"])
+            got = p.grad.double().norm().item()
+            if gn < 1e-6:
+                assert got < 1e-2, (n, got)
+                continue
+            if abs(got - gn) > 0.08 * gn + 1e-6:
+                bad.append((n, got, gn))
+    assert len(bad) <= max(2, len(params) // 50), bad[:10]
+    for key in gold:
+        if key.startswith("grad/") and key.endswith("/sub"):
+            n = key[len("grad/"):-len("/sub")]
+            _sub_close("grad " + n, params[n].grad, gold, "grad/" + n, 0.15 if ("alpha_" in n or n == "temp") else 6e-2)
+
+
 def test_training_mode_runs_with_dropout():
     """Training mode with the reference defaults (text dropout 0.1, DropPath linspace(0,0.1)) runs end to end and
     produces finite losses / gradients; two steps with the same seed are bit-identical (counter-based RNG)."""

@@ -162,6 +162,51 @@ def test_vqa_finetune_path(name, golden):
             cases.check_summary("grad/" + n, params[n].grad, gold, 2e-3, 1e-6)
 
 
+def _itc_setup(m):
+    with torch.no_grad():
+        for bn in ("image_queue", "text_queue", "image_input_queue"):
+            getattr(m, bn).copy_(cases.randn("itcq." + bn, tuple(getattr(m, bn).shape)))
+
+
+@pytest.mark.parametrize("name", list(cases.ITC_CASES))
+def test_itc_pretrain_steps(name, golden):
+    """MLM + ITC (feature queues) + hard-negative ITM over two training steps: oracle vs the reference's own
+    compute_itc / compute_itm_hardneg / _dequeue_and_enqueue (negative draws replayed from the fixture)."""
+    pc, gold = cases.ITC_CASES[name], golden(name)
+    m = detgen.fill_(R.FiberRef(pc["config"]).train())
+    _itc_setup(m)
+    c = m.config
+    for step, seed in enumerate((3, 4)):
+        b = detgen.synth_batch(pc["B"], c["image_size"], c["max_text_len"], c["vocab_size"], seed=seed,
+                               min_len=min(8, c["max_text_len"] // 2))
+        m.zero_grad(set_to_none=True)
+        mlm = m.compute_mlm(b)["mlm_loss"]
+        neg = (torch.from_numpy(gold[f"s{step}/image_neg_idx"]), torch.from_numpy(gold[f"s{step}/text_neg_idx"]))
+        out, negs = m.compute_itc(b, neg)
+        m.dequeue_and_enqueue(out["image_cls"], out["text_cls"], b["image"][0], b["text_ids"], b["text_masks"])
+        itm = m.compute_itm_hardneg(b, *negs)
+        for k, v in (("mlm_loss", mlm), ("itc_loss", out["itc_loss"]), ("itm_loss", itm["itm_loss"])):
+            g = float(gold[f"s{step}/{k}"])
+            assert abs(v.item() - g) < 1e-4 * max(1.0, abs(g)), (step, k, v.item(), g)
+        cases.check_summary(f"s{step}/itm_logits", itm["itm_logits"], gold, 1e-4, 1e-5)
+        assert int(m.queue_ptr) == int(gold[f"s{step}/queue_ptr"]) and int(m.queue_total) == int(gold[f"s{step}/queue_total"])
+        for bn in ("image_queue", "text_queue", "image_input_queue", "text_input_queue", "text_input_mask_queue"):
+            cases.check_summary(f"s{step}/{bn}", getattr(m, bn).float(), gold, 1e-4, 1e-5)
+    (mlm + out["itc_loss"] + itm["itm_loss"]).backward()
+    unused = set(gold["unused_params"].tolist())
+    for n, p in m.named_parameters():
+        if n in unused:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, f"{n} should be unused"
+        else:
+            gn = float(gold[f"gradnorm/{n}"])
+            assert abs(p.grad.double().norm().item() - gn) <= 2e-3 * gn + 1e-7, n
+    params = dict(m.named_parameters())
+    for key in gold:
+        if key.startswith("grad/") and key.endswith("/sub"):
+            n = key[len("grad/"):-len("/sub")]
+            cases.check_summary("grad/" + n, params[n].grad, gold, 2e-3, 1e-6)
+
+
 def test_state_dict_keys_match_reference_layout():
     """Key names of the oracle tree follow the reference's checkpoint layout."""
     m = R.FiberRef(cases.SWIN_T)
