@@ -216,8 +216,11 @@ class FIBERTransformerSS(LightningModule):
         # ---- fused branch (fiber_module.py:310-367) ------------------------------------------------------------
         # The text stack below the first fusion block (embeddings + layers 0..5: 20k-row GEMMs, 80-240 tiles for 256 CUs)
         # does not depend on the image stack below it (stages 0-1 and stage-2 blocks 0..13, mostly HBM-bound kernels), so it
-        # is issued on a second HIP stream and joined where the reference first mixes the two; autograd replays every
-        # node on its forward stream, so the two backward halves overlap the same way.
+        # can be issued on a second HIP stream and joined where the reference first mixes the two (autograd replays every
+        # node on its forward stream, so the backward halves overlap the same way).  OFF by default
+        # (config["overlap_text_stream"] / FIBER_OVERLAP=1): the +1.5 % it measured came from library stream-K GEMMs of the
+        # two streams running concurrently, which can deadlock (ops.lib_gemm); with those kept in one order the gain is
+        # within noise.
         num_pre_text = self.num_text_layer - self.num_fuse_block
 
         def text_prefix():
@@ -228,7 +231,7 @@ class FIBERTransformerSS(LightningModule):
             return t, e
 
         side = None
-        if self.config.get("overlap_text_stream", True) and not os.environ.get("FIBER_NO_OVERLAP"):
+        if (self.config.get("overlap_text_stream", False) or os.environ.get("FIBER_OVERLAP")) and not os.environ.get("FIBER_NO_OVERLAP"):
             side = self._text_stream(text_ids)
         if side is not None:
             main = torch.cuda.current_stream(text_ids.device)
@@ -245,7 +248,7 @@ class FIBERTransformerSS(LightningModule):
         # Fusion blocks: image block (reads the text tokens) and text layer (reads the image tokens) of one step are
         # independent of each other (fiber_module.py:327-346 evaluates both from the previous step's pair), so the text layer
         # runs on the second stream next to the much larger image block; two event waits per step keep the pair in lock step.
-        prefix_only = self.config.get("overlap_text_stream", True) == "prefix" or bool(os.environ.get("FIBER_OVERLAP_PREFIX_ONLY"))
+        prefix_only = self.config.get("overlap_text_stream", False) == "prefix" or bool(os.environ.get("FIBER_OVERLAP_PREFIX_ONLY"))
 
         def fused_step(blk, layer, image_embeds, text_embeds, **kw):
             nonlocal side
