@@ -221,6 +221,9 @@ def main():
               file=sys.stderr, flush=True)
     ips = args.batch * world * args.steps / dt
     lossv = loss.item()
+    if rank == 0 and hasattr(opt, "rebuilds"):
+        print(f"[bench] optimizer table rebuilds: {opt.rebuilds} over {args.steps + args.warmup} steps x {len(opt.param_groups)} groups",
+              file=sys.stderr, flush=True)
 
     if rank == 0:
         tf_per_gpu = ips / world * task["flop"] / 1e12

@@ -35,9 +35,11 @@ SIGNATURES = {
     "fiber_fold_rows_f32": [P, P, I, I],
     "fiber_dropout_bf16": [P, P, L, F, U64],
     "fiber_rowscale_add_bf16": [P, P, P, P, L, L],
+    "fiber_adamw_multi_f32": [P, P, P, I, F, F, F, F, F, I],
 }
 # host-side helpers without a stream argument
-PLAIN = {"fiber_layernorm_bwd_grid": [I], "fiber_window_attn_bwd_slices": [I, I], "fiber_colsum_slabs": [I, I], "fiber_gemm_row_tile": [I, I, I]}
+PLAIN = {"fiber_layernorm_bwd_grid": [I], "fiber_window_attn_bwd_slices": [I, I], "fiber_colsum_slabs": [I, I], "fiber_gemm_row_tile": [I, I, I],
+         "fiber_adamw_chunk": []}
 
 _lib = None
 

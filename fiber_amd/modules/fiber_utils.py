@@ -107,16 +107,25 @@ def set_schedule(pl_module):
         gi = param_group_index(n)
         if gi is not None and p.requires_grad:
             groups[gi]["params"].append(p)
+    own = None
     if cfg["optim_type"] == "adamw":
         # transformers 4.6.0 AdamW(correct_bias=True) == decoupled weight decay + bias correction == torch AdamW.
         # (torch's fused=True variant measured no faster here once the bf16 working copies are refreshed every step.)
-        optimizer = torch.optim.AdamW(groups, lr=lr, eps=1e-8, betas=(0.9, 0.98))
+        # On a HIP device: one kernel per parameter group that also rewrites the bf16 working copies (fiber_amd/optim.py);
+        # host tensors (the CPU wiring tests) take torch's implementation of the same rule.
+        import os
+        if any(p.is_cuda for g in groups for p in g["params"]) and not os.environ.get("FIBER_TORCH_ADAMW"):
+            from ..optim import FiberAdamW
+            optimizer = own = FiberAdamW(groups, lr=lr, eps=1e-8, betas=(0.9, 0.98))
+        else:
+            optimizer = torch.optim.AdamW(groups, lr=lr, eps=1e-8, betas=(0.9, 0.98))
     elif cfg["optim_type"] == "adam":
         optimizer = torch.optim.Adam(groups, lr=lr)
     else:
         optimizer = torch.optim.SGD(groups, lr=lr, momentum=0.9)
     from .. import ops
-    optimizer.register_step_post_hook(lambda *a, **k: ops.mark_weights_dirty())   # bf16 working copies follow the update
+    if own is None:
+        optimizer.register_step_post_hook(lambda *a, **k: ops.mark_weights_dirty())   # bf16 working copies follow the update
     tr = getattr(pl_module, "trainer", None)
     max_steps = getattr(tr, "max_steps", None) if tr is not None else None
     if max_steps is None:

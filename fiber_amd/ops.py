@@ -56,6 +56,23 @@ def bf16_weight_t(w):
     return wt
 
 
+def bf16_copy_if_cached(w):
+    """The cached bf16 working copy of `w` (whatever its state), or None -- for the fused optimizer, which rewrites it."""
+    hit = _wcache.get(id(w))
+    return hit[1] if (hit is not None and hit[2] is w) else None
+
+
+def restamp_bf16_copies(params, bump=True):
+    """After an optimizer step that rewrote the plain bf16 copies in place: every other derived cache entry (transposed /
+    permuted copies) is invalidated (`bump`, once per step), the rewritten ones are marked current."""
+    if bump:
+        _gen[0] += 1
+    for w in params:
+        hit = _wcache.get(id(w))
+        if hit is not None and hit[2] is w:
+            _wcache[id(w)] = (_stamp(w), hit[1], w)
+
+
 def cast_bf16(w):
     """Autograd-visible bf16 view of an fp32 parameter for library GEMMs (gradient flows back in fp32)."""
     return w.to(BF16)

@@ -91,6 +91,14 @@ int fiber_fold_rows_f32(const float* part, float* out, int rows, int N, fiber_st
 int fiber_dropout_bf16(const void* x, void* y, long n, float p, uint64_t seed, fiber_stream_t stream);
 int fiber_rowscale_add_bf16(const void* r, const void* x, const float* scale, void* out, long n, long per_sample,
                             fiber_stream_t stream);
+
+/* AdamW step of one parameter group in one launch (caller side of the path: transformers 4.6.0 AdamW(correct_bias=True) as
+ * configured by fiber_utils.set_schedule, fiber_utils.py:248-252), also refreshing the bf16 working copies of the weights.
+ * table: int64[n*5] device pointers (param fp32, grad fp32, exp_avg, exp_avg_sq, bf16 copy or 0); numel: int64[n];
+ * chunks: int32[nchunks*2] (tensor, chunk) pairs of fiber_adamw_chunk() elements; all three in device memory; step >= 1. */
+int fiber_adamw_chunk(void);
+int fiber_adamw_multi_f32(const long long* table, const long long* numel, const int* chunks, int nchunks, float lr,
+                          float weight_decay, float beta1, float beta2, float eps, int step, fiber_stream_t stream);
 #ifdef __cplusplus
 }
 #endif

@@ -338,3 +338,33 @@ def test_elementwise(ops):
     diff = (z.float() - r.float()).view(6, -1)
     ratio = diff.abs().sum(1) / xx.detach().float().view(6, -1).abs().sum(1)
     assert all(abs(v) < 1e-2 or abs(v - 2.0) < 2e-2 for v in ratio.tolist()), ratio
+
+
+def test_adamw_multi_matches_torch(ops):
+    """csrc/optim.hip vs torch.optim.AdamW (= transformers 4.6.0 AdamW(correct_bias=True), fiber_utils.py:248-252): two
+    groups with different lr / weight decay, ragged and unaligned sizes, a scalar parameter, a parameter without a gradient,
+    three steps with a changing lr; the cached bf16 working copy of a weight is rewritten by the same kernel."""
+    from fiber_amd.optim import FiberAdamW
+    shapes = [(768, 512), (4099,), (), (3, 5, 7), (1 << 20,), (17,)]
+    mine = [rnd(*s, seed=i).to(DEV).requires_grad_(True) if s else torch.tensor(0.3, device=DEV, requires_grad=True)
+            for i, s in enumerate(shapes)]
+    ref = [p.detach().clone().requires_grad_(True) for p in mine]
+    wb = ops.bf16_weight(mine[0])                                    # creates the cached working copy
+    groups = lambda ps: [{"params": ps[:3], "weight_decay": 0.01, "lr": 1e-3}, {"params": ps[3:], "weight_decay": 0.0, "lr": 5e-3}]
+    om = FiberAdamW(groups(mine), lr=1e-3, betas=(0.9, 0.98), eps=1e-8)
+    ot = torch.optim.AdamW(groups(ref), lr=1e-3, betas=(0.9, 0.98), eps=1e-8)
+    for step in range(3):
+        for i, (a, b) in enumerate(zip(mine, ref)):
+            if i == 5:
+                continue                                             # never receives a gradient
+            g = rnd(*shapes[i], seed=100 * step + i).to(DEV) if shapes[i] else torch.tensor(0.1 * (step + 1), device=DEV)
+            a.grad, b.grad = g.clone(), g.clone()
+        for o in (om, ot):
+            for gidx, grp in enumerate(o.param_groups):
+                grp["lr"] = (1e-3, 5e-3)[gidx] * (1.0 - 0.2 * step)
+            o.step()
+        for a, b in zip(mine, ref):
+            assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), (step, a.shape, (a - b).abs().max().item())
+        assert ops.bf16_weight(mine[0]) is wb                        # still the same tensor, now holding the new weights
+        assert torch.equal(wb, mine[0].detach().to(BF))
+    assert torch.equal(mine[5], ref[5])
