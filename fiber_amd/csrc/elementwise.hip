@@ -120,6 +120,38 @@ __global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(const bf16* __rest
   if (gc < N) out[(size_t)blockIdx.y * N + gc] = t;
 }
 
+// ds = scale[row / rows_per_sample] * dy (DropPath backward on the branch) with the column sums of ds (bias gradient of the
+// proj / fc2 linear) produced in the same pass: same slab layout as colsum_kernel.
+__global__ __launch_bounds__(256) void rowscale_colsum_kernel(const bf16* __restrict__ x, const float* __restrict__ scale,
+                                                              bf16* __restrict__ y, float* __restrict__ out, int M, int N,
+                                                              int rows_per_block, int rows_per_sample) {
+  __shared__ float red[8][32 * 8 + 1];
+  const int cv = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int col = (blockIdx.x * 32 + cv) * 8;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (col < N) {
+    for (int r = r0 + rl; r < r1; r += 8) {
+      const size_t off = (size_t)r * N + col;
+      const float sc = scale[r / rows_per_sample];
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(x + off);
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { o[e] = f2bf(sc * bf2f(a[e])); s[e] += bf2f(o[e]); }
+      *reinterpret_cast<bf16x8*>(y + off) = o;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rl][cv * 8 + e] = s[e];
+  __syncthreads();
+  const int c = threadIdx.x;
+  float t = 0.f;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) t += red[r][c];
+  const int gc = blockIdx.x * 256 + c;
+  if (gc < N) out[(size_t)blockIdx.y * N + gc] = t;
+}
+
 __global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ part, float* __restrict__ out, int slabs, int N) {
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
@@ -238,6 +270,26 @@ extern "C" int fiber_gelu_bwd_colsum_bf16(const void* dgelu, const void* h_pre, 
   if (gy > 1 && !workspace) return FIBER_EINVAL;
   hipLaunchKernelGGL(gelu_bwd_colsum_kernel, dim3(gx, gy), dim3(256), 0, stream, (const bf16*)dgelu, (const bf16*)h_pre, (bf16*)dh,
                      gy > 1 ? workspace : db, M, N, rpb);
+  FIBER_CHECK_LAUNCH();
+  if (gy > 1) {
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3(cdiv(N, 64)), dim3(256), 0, stream, workspace, db, gy, N);
+    FIBER_CHECK_LAUNCH();
+  }
+  return FIBER_OK;
+}
+
+// y = scale[row / rows_per_sample] * x and db[n] = sum_m y[m,n] in one pass over contiguous [M, N] tensors (N % 8 == 0);
+// workspace as for fiber_gelu_bwd_colsum_bf16.
+extern "C" int fiber_rowscale_colsum_bf16(const void* x, const float* scale, void* y, float* db, float* workspace, int M, int N,
+                                          int rows_per_sample, hipStream_t stream) {
+  if (M <= 0 || N <= 0) return FIBER_OK;
+  if ((N & 7) || rows_per_sample <= 0) return FIBER_EINVAL;
+  const int gx = cdiv(N, 256);
+  const int gy0 = fiber_colsum_slabs(M, N);
+  const int rpb = cdiv(M, gy0), gy = cdiv(M, rpb);
+  if (gy > 1 && !workspace) return FIBER_EINVAL;
+  hipLaunchKernelGGL(rowscale_colsum_kernel, dim3(gx, gy), dim3(256), 0, stream, (const bf16*)x, scale, (bf16*)y,
+                     gy > 1 ? workspace : db, M, N, rpb, rows_per_sample);
   FIBER_CHECK_LAUNCH();
   if (gy > 1) {
     hipLaunchKernelGGL(colsum_fold_kernel, dim3(cdiv(N, 64)), dim3(256), 0, stream, workspace, db, gy, N);

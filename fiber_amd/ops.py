@@ -123,6 +123,18 @@ def gelu_bwd_colsum(dg, h):
     return dh, db
 
 
+def rowscale_colsum(dy2, rowscale):
+    """ds = per-sample scale * dy and its column sums (bias gradient) in one pass."""
+    M, N = dy2.shape
+    ds = torch.empty_like(dy2)
+    db = torch.empty(N, dtype=torch.float32, device=dy2.device)
+    slabs = lib.plain("fiber_colsum_slabs", M, N)
+    ws = torch.empty(slabs * N, dtype=torch.float32, device=dy2.device) if slabs > 1 else None
+    lib.call("fiber_rowscale_colsum_bf16", lib.ptr(dy2), lib.ptr(rowscale), lib.ptr(ds), lib.ptr(db), lib.ptr(ws), M, N,
+             M // rowscale.numel())
+    return ds, db
+
+
 def colsum(x2):
     M, N = x2.shape
     out = torch.empty(N, dtype=torch.float32, device=x2.device)
@@ -241,12 +253,15 @@ class _Linear(torch.autograd.Function):
         x2, weight, pre, rowscale = ctx.saved_tensors
         dy2 = _c(dy).view(-1, weight.shape[0])
         dres = dy if ctx.has_res else None
-        if rowscale is not None:                      # branch gradient = per-sample scale * dy
-            ds = torch.empty_like(dy2)
-            lib.call("fiber_rowscale_add_bf16", None, lib.ptr(dy2), lib.ptr(rowscale), lib.ptr(ds), dy2.numel(),
-                     dy2.numel() // rowscale.numel())
-            dy2 = ds
         db = None
+        if rowscale is not None:                      # branch gradient = per-sample scale * dy
+            if ctx.has_bias and ctx.needs_input_grad[2] and not ctx.act and dy2.shape[1] % 8 == 0:
+                dy2, db = rowscale_colsum(dy2, rowscale)       # ... and the bias gradient from the same pass
+            else:
+                ds = torch.empty_like(dy2)
+                lib.call("fiber_rowscale_add_bf16", None, lib.ptr(dy2), lib.ptr(rowscale), lib.ptr(ds), dy2.numel(),
+                         dy2.numel() // rowscale.numel())
+                dy2 = ds
         if ctx.act:
             dh, db = gelu_bwd_colsum(dy2, pre)
         else:
@@ -299,18 +314,23 @@ class _MLP(torch.autograd.Function):
         x2, w1, w2, h, g, rowscale = ctx.saved_tensors
         dy2 = _c(dy).view(-1, w2.shape[0])
         dres = dy if ctx.has_res else None
+        db2 = None
         if rowscale is not None:
-            ds = torch.empty_like(dy2)
-            lib.call("fiber_rowscale_add_bf16", None, lib.ptr(dy2), lib.ptr(rowscale), lib.ptr(ds), dy2.numel(),
-                     dy2.numel() // rowscale.numel())
-            dy2 = ds
+            if dy2.shape[1] % 8 == 0:
+                dy2, db2 = rowscale_colsum(dy2, rowscale)      # DropPath backward + fc2 bias gradient in one pass
+            else:
+                ds = torch.empty_like(dy2)
+                lib.call("fiber_rowscale_add_bf16", None, lib.ptr(dy2), lib.ptr(rowscale), lib.ptr(ds), dy2.numel(),
+                         dy2.numel() // rowscale.numel())
+                dy2 = ds
         C, C4 = dy2.shape[1], h.shape[1]
         if C % 64 == 0 and C4 % 8 == 0 and _FUSED_MLP_BWD:
             dh, db1 = gemm_nt(dy2, bf16_weight_t(w2), None, None, 2, False, aux=h, want_colsum=True)
         else:                                         # shapes the DMA kernel does not cover (e.g. Swin-T C=96)
             dh, db1 = gelu_bwd_colsum(lib_matmul(dy2, bf16_weight(w2)), h)
         dw2 = wgrad(dy2, g)
-        db2 = colsum(dy2)
+        if db2 is None:
+            db2 = colsum(dy2)
         dx = lib_matmul(dh, bf16_weight(w1)).view(ctx.shp)
         dw1 = wgrad(dh, x2)
         return dx, dw1, db1, dw2, db2, dres, None

@@ -91,6 +91,10 @@ int fiber_fold_rows_f32(const float* part, float* out, int rows, int N, fiber_st
 int fiber_dropout_bf16(const void* x, void* y, long n, float p, uint64_t seed, fiber_stream_t stream);
 int fiber_rowscale_add_bf16(const void* r, const void* x, const float* scale, void* out, long n, long per_sample,
                             fiber_stream_t stream);
+/* y = scale[row / rows_per_sample] * x (DropPath backward, swin_transformer.py:390-391) and db = column sums of y (bias
+ * gradient of the proj / fc2 linear) in one pass; workspace as for fiber_gelu_bwd_colsum_bf16 */
+int fiber_rowscale_colsum_bf16(const void* x, const float* scale, void* y, float* db, float* workspace, int M, int N,
+                               int rows_per_sample, fiber_stream_t stream);
 
 /* AdamW step of one parameter group in one launch (caller side of the path: transformers 4.6.0 AdamW(correct_bias=True) as
  * configured by fiber_utils.set_schedule, fiber_utils.py:248-252), also refreshing the bf16 working copies of the weights.

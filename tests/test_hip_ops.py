@@ -368,3 +368,25 @@ def test_adamw_multi_matches_torch(ops):
         assert ops.bf16_weight(mine[0]) is wb                        # still the same tensor, now holding the new weights
         assert torch.equal(wb, mine[0].detach().to(BF))
     assert torch.equal(mine[5], ref[5])
+
+
+@pytest.mark.parametrize("B,L,K,N", [(3, 1000, 128, 136), (4, 576, 512, 512)])
+def test_linear_droppath_scale_backward(ops, B, L, K, N):
+    """y = shortcut + s_b * (x.W^T + b): the backward computes s_b * dy and the bias gradient in ONE pass
+    (fiber_rowscale_colsum_bf16); checked against autograd on the fp32 formula (timm DropPath, swin_transformer.py:390-391)."""
+    x = bf(rnd(B, L, K)).requires_grad_(True)
+    w = rnd(N, K, std=K ** -0.5).to(DEV).requires_grad_(True)
+    b = rnd(N, seed=1).to(DEV).requires_grad_(True)
+    r = bf(rnd(B, L, N, seed=2)).requires_grad_(True)
+    s = torch.tensor([0.0, 1.25, 1.0, 2.0][:B], device=DEV)
+    y = ops.linear(x, w, b, residual=r, rowscale=s)
+    xr, wr, br, rr = (t.detach().float().requires_grad_(True) for t in (x, w.to(BF), b, r))
+    yr = rr + s.view(B, 1, 1) * (xr @ wr.t() + br)
+    assert_close("y", y, yr, 4e-3)
+    g = bf(rnd(B, L, N, seed=3))
+    y.backward(g)
+    yr.backward(g.float())
+    assert_close("dx", x.grad, xr.grad, 8e-3)
+    assert_close("dw", w.grad, wr.grad, 8e-3)
+    assert_close("db", b.grad, br.grad, 8e-3)
+    assert_close("dres", r.grad, rr.grad, 1e-6)
