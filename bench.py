@@ -13,6 +13,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL across processes)
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -142,6 +144,24 @@ def time_dominant_kernel(B, device):
     return out
 
 
+def time_forward(model, batch, B, device):
+    """fwd ms/img: the fused-backbone forward (`infer`, B image-text pairs, no dropout, no autograd graph) on the batch that
+    was just trained on; HIP events around 5 passes after 2 warm-ups."""
+    was_training = model.training
+    model.eval()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.no_grad():
+        for _ in range(2):
+            model.infer(batch)
+        e0.record()
+        for _ in range(5):
+            model.infer(batch)
+        e1.record()
+    torch.cuda.synchronize(device)
+    model.train(was_training)
+    return e0.elapsed_time(e1) / 5 / B
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -240,6 +260,7 @@ def main():
                          "basis": f"{task['flop'] / 1e9:.1f} GFLOP algorithmic per image per step (BASELINE.md section 3 / SURVEY.md "
                                   "section 8d) / measured step time, per GPU"},
         }
+        res["fwd_ms_per_image"] = round(time_forward(model, batch, args.batch, device), 4)   # BASELINE.json metric, second half
         if args.task == "mlm_itm":
             res["roofline"]["dominant_kernel"] = time_dominant_kernel(args.batch, device)
             res["roofline"]["traffic"] = res["roofline"]["dominant_kernel"]["traffic"]
