@@ -21,6 +21,8 @@
 //   pass A (wave = query strip):  dQ, and in WINDOW mode the relative-position-bias gradient accumulated in registers
 //                                 over the windows a workgroup visits (no atomics; partials folded by a scatter kernel)
 //   pass B (wave = key strip):    dK, dV
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -555,11 +557,20 @@ __global__ __launch_bounds__(256) void dbias_scatter_kernel(const float* __restr
   }
 }
 
-int pick_waves(int nstrips) { return nstrips <= 12 ? nstrips : (nstrips % 9 == 0 ? 9 : 8); }
+// waves (16-row strips) per workgroup.  `staged` = rows of the OTHER operand every workgroup stages into LDS: when that is a
+// short text sequence (i2t cross-attention: 40-50 keys) small workgroups win -- three or four of them share a CU and overlap
+// each other's staging / softmax phases (op_bench, 576 queries x 40 keys: forward 812 -> 543 us) -- while a long staged side
+// (t2i backward: 576 keys per 40 queries) wants few, large workgroups so it is staged fewer times.
+int pick_waves(int nstrips, int staged) {
+  static const int force = getenv("FIBER_ATTN_WAVES") ? atoi(getenv("FIBER_ATTN_WAVES")) : 0;
+  if (force > 0) return nstrips < force ? nstrips : force;
+  if (staged <= 64 && nstrips > 4) return nstrips % 3 == 0 ? 3 : 4;
+  return nstrips <= 12 ? nstrips : (nstrips % 9 == 0 ? 9 : 8);
+}
 
 template <int D>
 int launch_fwd(AttnP& p, hipStream_t st) {
-  const int nstrips = cdiv(p.Lq, 16), nw = pick_waves(nstrips);
+  const int nstrips = cdiv(p.Lq, 16), nw = pick_waves(nstrips, p.Lk);
   const int nb = p.window ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
   const size_t sh = lds_bytes<D>(nb, 1, 1);
   if (p.window) hipLaunchKernelGGL((attn_fwd_kernel<D, true>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), sh, st, p);
@@ -581,7 +592,7 @@ int launch_bwd(AttnP& p, float* delta, float* dbias_table, float* dbias_ws, int 
   p.delta = delta;
   const int nb = p.window ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
   {
-    const int nstrips = cdiv(p.Lq, 16), nw = pick_waves(nstrips);
+    const int nstrips = cdiv(p.Lq, 16), nw = pick_waves(nstrips, p.Lk);
     int gz = p.G;
     p.groups_per_block = 1;
     p.dbias_part = nullptr;
@@ -601,7 +612,7 @@ int launch_bwd(AttnP& p, float* delta, float* dbias_table, float* dbias_ws, int 
     }
   }
   {
-    const int nstrips = cdiv(p.Lk, 16), nw = pick_waves(nstrips);
+    const int nstrips = cdiv(p.Lk, 16), nw = pick_waves(nstrips, 1 << 20);   // key-strip pass: measured worse with small workgroups
     if (p.window) hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, true>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), lds_bytes<D>(nb, 2, 2), st, p);
     else hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, false>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), lds_bytes<D>(nb, 2, 2), st, p);
     FIBER_CHECK_LAUNCH();
