@@ -169,6 +169,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("FIBER_BENCH_BATCH", "256")), help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the forward-only and dominant-kernel timings (clean rocprof runs)")
     ap.add_argument("--task", choices=sorted(TASKS), default="mlm_itm",
                     help="default = BASELINE.json's metric; the others are extra configurations of the same path")
     args = ap.parse_args()
@@ -260,8 +261,9 @@ def main():
                          "basis": f"{task['flop'] / 1e9:.1f} GFLOP algorithmic per image per step (BASELINE.md section 3 / SURVEY.md "
                                   "section 8d) / measured step time, per GPU"},
         }
-        res["fwd_ms_per_image"] = round(time_forward(model, batch, args.batch, device), 4)   # BASELINE.json metric, second half
-        if args.task == "mlm_itm":
+        if not args.no_extras:
+            res["fwd_ms_per_image"] = round(time_forward(model, batch, args.batch, device), 4)   # BASELINE.json metric, second half
+        if args.task == "mlm_itm" and not args.no_extras:
             res["roofline"]["dominant_kernel"] = time_dominant_kernel(args.batch, device)
             res["roofline"]["traffic"] = res["roofline"]["dominant_kernel"]["traffic"]
         if world == 1 and not args.no_cpu_baseline and args.task == "mlm_itm":
