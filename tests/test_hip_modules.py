@@ -274,6 +274,28 @@ def test_itc_pretrain_steps(name, golden):
             _sub_close("grad " + n, params[n].grad, gold, "grad/" + n, 0.15 if ("alpha_" in n or n == "temp") else 6e-2)
 
 
+def test_fully_padded_text_row_matches_oracle():
+    """A text row whose attention mask is all zeros (what the hard-negative draw returns while the ITC text queue is still
+    empty, objectives.py:143-166): every key of that row carries the -10000 mask, softmax degenerates to uniform weights;
+    the kernels must reproduce that (finite, equal to the fp32 oracle) in text self-attention and in i2t cross-attention."""
+    from fiber_amd.config import make_config
+    from fiber_amd.modules import FIBERTransformerSS
+    ref = detgen.fill_(R.FiberRef(cases.TINY).eval())
+    c = ref.config
+    model = FIBERTransformerSS(make_config(**cases.TINY)).eval()
+    load_from_oracle(model, ref)
+    model.to(DEV)
+    b = detgen.synth_batch(3, c["image_size"], c["max_text_len"], c["vocab_size"], seed=5, min_len=4)
+    b["text_masks"][1] = 0
+    b["text_ids"][1] = 0
+    with torch.no_grad():
+        want = ref.infer(b)
+        got = model.infer(_to_dev(b))
+    for k in ("text_feats", "image_feats", "cls_feats"):
+        assert torch.isfinite(got[k].float()).all(), k
+        assert_close(k, got[k], want[k], 2.5e-2)
+
+
 def test_training_mode_runs_with_dropout():
     """Training mode with the reference defaults (text dropout 0.1, DropPath linspace(0,0.1)) runs end to end and
     produces finite losses / gradients; two steps with the same seed are bit-identical (counter-based RNG)."""
