@@ -122,7 +122,7 @@ __device__ __forceinline__ void setup(const WinP& p, const Smem& S, int h, int n
 }
 
 // ================================================================ forward =====================================
-template <int MAXC>   // 16-byte staging chunks per thread (4*N chunks over 64*waves threads)
+template <int MAXC, int NTC = 0>   // MAXC: 16-byte staging chunks per thread; NTC: key/query tiles if known at compile time (9 for 12x12 windows)
 __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_fwd_kernel(WinP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nb = (2 * p.ws - 1) * (2 * p.ws - 1);
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_fwd_kernel(WinP p) 
   const int gq = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y, C = p.C, ld = 3 * C;
   const int qo = p.hmajor ? h * 96 : h * 32, ko = p.hmajor ? h * 96 + 32 : C + h * 32, vo = p.hmajor ? h * 96 + 64 : 2 * C + h * 32;
-  const int ntile = (p.N + 15) >> 4;
+  const int ntile = NTC ? NTC : (p.N + 15) >> 4;      // compile-time for the 12x12 window: guards fold, the 10th tile's code disappears
   setup(p, S, h, nb, 1, 1);
 
   // this thread's staging chunks: chunk id = tid + c*blockDim -> (row = id>>2 of the window, 16-byte piece id&3)
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_fwd_kernel(WinP p) 
 }
 
 // ================================================================ backward pass A: dQ + dbias =================
-template <int MAXC>   // 16-byte staging chunks per thread (4*N chunks over 64*waves threads)
+template <int MAXC, int NTC = 0>   // MAXC: 16-byte staging chunks per thread; NTC: key/query tiles if known at compile time (9 for 12x12 windows)
 __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dq_kernel(WinP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nb = (2 * p.ws - 1) * (2 * p.ws - 1);
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dq_kernel(WinP 
   const int gq = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y, C = p.C, ld = 3 * C;
   const int qo = p.hmajor ? h * 96 : h * 32, ko = p.hmajor ? h * 96 + 32 : C + h * 32, vo = p.hmajor ? h * 96 + 64 : 2 * C + h * 32;
-  const int ntile = (p.N + 15) >> 4;
+  const int ntile = NTC ? NTC : (p.N + 15) >> 4;      // compile-time for the 12x12 window: guards fold, the 10th tile's code disappears
   setup(p, S, h, nb, 2, 1);
   int spr[MAXC], spc[MAXC];
   bool sval[MAXC];
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dq_kernel(WinP 
 }
 
 // ================================================================ backward pass B: dK, dV ======================
-template <int MAXC>   // 16-byte staging chunks per thread (4*N chunks over 64*waves threads)
+template <int MAXC, int NTC = 0>   // MAXC: 16-byte staging chunks per thread; NTC: key/query tiles if known at compile time (9 for 12x12 windows)
 __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dkv_kernel(WinP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nb = (2 * p.ws - 1) * (2 * p.ws - 1);
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dkv_kernel(WinP
   const int gq = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y, C = p.C, ld = 3 * C;
   const int qo = p.hmajor ? h * 96 : h * 32, ko = p.hmajor ? h * 96 + 32 : C + h * 32, vo = p.hmajor ? h * 96 + 64 : 2 * C + h * 32;
-  const int ntile = (p.N + 15) >> 4;
+  const int ntile = NTC ? NTC : (p.N + 15) >> 4;      // compile-time for the 12x12 window: guards fold, the 10th tile's code disappears
   setup(p, S, h, nb, 2, 2);
   int spr[MAXC], spc[MAXC];
   bool sval[MAXC];
@@ -602,9 +602,12 @@ bool attrs_set = false;
 void ensure_attrs() {
   if (attrs_set) return;
   const int big = 160 * 1024;
-  hipFuncSetAttribute((const void*)win_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  hipFuncSetAttribute((const void*)win_bwd_dq_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  hipFuncSetAttribute((const void*)win_bwd_dkv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)win_fwd_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)win_bwd_dq_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)win_bwd_dkv_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)win_fwd_kernel<1, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)win_bwd_dq_kernel<1, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)win_bwd_dkv_kernel<1, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   attrs_set = true;
 }
 
@@ -615,6 +618,14 @@ void strip_geometry(int N, int& nw, int& sg) {
   // (MAXC = 1).  A split into <=4-wave strip groups (MAXC = 3, several workgroups per CU) measured no faster.
   nw = cdiv(N, 16);
   sg = 1;
+}
+
+// which kernels use the compile-time tile count for 12x12 windows (bit 0 forward, 1 dQ pass, 2 dK/dV pass).  Measured at
+// 512 images, stage 0 (tools/op_bench.py 512 attn): forward 1828 -> 1542 us; backward 7441 us with neither pass, 8837 with the
+// dQ pass on it (that kernel already sits at the 168-VGPR cap and spills more), 7301 with the dK/dV pass -> forward + dK/dV.
+int ntc_mask() {
+  static const int m = getenv("FIBER_WIN_NTC") ? atoi(getenv("FIBER_WIN_NTC")) : 5;
+  return m;
 }
 
 int blocks_for(int G, int heads) {
@@ -649,7 +660,8 @@ int fiber_win_fwd_launch(const void* qkv, const float* bias_table, void* o, floa
   const int nb = (2 * ws - 1) * (2 * ws - 1);
   int nw, sg;
   strip_geometry(p.N, nw, sg);
-  hipLaunchKernelGGL(win_fwd_kernel<1>, dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes(nb, 1, 1), st, p);
+  if (p.N == 144 && (ntc_mask() & 1)) hipLaunchKernelGGL((win_fwd_kernel<1, 9>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes(nb, 1, 1), st, p);
+  else hipLaunchKernelGGL((win_fwd_kernel<1, 0>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes(nb, 1, 1), st, p);
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }
@@ -674,12 +686,14 @@ int fiber_win_bwd_launch(const void* qkv, const float* bias_table, const void* o
   hipLaunchKernelGGL(win_delta_kernel, dim3((int)(g > 4096 ? 4096 : g)), dim3(256), 0, st, (const bf16*)o, (const bf16*)dout, delta_ws, nvec, heads);
   FIBER_CHECK_LAUNCH();
   const int gz = cdiv(p.G, p.gpb);
-  hipLaunchKernelGGL(win_bwd_dq_kernel<1>, dim3(gz, heads, sg), dim3(64 * nw), smem_bytes(nb, 2, 1), st, p);
+  if (p.N == 144 && (ntc_mask() & 2)) hipLaunchKernelGGL((win_bwd_dq_kernel<1, 9>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes(nb, 2, 1), st, p);
+  else hipLaunchKernelGGL((win_bwd_dq_kernel<1, 0>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes(nb, 2, 1), st, p);
   FIBER_CHECK_LAUNCH();
   if (hipMemsetAsync(dbias_table, 0, (size_t)nb * heads * sizeof(float), st) != hipSuccess) return FIBER_ELAUNCH;
   hipLaunchKernelGGL(win_dbias_scatter_kernel, dim3(p.N, heads), dim3(256), 0, st, dbias_ws, dbias_table, gz, heads, ws);
   FIBER_CHECK_LAUNCH();
-  hipLaunchKernelGGL(win_bwd_dkv_kernel<1>, dim3(gz, heads, sg), dim3(64 * nw), smem_bytes(nb, 2, 2), st, p);
+  if (p.N == 144 && (ntc_mask() & 4)) hipLaunchKernelGGL((win_bwd_dkv_kernel<1, 9>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes(nb, 2, 2), st, p);
+  else hipLaunchKernelGGL((win_bwd_dkv_kernel<1, 0>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes(nb, 2, 2), st, p);
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }
