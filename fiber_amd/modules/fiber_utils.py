@@ -128,6 +128,9 @@ def set_schedule(pl_module):
         optimizer.register_step_post_hook(lambda *a, **k: ops.mark_weights_dirty())   # bf16 working copies follow the update
     tr = getattr(pl_module, "trainer", None)
     max_steps = getattr(tr, "max_steps", None) if tr is not None else None
+    if max_steps is None and tr is not None and getattr(tr, "datamodule", None) is not None and getattr(tr, "max_epochs", None):
+        # epoch-bounded runs (fine-tuning configs set max_steps=None): fiber_utils.py:254-259
+        max_steps = (len(tr.datamodule.train_dataloader()) * tr.max_epochs // getattr(tr, "accumulate_grad_batches", 1))
     if max_steps is None:
         max_steps = cfg["max_steps"]
     warmup = cfg["warmup_steps"]

@@ -400,6 +400,45 @@ def gen_itc(sw, rb, heads):
         save(name, d)
 
 
+def gen_schedule():
+    """G8: the reference's set_schedule (compiled out of fiber_utils.py) on a module with the FIBER parameter names: which
+    parameter lands in which optimizer group, group lr / weight decay, and the LambdaLR factors over a short run -- for the
+    step-bounded pre-training config and the epoch-bounded (max_steps=None) fine-tuning config."""
+    import types
+    from transformers.optimization import get_cosine_schedule_with_warmup, get_polynomial_decay_schedule_with_warmup
+    from .fiber_ref import FiberRef
+    fn = _reference_functions(os.path.join(shim.MODS, "fiber_utils.py"), ["set_schedule"])
+    ns = fn["set_schedule"].__globals__
+    ns.update(AdamW=torch.optim.AdamW, get_cosine_schedule_with_warmup=get_cosine_schedule_with_warmup,
+              get_polynomial_decay_schedule_with_warmup=get_polynomial_decay_schedule_with_warmup)
+    d = {}
+    for tag, over, trainer in (
+            ("pretrain", dict(loss_names={"mlm": 1, "itm": 1}, learning_rate=1e-5, lr_mult_head=5, lr_mult_cross_modal=5,
+                              warmup_steps=0.1), dict(max_steps=200, max_epochs=None, accumulate_grad_batches=1, n_batches=0)),
+            ("vqa", dict(loss_names={"vqa": 1}, learning_rate=2e-5, lr_mult_head=50, lr_mult_cross_modal=5, warmup_steps=0.1,
+                         vqav2_label_size=17), dict(max_steps=None, max_epochs=10, accumulate_grad_batches=2, n_batches=37))):
+        cfg = dict(cases.TINY, weight_decay=0.01, end_lr=0, decay_power=1, optim_type="adamw", **over)
+        m = FiberRef(cfg)
+        m.hparams = types.SimpleNamespace(config=cfg)
+        dl = list(range(trainer["n_batches"]))
+        m.trainer = types.SimpleNamespace(max_steps=trainer["max_steps"], max_epochs=trainer["max_epochs"],
+                                          accumulate_grad_batches=trainer["accumulate_grad_batches"],
+                                          datamodule=types.SimpleNamespace(train_dataloader=lambda dl=dl: dl))
+        (opt,), (sch,) = fn["set_schedule"](m)
+        names = {id(p): n for n, p in m.named_parameters()}
+        for gi, g in enumerate(opt.param_groups):
+            d[f"{tag}/group{gi}/names"] = np.array(sorted(names[id(p)] for p in g["params"]))
+            d[f"{tag}/group{gi}/lr"], d[f"{tag}/group{gi}/wd"] = np.float64(g["initial_lr"]), np.float64(g["weight_decay"])
+        lrs = []
+        for _ in range(60):
+            lrs.append([g["lr"] for g in opt.param_groups])
+            opt.step()
+            sch["scheduler"].step()
+        d[f"{tag}/lrs"] = np.array(lrs)
+        d[f"{tag}/all_names"] = np.array(sorted(n for n, _ in m.named_parameters()))
+    save("schedule", d)
+
+
 def gen_adapt():
     """swin_helpers.swin_adapt_position_encoding run on a seeded fake state dict."""
     hp = sys.modules["_fiber_reference_modules.swin_helpers"]
@@ -439,6 +478,8 @@ def main():
         gen_vqa(sw, rb, heads)
     if not only or "itc" in only:
         gen_itc(sw, rb, heads)
+    if not only or "schedule" in only:
+        gen_schedule()
     if not only or "adapt" in only:
         gen_adapt()
 

@@ -65,3 +65,41 @@ def test_param_group_rules():
     assert g("vit_model.layers.3.blocks.0.attn.norm_i2t_i.weight") == 4
     # "bias" is a substring of relative_position_bias_table -> the reference puts it in the no-decay group
     assert g("vit_model.layers.0.blocks.0.attn.relative_position_bias_table") == 1
+
+
+def test_set_schedule_matches_reference_groups_and_lr(golden):
+    """G8: optimizer group membership, group lr / weight decay and the per-step learning rates of
+    fiber_utils.set_schedule against the reference's own set_schedule (run by oracle/gen_golden.py) -- for the step-bounded
+    pre-training config and the epoch-bounded fine-tuning config (max_steps=None -> dataloader length x epochs // accumulation)."""
+    import types
+    import numpy as np
+    import torch
+    from fiber_amd.config import make_config
+    from fiber_amd.modules import FIBERTransformerSS, fiber_utils
+    from oracle import cases
+    gold = golden("schedule")
+    for tag, over, trainer in (
+            ("pretrain", dict(loss_names={"mlm": 1, "itm": 1}, learning_rate=1e-5, lr_mult_head=5, lr_mult_cross_modal=5,
+                              warmup_steps=0.1), dict(max_steps=200, max_epochs=None, accumulate_grad_batches=1, n_batches=0)),
+            ("vqa", dict(loss_names={"vqa": 1}, learning_rate=2e-5, lr_mult_head=50, lr_mult_cross_modal=5, warmup_steps=0.1,
+                         vqav2_label_size=17), dict(max_steps=None, max_epochs=10, accumulate_grad_batches=2, n_batches=37))):
+        cfg = make_config(**dict(cases.TINY, weight_decay=0.01, end_lr=0, decay_power=1, optim_type="adamw", **over))
+        m = FIBERTransformerSS(cfg)
+        assert sorted(n for n, _ in m.named_parameters()) == gold[f"{tag}/all_names"].tolist()
+        dl = list(range(trainer["n_batches"]))
+        m.trainer = types.SimpleNamespace(max_steps=trainer["max_steps"], max_epochs=trainer["max_epochs"],
+                                          accumulate_grad_batches=trainer["accumulate_grad_batches"],
+                                          datamodule=types.SimpleNamespace(train_dataloader=lambda dl=dl: dl))
+        (opt,), (sch,) = fiber_utils.set_schedule(m)
+        names = {id(p): n for n, p in m.named_parameters()}
+        assert len(opt.param_groups) == 6
+        for gi, g in enumerate(opt.param_groups):
+            assert sorted(names[id(p)] for p in g["params"]) == gold[f"{tag}/group{gi}/names"].tolist(), (tag, gi)
+            assert abs(g["initial_lr"] - float(gold[f"{tag}/group{gi}/lr"])) < 1e-12
+            assert g["weight_decay"] == float(gold[f"{tag}/group{gi}/wd"])
+        want = gold[f"{tag}/lrs"]
+        for step in range(want.shape[0]):
+            got = np.array([g["lr"] for g in opt.param_groups])
+            np.testing.assert_allclose(got, want[step], rtol=1e-9, atol=1e-15, err_msg=f"{tag} step {step}")
+            opt.step()
+            sch["scheduler"].step()
