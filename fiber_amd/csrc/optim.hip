@@ -36,13 +36,15 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamArgs a) {
   bf16* w = reinterpret_cast<bf16*>(a.table[5 * t + 4]);
   const long long n = a.numel[t];
   const long long lo = (long long)c * CHUNK, hi = lo + CHUNK < n ? lo + CHUNK : n;
-  const bool vec = (((a.table[5 * t + 0] | a.table[5 * t + 1] | a.table[5 * t + 2] | a.table[5 * t + 3]) & 15) == 0) &&
-                   ((a.table[5 * t + 4] & 7) == 0);
+  // parameters / moments / bf16 copies are separate allocations (aligned); gradients may be views into DDP's flat buckets
+  // (gradient_as_bucket_view) and then start at any multiple of 4 bytes: they are read with four scalar loads in that case
+  const bool vec = (((a.table[5 * t + 0] | a.table[5 * t + 2] | a.table[5 * t + 3]) & 15) == 0) && ((a.table[5 * t + 4] & 7) == 0);
+  const bool gvec = (a.table[5 * t + 1] & 15) == 0;
   long long i = lo + threadIdx.x * 4;
   if (vec) {
     for (; i + 3 < hi; i += 1024) {
       float4 pp = *reinterpret_cast<float4*>(p + i);
-      const float4 gg = *reinterpret_cast<const float4*>(g + i);
+      const float4 gg = gvec ? *reinterpret_cast<const float4*>(g + i) : float4{g[i], g[i + 1], g[i + 2], g[i + 3]};
       float4 mm = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
       adam1(pp.x, gg.x, mm.x, vv.x, a); adam1(pp.y, gg.y, mm.y, vv.y, a);
       adam1(pp.z, gg.z, mm.z, vv.z, a); adam1(pp.w, gg.w, mm.w, vv.w, a);

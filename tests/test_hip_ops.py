@@ -370,6 +370,28 @@ def test_adamw_multi_matches_torch(ops):
     assert torch.equal(mine[5], ref[5])
 
 
+def test_adamw_multi_bucket_view_gradients(ops):
+    """Gradients that are views into one flat buffer at 4-byte (not 16-byte) aligned offsets -- what DDP's
+    gradient_as_bucket_view hands the optimizer after a 1-element parameter (alpha_i2t / alpha_t2i) sits in the bucket."""
+    from fiber_amd.optim import FiberAdamW
+    sizes = [1, 4096 + 8, 1, 333, 2048]
+    flat = rnd(sum(sizes) + 3, seed=9).to(DEV)
+    mine = [rnd(n, seed=20 + i).to(DEV).requires_grad_(True) for i, n in enumerate(sizes)]
+    ref = [p.detach().clone().requires_grad_(True) for p in mine]
+    off = 3                                                  # first view starts 12 bytes into the buffer
+    for a, b, n in zip(mine, ref, sizes):
+        a.grad = flat[off:off + n]
+        b.grad = flat[off:off + n].clone()
+        off += n
+    om = FiberAdamW(mine, lr=1e-2, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01)
+    ot = torch.optim.AdamW(ref, lr=1e-2, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01)
+    for _ in range(2):
+        om.step()
+        ot.step()
+    for a, b in zip(mine, ref):
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), (a.shape, (a - b).abs().max().item())
+
+
 @pytest.mark.parametrize("B,L,K,N", [(3, 1000, 128, 136), (4, 576, 512, 512)])
 def test_linear_droppath_scale_backward(ops, B, L, K, N):
     """y = shortcut + s_b * (x.W^T + b): the backward computes s_b * dy and the bias gradient in ONE pass
