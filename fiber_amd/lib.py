@@ -36,6 +36,8 @@ SIGNATURES = {
     "fiber_dropout_bf16": [P, P, L, F, U64],
     "fiber_rowscale_add_bf16": [P, P, P, P, L, L],
     "fiber_rowscale_colsum_bf16": [P, P, P, P, P, I, I, I],
+    "fiber_ce_fwd_bf16": [P, P, P, P, I, I, L],
+    "fiber_ce_bwd_bf16": [P, P, P, P, P, I, I, L],
     "fiber_adamw_multi_f32": [P, P, P, I, F, F, F, F, F, I],
 }
 # host-side helpers without a stream argument

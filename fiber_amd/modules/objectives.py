@@ -7,12 +7,16 @@ import torch.nn.functional as F
 from .. import ops
 
 
+def _mlm_ce(logits, labels):
+    """F.cross_entropy(logits, labels, ignore_index=-100) (objectives.py:24-28) on the HIP kernel for bf16 device logits."""
+    return ops.cross_entropy(logits.to(torch.bfloat16), labels, -100)
+
+
 def compute_mlm(pl_module, batch):
     infer = pl_module.infer(batch, mask_text=True, mask_image=False)
     mlm_logits = pl_module.mlm_score(infer["text_feats"])
     mlm_labels = infer["text_labels"]
-    mlm_loss = F.cross_entropy(
-        mlm_logits.view(-1, pl_module.hparams.config["vocab_size"]).float(), mlm_labels.view(-1), ignore_index=-100)
+    mlm_loss = _mlm_ce(mlm_logits.view(-1, pl_module.hparams.config["vocab_size"]), mlm_labels.view(-1))
     ret = {"mlm_loss": mlm_loss, "mlm_logits": mlm_logits, "mlm_labels": mlm_labels, "mlm_ids": infer["text_ids"]}
     phase = "train" if pl_module.training else "val"
     loss = getattr(pl_module, f"{phase}_mlm_loss")(ret["mlm_loss"])
@@ -71,8 +75,7 @@ def compute_mlm_itm_fused(pl_module, batch, itm_labels=None):
     infer = pl_module.infer(fused, mask_text=False, mask_image=False)
     mlm_logits = pl_module.mlm_score(infer["text_feats"][:B])
     mlm_labels = batch["text_labels_mlm"]
-    mlm_loss = F.cross_entropy(mlm_logits.view(-1, pl_module.hparams.config["vocab_size"]).float(), mlm_labels.view(-1),
-                               ignore_index=-100)
+    mlm_loss = _mlm_ce(mlm_logits.view(-1, pl_module.hparams.config["vocab_size"]), mlm_labels.view(-1))
     itm_logits = pl_module.itm_score(infer["cls_feats"][B:])
     itm_loss = F.cross_entropy(itm_logits, itm_labels.long())
     ret = {"mlm_loss": mlm_loss, "mlm_logits": mlm_logits, "mlm_labels": mlm_labels, "mlm_ids": batch["text_ids_mlm"],

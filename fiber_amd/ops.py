@@ -205,6 +205,39 @@ class _LibLinear(torch.autograd.Function):
         return dx, dw, db
 
 
+class _CrossEntropy(torch.autograd.Function):
+    """mean over the non-ignored rows of logsumexp(x) - x[label] for bf16 logits [rows, V] (F.cross_entropy semantics with
+    ignore_index), forward and backward on csrc/loss.hip: no fp32 copy of the logits, no log-softmax tensor."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index):
+        rows, V = logits.shape
+        x = logits if logits.is_contiguous() else logits.contiguous()
+        lab = labels.contiguous()
+        loss = torch.empty(rows, dtype=torch.float32, device=x.device)
+        lse = torch.empty_like(loss)
+        lib.call("fiber_ce_fwd_bf16", lib.ptr(x), lib.ptr(lab), lib.ptr(loss), lib.ptr(lse), rows, V, int(ignore_index))
+        nvalid = (lab != ignore_index).sum().clamp(min=1).float()
+        ctx.save_for_backward(x, lab, lse, nvalid)
+        ctx.ignore = int(ignore_index)
+        return loss.sum() / nvalid
+
+    @staticmethod
+    def backward(ctx, g):
+        x, lab, lse, nvalid = ctx.saved_tensors
+        scale = (g.float() / nvalid).reshape(1).contiguous()
+        dx = torch.empty_like(x)
+        lib.call("fiber_ce_bwd_bf16", lib.ptr(x), lib.ptr(lab), lib.ptr(lse), lib.ptr(scale), lib.ptr(dx), x.shape[0], x.shape[1],
+                 ctx.ignore)
+        return dx, None, None
+
+
+def cross_entropy(logits, labels, ignore_index=-100):
+    """F.cross_entropy(logits.float(), labels, ignore_index=...) for bf16 logits [rows, V] (mean over valid rows)."""
+    assert logits.dtype == BF16 and logits.dim() == 2 and labels.dtype == torch.int64
+    return _CrossEntropy.apply(logits, labels, ignore_index)
+
+
 def lib_linear(x, w, b=None):
     return _LibLinear.apply(x, w, b)
 

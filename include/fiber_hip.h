@@ -96,6 +96,14 @@ int fiber_rowscale_add_bf16(const void* r, const void* x, const float* scale, vo
 int fiber_rowscale_colsum_bf16(const void* x, const float* scale, void* y, float* db, float* workspace, int M, int N,
                                int rows_per_sample, fiber_stream_t stream);
 
+/* Cross-entropy over the vocabulary for bf16 logits (caller side: compute_mlm's F.cross_entropy(..., ignore_index=-100),
+ * objectives.py:24-28).  fwd: loss[r] = logsumexp(x[r,:]) - x[r, labels[r]] (0 on ignored rows), lse saved; bwd: dlogits =
+ * (softmax - onehot) * scale[0] with scale a device scalar (upstream gradient / number of valid rows). */
+int fiber_ce_fwd_bf16(const void* logits, const long long* labels, float* loss, float* lse, int rows, int V,
+                      long long ignore_index, fiber_stream_t stream);
+int fiber_ce_bwd_bf16(const void* logits, const long long* labels, const float* lse, const float* scale, void* dlogits, int rows,
+                      int V, long long ignore_index, fiber_stream_t stream);
+
 /* AdamW step of one parameter group in one launch (caller side of the path: transformers 4.6.0 AdamW(correct_bias=True) as
  * configured by fiber_utils.set_schedule, fiber_utils.py:248-252), also refreshing the bf16 working copies of the weights.
  * table: int64[n*5] device pointers (param fp32, grad fp32, exp_avg, exp_avg_sq, bf16 copy or 0); numel: int64[n];

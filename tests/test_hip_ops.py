@@ -412,3 +412,22 @@ def test_linear_droppath_scale_backward(ops, B, L, K, N):
     assert_close("dw", w.grad, wr.grad, 8e-3)
     assert_close("db", b.grad, br.grad, 8e-3)
     assert_close("dres", r.grad, rr.grad, 1e-6)
+
+
+@pytest.mark.parametrize("rows,V", [(37, 50265), (256, 1000), (5, 17)])
+def test_cross_entropy_bf16(ops, rows, V):
+    """csrc/loss.hip vs F.cross_entropy(logits.float(), labels, ignore_index=-100) (objectives.py:24-28): odd vocabulary size
+    (rows start at unaligned addresses), mostly ignored rows as in MLM, one all-ignored edge (handled by the clamp)."""
+    x = bf(rnd(rows, V, seed=1) * 3).requires_grad_(True)
+    lab = torch.randint(0, V, (rows,), generator=torch.Generator().manual_seed(0))
+    lab[torch.rand(rows, generator=torch.Generator().manual_seed(1)) < 0.7] = -100
+    lab[0] = V - 1
+    lab = lab.to(DEV)
+    loss = ops.cross_entropy(x, lab)
+    xr = x.detach().float().requires_grad_(True)
+    want = F.cross_entropy(xr, lab, ignore_index=-100)
+    assert abs(loss.item() - want.item()) < 2e-5 * max(1.0, abs(want.item())), (loss.item(), want.item())
+    (loss * 1.7).backward()
+    (want * 1.7).backward()
+    assert_close("dlogits", x.grad, xr.grad, 6e-3)
+    assert float(x.grad[lab == -100].abs().max()) == 0.0
