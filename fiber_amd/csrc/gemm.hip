@@ -7,14 +7,21 @@
 // swin_transformer.py:325; roberta.py:231-241,337,398,415 query/key/value/dense layers; PatchMerging.reduction
 // swin_transformer.py:431; fiber_module.py:349-350 cross-modal transforms).
 //
-// Design (CDNA4): 256-thread workgroups (4 waves, 2x2), block tile BMxBNx64, per-wave (BM/2)x(BN/2) built from
-// v_mfma_f32_32x32x16_bf16 tiles.  Operands are staged global -> VGPR (16 B/lane, coalesced 128-B rows) -> LDS with a
-// 16-byte-chunk XOR swizzle (chunk ^= (row>>1)&7) that makes both the ds_write_b128 staging stores and the
-// ds_read_b128 fragment loads bank-conflict free (LDS bank row = 256 B = two 128-B tile rows).  LDS is double
-// buffered: loads for tile t+1 are issued before the MFMAs of tile t and written after them, one barrier per K tile.
-// The MFMA is issued with swapped operands (D^T = W.X^T) so each lane owns 4 consecutive output columns and the
-// epilogue (bias, exact-erf GELU, residual, optional pre-activation copy) reads/writes 8-byte vectors.
-// Workgroup ids are remapped so that consecutive tiles of one X row-panel land on the same XCD (shared L2).
+// Kernel family (CDNA4, all NT = both operands K-contiguous, v_mfma_f32_32x32x16_bf16 issued with swapped operands so each
+// lane owns 4 consecutive output columns):
+//   gemm_nt_wide_persist_kernel  256x256 tile, 8 waves, two 64-KB LDS-DMA stages, two wave groups half a sub-tile apart,
+//                                persistent over output tiles (>= 512 tiles, N % 256 == 0)          <- the large shapes
+//   gemm_nt_wide_kernel          the same K loop, one tile per workgroup (200..511 tiles)
+//   gemm_nt_glds_kernel          256x128 (3-stage ring, counted vmcnt) / 128x128 / 64x64 tiles for N not a multiple of 256 or
+//                                few tiles (stage-0 qkv / proj, text layers at small batch, edge configs)
+//   gemm_nt_kernel               register-staged fallback for K % 64 != 0 (patch embedding K = 48 -> 64 padded is DMA-able;
+//                                this covers odd test shapes)
+// Operands go global -> LDS by global_load_lds_dwordx4 with a 16-byte-chunk XOR swizzle (chunk ^= (row>>1)&7) applied on the
+// per-lane SOURCE address (the DMA writes lane-linear) and on the ds_read_b128 side: conflict-free for both (LDS bank row =
+// 256 B = two 128-B tile rows).  Every epilogue (bias, exact-erf GELU + pre-activation copy, DropPath row scale, residual,
+// gelu' * aux + column sums) is a compile-time variant of tile_epilogue<>, staged through LDS so that global stores and
+// residual loads are 16-byte row-contiguous.  Workgroup ids are remapped so that consecutive tiles of one X row panel land on
+// the same XCD (shared L2).  Measurements behind each choice: profiles/r01_summary.md.
 #include <stdlib.h>
 
 #include "common.h"
