@@ -318,11 +318,14 @@ class FIBERTransformerSS(LightningModule):
             ret.update(self.infer(batch))
             return ret
         if "itc" in self.current_tasks:                       # task_pretrain_mlm_itm_itc (reference forward :437-451)
-            if "mlm" in self.current_tasks:
+            fuse = ("mlm" in self.current_tasks and "itm" in self.current_tasks and self.config.get("fuse_mlm_itm", True))
+            if "mlm" in self.current_tasks and not fuse:
                 ret.update(objectives.compute_mlm(self, batch))
             ret_itc, image_neg, text_neg, text_mask_neg = objectives.compute_itc(self, batch, batch.get("itc_neg_override"))
             ret.update(ret_itc)
-            if "itm" in self.current_tasks:
+            if fuse:                                          # MLM + hard-negative ITM as one 4B-sample fused pass
+                ret.update(objectives.compute_mlm_itm_hardneg_fused(self, batch, image_neg, text_neg, text_mask_neg))
+            elif "itm" in self.current_tasks:
                 ret.update(objectives.compute_itm_hardneg(self, batch, image_neg, text_neg, text_mask_neg))
         elif ("mlm" in self.current_tasks and "itm" in self.current_tasks and self.config.get("fuse_mlm_itm", True)):
             ret.update(objectives.compute_mlm_itm_fused(self, batch, batch.get("itm_labels_override")))

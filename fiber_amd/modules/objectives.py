@@ -161,6 +161,36 @@ def compute_itm_hardneg(pl_module, batch, image_neg, text_neg, text_mask_neg):
     return ret
 
 
+def compute_mlm_itm_hardneg_fused(pl_module, batch, image_neg, text_neg, text_mask_neg):
+    """compute_mlm + compute_itm_hardneg (objectives.py:17-33, 78-116) in ONE fused-backbone pass over 4B samples
+    [B masked-text pairs ; B true pairs ; B (image, hard-negative text) ; B (hard-negative image, text)] -- the same
+    per-sample computation as the reference's two infer() calls, with a quarter fewer launches and larger GEMMs."""
+    B = len(batch["text"])
+    img = batch["image"][0]
+    fused = {
+        "image": [torch.cat([img, img, img, image_neg.to(img.dtype)], 0)],
+        "text_ids": torch.cat([batch["text_ids_mlm"], batch["text_ids"], text_neg, batch["text_ids"]], 0),
+        "text_labels": torch.cat([batch["text_labels_mlm"]] + [batch["text_labels"]] * 3, 0),
+        "text_masks": torch.cat([batch["text_masks"], batch["text_masks"], text_mask_neg, batch["text_masks"]], 0),
+    }
+    infer = pl_module.infer(fused, mask_text=False, mask_image=False)
+    mlm_logits = pl_module.mlm_score(infer["text_feats"][:B])
+    mlm_labels = batch["text_labels_mlm"]
+    mlm_loss = _mlm_ce(mlm_logits.view(-1, pl_module.hparams.config["vocab_size"]), mlm_labels.view(-1))
+    itm_labels = torch.cat([torch.ones(B), torch.zeros(2 * B)]).to(pl_module.device)
+    itm_logits = pl_module.itm_score(infer["cls_feats"][B:])
+    itm_loss = F.cross_entropy(itm_logits, itm_labels.long())
+    ret = {"mlm_loss": mlm_loss, "mlm_logits": mlm_logits, "mlm_labels": mlm_labels, "mlm_ids": batch["text_ids_mlm"],
+           "itm_loss": itm_loss, "itm_logits": itm_logits, "itm_labels": itm_labels}
+    phase = "train" if pl_module.training else "val"
+    for task in ("mlm", "itm"):
+        loss = getattr(pl_module, f"{phase}_{task}_loss")(ret[f"{task}_loss"])
+        acc = getattr(pl_module, f"{phase}_{task}_accuracy")(ret[f"{task}_logits"], ret[f"{task}_labels"])
+        pl_module.log(f"{task}/{phase}/loss", loss)
+        pl_module.log(f"{task}/{phase}/accuracy", acc)
+    return ret
+
+
 def compute_vqa(pl_module, batch):
     """VQAv2 fine-tune head (objectives.py:182-213): soft-target BCE over the answer vocabulary, scaled by its size."""
     infer = pl_module.infer(batch, mask_text=False, mask_image=False)

@@ -213,8 +213,9 @@ def test_vqa_finetune_path(name, golden):
             _sub_close("grad " + n, params[n].grad, gold, "grad/" + n, 0.15 if "alpha_" in n else 6e-2)
 
 
+@pytest.mark.parametrize("fuse", [True, False])
 @pytest.mark.parametrize("name", list(cases.ITC_CASES))
-def test_itc_pretrain_steps(name, golden):
+def test_itc_pretrain_steps(name, fuse, golden):
     """task_pretrain_mlm_itm_itc: MLM + ITC against the feature queues + ITM on hard negatives, two
     consecutive training steps (second one draws negatives from the queue and wraps the queue pointer), against the
     reference's own compute_itc / compute_itm_hardneg / _dequeue_and_enqueue with the negative draws replayed."""
@@ -223,7 +224,7 @@ def test_itc_pretrain_steps(name, golden):
     pc, gold = cases.ITC_CASES[name], golden(name)
     ref = detgen.fill_(R.FiberRef(pc["config"]).train())
     c = ref.config
-    model = FIBERTransformerSS(make_config(**pc["config"])).train()
+    model = FIBERTransformerSS(make_config(**dict(pc["config"], fuse_mlm_itm=fuse))).train()   # one 4B pass / reference order
     load_from_oracle(model, ref)
     with torch.no_grad():
         for bn in ("image_queue", "text_queue", "image_input_queue"):
