@@ -45,6 +45,9 @@ struct AttnP {
   const float* bias_table;   // [(2ws-1)^2, H] fp32
   float* dbias_part;         // [gridDim.z, H, N, N] fp32 partial bias gradients (pass A, WINDOW)
   int groups_per_block;      // pass A: windows visited by one workgroup
+  // LDS chunk geometry of this launch (host-chosen, launch_geometry()): tiles per chunk cap, rows of the row-major images,
+  // row length of the transposed images
+  int tpc_cap, chrows, chp;
   // attention-probability dropout
   float p_drop; uint64_t seed;
 };
@@ -75,10 +78,10 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
 }
 
 // Stage `nrows` rows (row r of the chunk <-> global row rowmap[r]) of a [*, ld] bf16 matrix (head slice D wide) into LDS,
-// row-major (stride D+8) and/or transposed ([D][CHP]).  Rows >= valid are zero filled.
+// row-major (stride D+8) and/or transposed ([D][chp]).  Rows >= valid are zero filled.
 template <int D, bool RM, bool TR>
 __device__ __forceinline__ void stage(const bf16* __restrict__ src, int ld, int hcol, const int* rowmap, int nrows,
-                                      int valid, bf16* rm, bf16* tr) {
+                                      int valid, bf16* rm, bf16* tr, int chp) {
   constexpr int CPR = D / 8;
   for (int idx = threadIdx.x; idx < nrows * CPR; idx += blockDim.x) {
     const int r = idx / CPR, c = idx - r * CPR;
@@ -92,15 +95,15 @@ __device__ __forceinline__ void stage(const bf16* __restrict__ src, int ld, int 
     if (RM) *reinterpret_cast<bf16x8*>(rm + r * (D + 8) + c * 8) = v;
     if (TR) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) tr[(c * 8 + e) * CHP + r] = v[e];
+      for (int e = 0; e < 8; ++e) tr[(c * 8 + e) * chp + r] = v[e];
     }
   }
 }
 
 // fragment of a transposed LDS image for MFMA operand A: row d, k-slots = keys {t0*16+g*4..+3} U {t0*16+16+g*4..+3}
-__device__ __forceinline__ bf16x8 tr_frag(const bf16* tr, int d, int t0, int g) {
-  const bf16x4 lo = *reinterpret_cast<const bf16x4*>(tr + d * CHP + t0 * 16 + g * 4);
-  const bf16x4 hi = *reinterpret_cast<const bf16x4*>(tr + d * CHP + t0 * 16 + 16 + g * 4);
+__device__ __forceinline__ bf16x8 tr_frag(const bf16* tr, int d, int t0, int g, int chp) {
+  const bf16x4 lo = *reinterpret_cast<const bf16x4*>(tr + d * chp + t0 * 16 + g * 4);
+  const bf16x4 hi = *reinterpret_cast<const bf16x4*>(tr + d * chp + t0 * 16 + 16 + g * 4);
   bf16x8 o;
 #pragma unroll
   for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi[e]; }
@@ -114,7 +117,7 @@ struct Lds {
   bf16* rm0; bf16* rm1; bf16* tr0; bf16* tr1;
 };
 template <int D>
-__device__ __forceinline__ Lds carve(char* base, int nbias, int n_rm, int n_tr) {
+__device__ __forceinline__ Lds carve(char* base, int nbias, int n_rm, int n_tr, int chrows, int chp) {
   Lds L;
   L.rowmap = reinterpret_cast<int*>(base);
   L.reg = L.rowmap + CH;
@@ -123,15 +126,15 @@ __device__ __forceinline__ Lds carve(char* base, int nbias, int n_rm, int n_tr) 
   L.btab = L.aux + CH;
   size_t off = (size_t)(4 * CH + ((nbias + 3) & ~3)) * 4;
   bf16* img = reinterpret_cast<bf16*>(base + off);
-  L.rm0 = img; img += (n_rm > 0) * CH * (D + 8);
-  L.rm1 = img; img += (n_rm > 1) * CH * (D + 8);
-  L.tr0 = img; img += (n_tr > 0) * D * CHP;
+  L.rm0 = img; img += (n_rm > 0) * chrows * (D + 8);
+  L.rm1 = img; img += (n_rm > 1) * chrows * (D + 8);
+  L.tr0 = img; img += (n_tr > 0) * D * chp;
   L.tr1 = img;
   return L;
 }
 template <int D>
-size_t lds_bytes(int nbias, int n_rm, int n_tr) {
-  return (size_t)(4 * CH + ((nbias + 3) & ~3)) * 4 + (size_t)n_rm * CH * (D + 8) * 2 + (size_t)n_tr * D * CHP * 2;
+size_t lds_bytes(int nbias, int n_rm, int n_tr, int chrows, int chp) {
+  return (size_t)(4 * CH + ((nbias + 3) & ~3)) * 4 + (size_t)n_rm * chrows * (D + 8) * 2 + (size_t)n_tr * D * chp * 2;
 }
 
 // rows of chunk `c0..c0+n` of the KEY (or query) axis -> LDS rowmap/reg/addmask
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = D / 32, DT = D / 16;
   const int nb = WINDOW ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
-  Lds L = carve<D>(smem, nb, 1, 1);
+  Lds L = carve<D>(smem, nb, 1, 1, p.chrows, p.chp);
   bf16* Ks = L.rm0; bf16* Vt = L.tr0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int gq = lane >> 4, lq = lane & 15;
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnP p) {
   for (int ks = 0; ks < KS; ++ks)
     qf[ks] = *reinterpret_cast<const bf16x8*>(p.q + (size_t)qtok * p.ldq + h * D + ks * 32 + gq * 8);
 
-  const int ntiles = (p.Lk + 15) / 16, nchunk = (ntiles + NKT - 1) / NKT, tpc = (ntiles + nchunk - 1) / nchunk;
+  const int ntiles = (p.Lk + 15) / 16, nchunk = (ntiles + p.tpc_cap - 1) / p.tpc_cap, tpc = (ntiles + nchunk - 1) / nchunk;
   float m = -INFINITY, lsum = 0.f;
   f32x4 oacc[DT];
 #pragma unroll
@@ -196,8 +199,8 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnP p) {
     fill_rowmeta(p, L, g, kbase, tpc * 16, p.Lk, true);
     __syncthreads();
     const int valid = min(tpc * 16, p.Lk - kbase);
-    stage<D, true, false>(p.k, p.ldk, h * D, L.rowmap, tpc * 16, valid, Ks, nullptr);
-    stage<D, false, true>(p.v, p.ldv, h * D, L.rowmap, (tpc * 16 + 31) & ~31, valid, nullptr, Vt);
+    stage<D, true, false>(p.k, p.ldk, h * D, L.rowmap, tpc * 16, valid, Ks, nullptr, p.chp);
+    stage<D, false, true>(p.v, p.ldv, h * D, L.rowmap, (tpc * 16 + 31) & ~31, valid, nullptr, Vt, p.chp);
     __syncthreads();
 
     f32x4 s[NKT];
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnP p) {
         const bf16x8 pf = pack8(s[2 * t2], s[2 * t2 + 1]);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-          const bf16x8 vf = tr_frag(Vt, dt * 16 + lq, 2 * t2, gq);
+          const bf16x8 vf = tr_frag(Vt, dt * 16 + lq, 2 * t2, gq, p.chp);
           oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);   // O^T[d][query]
         }
       }
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = D / 32, DT = D / 16;
   const int nb = WINDOW ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
-  Lds L = carve<D>(smem, nb, 2, 1);
+  Lds L = carve<D>(smem, nb, 2, 1, p.chrows, p.chp);
   bf16* Ks = L.rm0; bf16* Vs = L.rm1; bf16* Kt = L.tr0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int gq = lane >> 4, lq = lane & 15;
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
   const int i = strip * 16 + lq;
   const bool qvalid = i < p.Lq;
   for (int t = threadIdx.x; t < nb; t += blockDim.x) L.btab[t] = p.bias_table[(size_t)t * p.H + h];
-  const int ntiles = (p.Lk + 15) / 16, nchunk = (ntiles + NKT - 1) / NKT, tpc = (ntiles + nchunk - 1) / nchunk;
+  const int ntiles = (p.Lk + 15) / 16, nchunk = (ntiles + p.tpc_cap - 1) / p.tpc_cap, tpc = (ntiles + nchunk - 1) / nchunk;
   const uint32_t thresh = (uint32_t)((double)p.p_drop * 4294967296.0);
   const float inv_keep = 1.f / (1.f - p.p_drop);
 
@@ -345,8 +348,8 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
       fill_rowmeta(p, L, g, kbase, tpc * 16, p.Lk, true);
       __syncthreads();
       const int valid = min(tpc * 16, p.Lk - kbase);
-      stage<D, true, true>(p.k, p.ldk, h * D, L.rowmap, (tpc * 16 + 31) & ~31, valid, Ks, Kt);
-      stage<D, true, false>(p.v, p.ldv, h * D, L.rowmap, tpc * 16, valid, Vs, nullptr);
+      stage<D, true, true>(p.k, p.ldk, h * D, L.rowmap, (tpc * 16 + 31) & ~31, valid, Ks, Kt, p.chp);
+      stage<D, true, false>(p.v, p.ldv, h * D, L.rowmap, tpc * 16, valid, Vs, nullptr, p.chp);
       __syncthreads();
 #pragma unroll
       for (int t2 = 0; t2 < NKT / 2; ++t2) {
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
           const bf16x8 dsf = pack8(ds[0], ds[1]);
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
-            const bf16x8 ktf = tr_frag(Kt, dt * 16 + lq, 2 * t2, gq);
+            const bf16x8 ktf = tr_frag(Kt, dt * 16 + lq, 2 * t2, gq, p.chp);
             dqacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf, dqacc[dt], 0, 0, 0);   // dQ^T[d][query]
           }
         }
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = D / 32, DT = D / 16;
   const int nb = WINDOW ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
-  Lds L = carve<D>(smem, nb, 2, 2);
+  Lds L = carve<D>(smem, nb, 2, 2, p.chrows, p.chp);
   bf16* Qs = L.rm0; bf16* dOs = L.rm1; bf16* Qt = L.tr0; bf16* dOt = L.tr1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int gq = lane >> 4, lq = lane & 15;
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnP p) {
     kf[ks] = *reinterpret_cast<const bf16x8*>(p.k + (size_t)ktok * p.ldk + h * D + ks * 32 + gq * 8);
     vf[ks] = *reinterpret_cast<const bf16x8*>(p.v + (size_t)ktok * p.ldv + h * D + ks * 32 + gq * 8);
   }
-  const int ntiles = (p.Lq + 15) / 16, nchunk = (ntiles + NKT - 1) / NKT, tpc = (ntiles + nchunk - 1) / nchunk;
+  const int ntiles = (p.Lq + 15) / 16, nchunk = (ntiles + p.tpc_cap - 1) / p.tpc_cap, tpc = (ntiles + nchunk - 1) / nchunk;
   const uint32_t thresh = (uint32_t)((double)p.p_drop * 4294967296.0);
   const float inv_keep = 1.f / (1.f - p.p_drop);
   f32x4 dkacc[DT], dvacc[DT];
@@ -472,8 +475,8 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnP p) {
     __syncthreads();
     const int valid = min(tpc * 16, p.Lq - qbase);
     const int nst = (tpc * 16 + 31) & ~31;
-    stage<D, true, true>(p.q, p.ldq, h * D, L.rowmap, nst, valid, Qs, Qt);
-    stage<D, true, true>(p.dout, p.lddo, h * D, L.rowmap, nst, valid, dOs, dOt);
+    stage<D, true, true>(p.q, p.ldq, h * D, L.rowmap, nst, valid, Qs, Qt, p.chp);
+    stage<D, true, true>(p.dout, p.lddo, h * D, L.rowmap, nst, valid, dOs, dOt, p.chp);
     for (int r = threadIdx.x; r < tpc * 16; r += blockDim.x) {   // per-query lse (addmask slot) and delta (aux slot)
       const bool ok = r < valid;
       L.addmask[r] = ok ? p.lse[(size_t)L.rowmap[r] * p.H + h] : INFINITY;   // +inf -> p = exp(-inf) = 0 for padded queries
@@ -523,8 +526,8 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnP p) {
         const bf16x8 dsf = pack8(ds[0], ds[1]), pf = pack8(pd[0], pd[1]);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-          const bf16x8 qtf = tr_frag(Qt, dt * 16 + lq, 2 * t2, gq);
-          const bf16x8 dotf = tr_frag(dOt, dt * 16 + lq, 2 * t2, gq);
+          const bf16x8 qtf = tr_frag(Qt, dt * 16 + lq, 2 * t2, gq, p.chp);
+          const bf16x8 dotf = tr_frag(dOt, dt * 16 + lq, 2 * t2, gq, p.chp);
           dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf, dkacc[dt], 0, 0, 0);   // dK^T[d][key]
           dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotf, pf, dvacc[dt], 0, 0, 0);   // dV^T[d][key]
         }
@@ -568,11 +571,24 @@ int pick_waves(int nstrips, int staged) {
   return nstrips <= 12 ? nstrips : (nstrips % 9 == 0 ? 9 : 8);
 }
 
+// LDS chunk geometry for a launch that stages `staged_len` rows per group with `nw` waves per workgroup.  The images are
+// sized to the chunk actually used (a 40-token text sequence needs 48 rows, not 160), and small workgroups take chunks of at
+// most 5 tiles: with the full 160-row layout a 3-wave workgroup of the D = 64 kernels owned 47-91 KB of LDS, i.e. one or two
+// workgroups (3-6 waves) per CU.
+void launch_geometry(AttnP& p, int staged_len, int nw, bool backward) {
+  const int ntiles = cdiv(staged_len, 16);
+  p.tpc_cap = (backward && nw <= 4 && ntiles > 5 && !p.window) ? 5 : NKT;   // forward: one row-major + one transposed image only, shorter chunks just add barriers (t2i forward 388 -> 422 us)
+  const int nchunk = cdiv(ntiles, p.tpc_cap), tpc = cdiv(ntiles, nchunk);
+  p.chrows = (tpc * 16 + 31) & ~31;
+  p.chp = p.chrows + 8;
+}
+
 template <int D>
 int launch_fwd(AttnP& p, hipStream_t st) {
   const int nstrips = cdiv(p.Lq, 16), nw = pick_waves(nstrips, p.Lk);
   const int nb = p.window ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
-  const size_t sh = lds_bytes<D>(nb, 1, 1);
+  launch_geometry(p, p.Lk, nw, false);
+  const size_t sh = lds_bytes<D>(nb, 1, 1, p.chrows, p.chp);
   if (p.window) hipLaunchKernelGGL((attn_fwd_kernel<D, true>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), sh, st, p);
   else hipLaunchKernelGGL((attn_fwd_kernel<D, false>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), sh, st, p);
   FIBER_CHECK_LAUNCH();
@@ -602,8 +618,10 @@ int launch_bwd(AttnP& p, float* delta, float* dbias_table, float* dbias_ws, int 
       gz = cdiv(p.G, p.groups_per_block);
       p.dbias_part = dbias_ws;
     }
-    if (p.window) hipLaunchKernelGGL((attn_bwd_dq_kernel<D, true>), dim3(cdiv(nstrips, nw), p.H, gz), dim3(64 * nw), lds_bytes<D>(nb, 2, 1), st, p);
-    else hipLaunchKernelGGL((attn_bwd_dq_kernel<D, false>), dim3(cdiv(nstrips, nw), p.H, gz), dim3(64 * nw), lds_bytes<D>(nb, 2, 1), st, p);
+    launch_geometry(p, p.Lk, nw, true);
+    const size_t sh = lds_bytes<D>(nb, 2, 1, p.chrows, p.chp);
+    if (p.window) hipLaunchKernelGGL((attn_bwd_dq_kernel<D, true>), dim3(cdiv(nstrips, nw), p.H, gz), dim3(64 * nw), sh, st, p);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<D, false>), dim3(cdiv(nstrips, nw), p.H, gz), dim3(64 * nw), sh, st, p);
     FIBER_CHECK_LAUNCH();
     if (p.window) {
       if (hipMemsetAsync(dbias_table, 0, (size_t)nb * p.H * sizeof(float), st) != hipSuccess) return FIBER_ELAUNCH;
@@ -613,8 +631,10 @@ int launch_bwd(AttnP& p, float* delta, float* dbias_table, float* dbias_ws, int 
   }
   {
     const int nstrips = cdiv(p.Lk, 16), nw = pick_waves(nstrips, 1 << 20);   // key-strip pass: measured worse with small workgroups
-    if (p.window) hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, true>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), lds_bytes<D>(nb, 2, 2), st, p);
-    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, false>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), lds_bytes<D>(nb, 2, 2), st, p);
+    launch_geometry(p, p.Lq, nw, true);
+    const size_t sh = lds_bytes<D>(nb, 2, 2, p.chrows, p.chp);
+    if (p.window) hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, true>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), sh, st, p);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, false>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), sh, st, p);
     FIBER_CHECK_LAUNCH();
   }
   return FIBER_OK;
