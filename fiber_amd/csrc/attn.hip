@@ -111,9 +111,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16* tr, int d, int t0, int g, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Shared LDS layout (dynamic): [rowmap int CH][reg int CH][addmask float CH][aux float CH][btab float nb] then bf16 images
+// Shared LDS layout (dynamic): [rowmap int CH][reg int CH][addmask float CH][aux float CH][woff int CH][btab float nb] then bf16 images
 struct Lds {
-  int* rowmap; int* reg; float* addmask; float* aux; float* btab;
+  int* rowmap; int* reg; float* addmask; float* aux; int* woff; float* btab;
   bf16* rm0; bf16* rm1; bf16* tr0; bf16* tr1;
 };
 template <int D>
@@ -123,8 +123,9 @@ __device__ __forceinline__ Lds carve(char* base, int nbias, int n_rm, int n_tr, 
   L.reg = L.rowmap + CH;
   L.addmask = reinterpret_cast<float*>(L.reg + CH);
   L.aux = L.addmask + CH;
-  L.btab = L.aux + CH;
-  size_t off = (size_t)(4 * CH + ((nbias + 3) & ~3)) * 4;
+  L.woff = reinterpret_cast<int*>(L.aux + CH);
+  L.btab = reinterpret_cast<float*>(L.woff + CH);
+  size_t off = (size_t)(5 * CH + ((nbias + 3) & ~3)) * 4;
   bf16* img = reinterpret_cast<bf16*>(base + off);
   L.rm0 = img; img += (n_rm > 0) * chrows * (D + 8);
   L.rm1 = img; img += (n_rm > 1) * chrows * (D + 8);
@@ -134,8 +135,17 @@ __device__ __forceinline__ Lds carve(char* base, int nbias, int n_rm, int n_tr, 
 }
 template <int D>
 size_t lds_bytes(int nbias, int n_rm, int n_tr, int chrows, int chp) {
-  return (size_t)(4 * CH + ((nbias + 3) & ~3)) * 4 + (size_t)n_rm * chrows * (D + 8) * 2 + (size_t)n_tr * D * chp * 2;
+  return (size_t)(5 * CH + ((nbias + 3) & ~3)) * 4 + (size_t)n_rm * chrows * (D + 8) * 2 + (size_t)n_tr * D * chp * 2;
 }
+
+// WINDOW mode: relative_position_index(i, j) = off(i) - off(j) + wconst with off(x) = row(x) * (2 ws - 1) + col(x)
+// (swin_transformer.py:166-176).  off() of every staged row is tabulated once per chunk (Lds::woff) and each lane keeps its
+// own, so a score costs two LDS reads instead of two integer divisions (the 576^2 configuration spends half its step here).
+__device__ __forceinline__ int win_off(const AttnP& p, int x) {
+  const int pr = x / p.ws;
+  return pr * (2 * p.ws - 1) + (x - pr * p.ws);
+}
+__device__ __forceinline__ int win_const(const AttnP& p) { return (p.ws - 1) * (2 * p.ws - 1) + (p.ws - 1); }
 
 // rows of chunk `c0..c0+n` of the KEY (or query) axis -> LDS rowmap/reg/addmask
 __device__ __forceinline__ void fill_rowmeta(const AttnP& p, const Lds& L, int g, int base, int n, int len, bool keys) {
@@ -150,14 +160,10 @@ __device__ __forceinline__ void fill_rowmeta(const AttnP& p, const Lds& L, int g
       am = -INFINITY;
     }
     L.rowmap[r] = tok; L.reg[r] = reg; L.addmask[r] = am;
+    if (p.window) L.woff[r] = win_off(p, j < len ? j : len - 1);     // relative-position offset of this row (see win_off)
   }
 }
 
-// score bias for (query i, key j) in WINDOW mode
-__device__ __forceinline__ float win_bias(const AttnP& p, const float* btab, int i, int j) {
-  const int pri = i / p.ws, pci = i - pri * p.ws, prj = j / p.ws, pcj = j - prj * p.ws;
-  return btab[(pri - prj + p.ws - 1) * (2 * p.ws - 1) + (pci - pcj + p.ws - 1)];
-}
 
 // ===================================================== forward =================================================
 template <int D, bool WINDOW>
@@ -173,6 +179,7 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnP p) {
   const int strip = blockIdx.x * nw + wave;
   const int i = strip * 16 + lq;                      // this lane's query (window-local / sample-local)
   const bool qvalid = i < p.Lq;
+  const int ioff = WINDOW ? win_off(p, qvalid ? i : 0) + win_const(p) : 0;   // this lane's query in relative-position offsets
   int qtok = 0, qreg = 0;
   {
     const int ic = qvalid ? i : p.Lq - 1;
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnP p) {
           const int jl = kt * 16 + gq * 4 + r;
           float v = a[r] * p.scale + L.addmask[jl];
           if (WINDOW) {
-            v += win_bias(p, L.btab, qvalid ? i : 0, min(kbase + jl, p.Lk - 1));
+            v += L.btab[ioff - L.woff[jl]];
             if (L.reg[jl] != qreg) v += -100.f;
           }
           s[kt][r] = v;
@@ -311,6 +318,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
   const int strip = blockIdx.x * nw + wave;
   const int i = strip * 16 + lq;
   const bool qvalid = i < p.Lq;
+  const int ioff = WINDOW ? win_off(p, qvalid ? i : 0) + win_const(p) : 0;   // this lane's query in relative-position offsets
   for (int t = threadIdx.x; t < nb; t += blockDim.x) L.btab[t] = p.bias_table[(size_t)t * p.H + h];
   const int ntiles = (p.Lk + 15) / 16, nchunk = (ntiles + p.tpc_cap - 1) / p.tpc_cap, tpc = (ntiles + nchunk - 1) / nchunk;
   const uint32_t thresh = (uint32_t)((double)p.p_drop * 4294967296.0);
@@ -373,7 +381,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
                 const int jl = kt * 16 + gq * 4 + r;
                 float sv = a[r] * p.scale + L.addmask[jl];
                 if (WINDOW) {
-                  sv += win_bias(p, L.btab, qvalid ? i : 0, min(kbase + jl, p.Lk - 1));
+                  sv += L.btab[ioff - L.woff[jl]];
                   if (L.reg[jl] != qreg) sv += -100.f;
                 }
                 const float pr = __expf(sv - lse);
@@ -447,6 +455,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnP p) {
   const int strip = blockIdx.x * nw + wave;
   const int j = strip * 16 + lq;                      // this lane's key
   const bool kvalid = j < p.Lk;
+  const int joff = WINDOW ? win_off(p, kvalid ? j : 0) - win_const(p) : 0;    // this lane's key
   int ktok = 0, kreg = 0;
   float kadd = 0.f;
   {
@@ -507,7 +516,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnP p) {
               const int ig = min(qbase + il, p.Lq - 1);
               float sv = a[r] * p.scale + kadd;
               if (WINDOW) {
-                sv += win_bias(p, L.btab, ig, kvalid ? j : 0);
+                sv += L.btab[L.woff[il] - joff];
                 if (L.reg[il] != kreg) sv += -100.f;
               }
               float pr = kvalid ? __expf(sv - L.addmask[il]) : 0.f;
