@@ -3,6 +3,7 @@
 transformers==4.6.0 (`AdamW(correct_bias=True)`: decoupled weight decay, eps 1e-8, betas (0.9, 0.98);
 `get_polynomial_decay_schedule_with_warmup`)."""
 import math
+import os
 
 import torch
 
@@ -113,7 +114,6 @@ def set_schedule(pl_module):
         # (torch's fused=True variant measured no faster here once the bf16 working copies are refreshed every step.)
         # On a HIP device: one kernel per parameter group that also rewrites the bf16 working copies (fiber_amd/optim.py);
         # host tensors (the CPU wiring tests) take torch's implementation of the same rule.
-        import os
         if any(p.is_cuda for g in groups for p in g["params"]) and not os.environ.get("FIBER_TORCH_ADAMW"):
             from ..optim import FiberAdamW
             optimizer = own = FiberAdamW(groups, lr=lr, eps=1e-8, betas=(0.9, 0.98))
