@@ -178,11 +178,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X devices (there is no CPU fallback for the product path)"
+    local %= torch.cuda.device_count()                      # (only matters for the 2-ranks-on-1-GPU gloo wiring test)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
     from fiber_amd import parallel
-    parallel.init_distributed("nccl")
+    parallel.init_distributed(os.environ.get("FIBER_DIST_BACKEND", "nccl"))   # RCCL; "gloo" only for 1-GPU wiring tests
 
     from fiber_amd import lib, ops
     from fiber_amd.config import make_config

@@ -69,3 +69,33 @@ def test_two_rank_ddp_on_one_gpu(tmp_path):
     res = torch.load(out)
     assert res["finite"] and all(l == l for l in res["losses"])
     assert res["same"], "parameters diverged across DDP ranks (gradient all-reduce / frozen-parameter wiring is wrong)"
+
+
+def test_bench_contract_two_ranks_one_gpu():
+    """bench.py exactly as the driver launches it at N > 1 (torch.distributed.run, one process per rank), with the backend
+    switched to gloo so that two ranks can share the one visible GPU: rank 0 must print ONE JSON line with the contract keys,
+    n_gpus = 2 and a whole-job value."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, FIBER_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
+    assert abs(d["value"] - 16 / (d["ms_per_step"] * 1e-3)) < 0.05 * d["value"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
