@@ -686,8 +686,8 @@ int fiber_win_bwd_launch(const void* qkv, const float* bias_table, const void* o
 extern "C" int fiber_window_attn_fwd_bf16(const void* qkv, const float* bias_table, void* o, float* lse, int B, int Hres,
                                           int Wres, int C, int heads, int ws, int shift, int head_major, hipStream_t stream) {
   if (C != heads * 32 || Hres % ws || Wres % ws || shift < 0 || shift >= ws) return FIBER_EINVAL;
-  if (ws * ws <= 160) return fiber_win_fwd_launch(qkv, bias_table, o, lse, B, Hres, Wres, C, heads, ws, shift, head_major, stream);
-  if (head_major) return FIBER_EINVAL;                 // the generic (N > 160) path reads the reference layout only
+  if (ws * ws <= 336) return fiber_win_fwd_launch(qkv, bias_table, o, lse, B, Hres, Wres, C, heads, ws, shift, head_major, stream);
+  if (head_major) return FIBER_EINVAL;                 // the generic (N > 336) path reads the reference layout only
   ensure_attrs();
   AttnP p{};
   const bf16* base = (const bf16*)qkv;
@@ -709,7 +709,7 @@ extern "C" int fiber_window_attn_bwd_bf16(const void* qkv, const float* bias_tab
                                           float* dbias_ws, int B, int Hres, int Wres, int C, int heads, int ws, int shift,
                                           int head_major, hipStream_t stream) {
   if (C != heads * 32 || Hres % ws || Wres % ws || shift < 0 || shift >= ws) return FIBER_EINVAL;
-  if (ws * ws <= 160)
+  if (ws * ws <= 336)
     return fiber_win_bwd_launch(qkv, bias_table, o, dout, lse, dqkv, dbias_table, delta_ws, dbias_ws, B, Hres, Wres, C, heads,
                                 ws, shift, head_major, stream);
   if (head_major) return FIBER_EINVAL;

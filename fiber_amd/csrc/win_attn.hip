@@ -1,4 +1,4 @@
-// Swin (shifted-)window attention, specialised + persistent (gfx950 / CDNA4).  head_dim 32, N = ws*ws <= 160.
+// Swin (shifted-)window attention, specialised + persistent (gfx950 / CDNA4).  head_dim 32, N = ws*ws <= 336.
 //
 // Same math and MFMA formulation as attn.hip's WINDOW mode (swin_transformer.py:195-219 with roll / partition /
 // reverse :99-126,364-387 folded into addressing, bias gather :208-211, shift mask :327-350), restructured for
@@ -20,10 +20,13 @@
 
 namespace {
 
-constexpr int MAXN = 160;          // keys per window (<= 10 tiles of 16)
-constexpr int MT = 10;
+// Tile capacity is a template parameter MTT of every kernel / helper below: 10 tiles (N <= 160: the 12x12 windows of the 384^2
+// configurations, bias slice held in registers) or 21 tiles (N <= 336: the 18x18 windows of the 576^2 configuration, bias
+// looked up from LDS per score -- 84 more registers per lane do not exist).  MT / MAXN / TS are derived locally from it.
 constexpr int RS = 40;             // row stride (elements) of row-major LDS tiles: 32 + 8 pad (80 B, 16-B aligned)
-constexpr int TS = MAXN + 8;       // row stride of transposed LDS tiles
+// (tiles are consumed in pairs by the second MFMA of each pass: an odd capacity is rounded up for the pair loops, the
+// per-tile register arrays and the transposed-image stride, the extra tile being all zeros)
+#define WIN_DIMS(MTT) constexpr int MT = (MTT), MTP = ((MTT) + 1) & ~1, MAXN = MTP * 16, TS = MAXN + 8; (void)MT; (void)MTP; (void)MAXN; (void)TS
 
 struct WinP {
   const bf16* qkv; bf16* o; const bf16* dout; bf16* dqkv;
@@ -41,7 +44,9 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
   for (int e = 0; e < 4; ++e) { o[e] = f2bf(a[e]); o[4 + e] = f2bf(b[e]); }
   return o;
 }
+template <int MTT>
 __device__ __forceinline__ bf16x8 tr_frag(const bf16* tr, int d, int t0, int g) {
+  WIN_DIMS(MTT);
   const bf16x4 lo = *reinterpret_cast<const bf16x4*>(tr + d * TS + t0 * 16 + g * 4);
   const bf16x4 hi = *reinterpret_cast<const bf16x4*>(tr + d * TS + t0 * 16 + 16 + g * 4);
   bf16x8 o;
@@ -87,7 +92,9 @@ struct Smem {
   int* koff; int* kreg; float* btab; float* lse; float* dlt;
   bf16* a0; bf16* a1; bf16* t0; bf16* t1;
 };
+template <int MTT>
 __device__ __forceinline__ Smem carve(char* base, int nb, int n_rm, int n_tr) {
+  WIN_DIMS(MTT);
   Smem S;
   S.koff = reinterpret_cast<int*>(base);
   S.kreg = S.koff + MAXN;
@@ -101,12 +108,16 @@ __device__ __forceinline__ Smem carve(char* base, int nb, int n_rm, int n_tr) {
   S.t1 = img;
   return S;
 }
+template <int MTT>
 size_t smem_bytes(int nb, int n_rm, int n_tr) {
+  WIN_DIMS(MTT);
   return (size_t)(4 * MAXN + ((nb + 3) & ~3)) * 4 + (size_t)n_rm * MAXN * RS * 2 + (size_t)n_tr * 32 * TS * 2;
 }
 
 // common per-block setup: bias column of this head, key offsets, zeroed LDS tiles (padding rows stay zero forever)
+template <int MTT>
 __device__ __forceinline__ void setup(const WinP& p, const Smem& S, int h, int nb, int n_rm, int n_tr) {
+  WIN_DIMS(MTT);
   for (int t = threadIdx.x; t < nb; t += blockDim.x) S.btab[t] = p.bias_table[(size_t)t * p.heads + h];
   for (int j = threadIdx.x; j < MAXN; j += blockDim.x) {
     const int jj = j < p.N ? j : 0;
@@ -122,18 +133,21 @@ __device__ __forceinline__ void setup(const WinP& p, const Smem& S, int h, int n
 }
 
 // ================================================================ forward =====================================
-template <int MAXC, int NTC = 0>   // MAXC: 16-byte staging chunks per thread; NTC: key/query tiles if known at compile time (9 for 12x12 windows)
-__global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_fwd_kernel(WinP p) {
+// MAXC: 16-byte staging chunks per thread; NTC: key/query tiles if known at compile time (9 for 12x12 windows);
+// MTT: tile capacity (10 / 21); BREG: window-invariant bias slice in registers (else LDS look-ups per score)
+template <int MAXC, int NTC = 0, int MTT = 10, bool BREG = true>
+__global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) {
+  WIN_DIMS(MTT);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nb = (2 * p.ws - 1) * (2 * p.ws - 1);
-  Smem S = carve(smem, nb, 1, 1);
+  Smem S = carve<MTT>(smem, nb, 1, 1);
   bf16* Ks = S.a0; bf16* Vt = S.t0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gq = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y, C = p.C, ld = 3 * C;
   const int qo = p.hmajor ? h * 96 : h * 32, ko = p.hmajor ? h * 96 + 32 : C + h * 32, vo = p.hmajor ? h * 96 + 64 : 2 * C + h * 32;
   const int ntile = NTC ? NTC : (p.N + 15) >> 4;      // compile-time for the 12x12 window: guards fold, the 10th tile's code disappears
-  setup(p, S, h, nb, 1, 1);
+  setup<MTT>(p, S, h, nb, 1, 1);
 
   // this thread's staging chunks: chunk id = tid + c*blockDim -> (row = id>>2 of the window, 16-byte piece id&3)
   int spr[MAXC], spc[MAXC];
@@ -159,14 +173,31 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_fwd_kernel(WinP p) 
   // (bias_table[rel_index(i, j)], swin_transformer.py:208-211) is window-invariant: gather it ONCE into registers
   // (-inf for padded keys) and the per-score work becomes a single fma.
   __syncthreads();
-  f32x4 breg[MT];
-#pragma unroll
-  for (int kt = 0; kt < MT; ++kt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int jj = kt * 16 + gq * 4 + r;
-      breg[kt][r] = (kt < ntile && jj < p.N) ? S.btab[qoff - S.koff[jj]] * 1.4426950408889634f : -INFINITY;   // log2 domain
+  f32x4 breg[BREG ? MT : 1];
+  // bias of key tile kt for this lane's query, log2 domain, -inf on padded keys
+  auto bias_tile = [&](int kt) -> f32x4 {
+    if constexpr (BREG) {
+      return breg[kt];
+    } else {
+      const int4 ko = *reinterpret_cast<const int4*>(S.koff + kt * 16 + gq * 4);
+      const int j0 = kt * 16 + gq * 4;
+      f32x4 b;
+      b[0] = j0 + 0 < p.N ? S.btab[qoff - ko.x] * 1.4426950408889634f : -INFINITY;
+      b[1] = j0 + 1 < p.N ? S.btab[qoff - ko.y] * 1.4426950408889634f : -INFINITY;
+      b[2] = j0 + 2 < p.N ? S.btab[qoff - ko.z] * 1.4426950408889634f : -INFINITY;
+      b[3] = j0 + 3 < p.N ? S.btab[qoff - ko.w] * 1.4426950408889634f : -INFINITY;
+      return b;
     }
+  };
+  if constexpr (BREG) {
+#pragma unroll
+    for (int kt = 0; kt < MT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int jj = kt * 16 + gq * 4 + r;
+        breg[kt][r] = (kt < ntile && jj < p.N) ? S.btab[qoff - S.koff[jj]] * 1.4426950408889634f : -INFINITY;   // log2 domain
+      }
+  }
   const float scale2 = scale * 1.4426950408889634f;     // scores kept in the log2 domain: exp is a bare v_exp_f32
   Geo geo;
   geo.set(p, g0);
@@ -210,7 +241,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_fwd_kernel(WinP p) 
     // The body is instantiated twice (BORDER true/false) and selected by a wave-uniform branch per window: only windows
     // on the wrapped border pay for the region-mask compares/selects (swin_transformer.py:327-350); padded key tiles carry
     // bias = -inf so exp2 gives exact zeros without per-element selects.
-    f32x4 s[MT];
+    f32x4 s[MTP];
     float mx = -INFINITY, sum;
     f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     {
@@ -219,9 +250,10 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_fwd_kernel(WinP p) 
         if (kt < ntile) {
           const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 16 + lq) * RS + gq * 8);
           const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);   // S^T[key][query]
+          const f32x4 bt = bias_tile(kt);
           f32x4 v;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaf(a[r], scale2, breg[kt][r]);
+          for (int r = 0; r < 4; ++r) v[r] = fmaf(a[r], scale2, bt[r]);
           if (border) {
             const int4 kg = *reinterpret_cast<const int4*>(S.kreg + kt * 16 + gq * 4);
             v[0] = kg.x != qreg ? v[0] - 144.26950408889634f : v[0];     // -100 * log2(e)
@@ -236,7 +268,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_fwd_kernel(WinP p) 
       mx = g4max(mx);
       float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-      for (int kt = 0; kt < MT; ++kt) {
+      for (int kt = 0; kt < MTP; ++kt) {
         if (kt < ntile) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - mx);
@@ -248,12 +280,12 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_fwd_kernel(WinP p) 
       }
       sum = g4sum(s0 + s1);
 #pragma unroll
-      for (int t2 = 0; t2 < MT / 2; ++t2) {
+      for (int t2 = 0; t2 < MTP / 2; ++t2) {
         if (t2 * 2 < ntile) {
           const bf16x8 pf = pack8(s[2 * t2], s[2 * t2 + 1]);
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt)
-            oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Vt, dt * 16 + lq, 2 * t2, gq), pf, oacc[dt], 0, 0, 0);
+            oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<MTT>(Vt, dt * 16 + lq, 2 * t2, gq), pf, oacc[dt], 0, 0, 0);
         }
       }
     }
@@ -272,18 +304,21 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_fwd_kernel(WinP p) 
 }
 
 // ================================================================ backward pass A: dQ + dbias =================
-template <int MAXC, int NTC = 0>   // MAXC: 16-byte staging chunks per thread; NTC: key/query tiles if known at compile time (9 for 12x12 windows)
-__global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dq_kernel(WinP p) {
+// MAXC: 16-byte staging chunks per thread; NTC: key/query tiles if known at compile time (9 for 12x12 windows);
+// MTT: tile capacity (10 / 21); BREG: window-invariant bias slice in registers (else LDS look-ups per score)
+template <int MAXC, int NTC = 0, int MTT = 10, bool BREG = true>
+__global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP p) {
+  WIN_DIMS(MTT);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nb = (2 * p.ws - 1) * (2 * p.ws - 1);
-  Smem S = carve(smem, nb, 2, 1);
+  Smem S = carve<MTT>(smem, nb, 2, 1);
   bf16* Ks = S.a0; bf16* Vs = S.a1; bf16* Kt = S.t0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gq = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y, C = p.C, ld = 3 * C;
   const int qo = p.hmajor ? h * 96 : h * 32, ko = p.hmajor ? h * 96 + 32 : C + h * 32, vo = p.hmajor ? h * 96 + 64 : 2 * C + h * 32;
   const int ntile = NTC ? NTC : (p.N + 15) >> 4;      // compile-time for the 12x12 window: guards fold, the 10th tile's code disappears
-  setup(p, S, h, nb, 2, 1);
+  setup<MTT>(p, S, h, nb, 2, 1);
   int spr[MAXC], spc[MAXC];
   bool sval[MAXC];
 #pragma unroll
@@ -300,15 +335,31 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dq_kernel(WinP 
   const int qoff = (qpr + p.ws - 1) * (2 * p.ws - 1) + qpc + p.ws - 1;
   const float scale = 0.17677669529663687f;
 
-  f32x4 dbacc[MT], breg[MT];
+  f32x4 dbacc[MTP], breg[BREG ? MT : 1];
+  auto bias_tile = [&](int kt) -> f32x4 {                 // log2 domain, -inf on padded keys
+    if constexpr (BREG) {
+      return breg[kt];
+    } else {
+      const int4 ko = *reinterpret_cast<const int4*>(S.koff + kt * 16 + gq * 4);
+      const int j0 = kt * 16 + gq * 4;
+      f32x4 b;
+      b[0] = j0 + 0 < p.N ? S.btab[qoff - ko.x] * 1.4426950408889634f : -INFINITY;
+      b[1] = j0 + 1 < p.N ? S.btab[qoff - ko.y] * 1.4426950408889634f : -INFINITY;
+      b[2] = j0 + 2 < p.N ? S.btab[qoff - ko.z] * 1.4426950408889634f : -INFINITY;
+      b[3] = j0 + 3 < p.N ? S.btab[qoff - ko.w] * 1.4426950408889634f : -INFINITY;
+      return b;
+    }
+  };
   __syncthreads();
 #pragma unroll
   for (int kt = 0; kt < MT; ++kt) {
     dbacc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (BREG) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int jj = kt * 16 + gq * 4 + r;
-      breg[kt][r] = (kt < ntile && jj < p.N) ? S.btab[qoff - S.koff[jj]] * 1.4426950408889634f : -INFINITY;   // window-invariant bias slice, log2 domain
+      for (int r = 0; r < 4; ++r) {
+        const int jj = kt * 16 + gq * 4 + r;
+        breg[kt][r] = (kt < ntile && jj < p.N) ? S.btab[qoff - S.koff[jj]] * 1.4426950408889634f : -INFINITY;   // window-invariant bias slice, log2 domain
+      }
     }
   }
 
@@ -365,7 +416,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dq_kernel(WinP 
     const float gate = qval ? 1.f : 0.f;                 // lanes of padded queries contribute nothing
     {
 #pragma unroll
-      for (int t2 = 0; t2 < MT / 2; ++t2) {
+      for (int t2 = 0; t2 < MTP / 2; ++t2) {
         if (t2 * 2 < ntile) {
           f32x4 ds[2];
 #pragma unroll
@@ -377,9 +428,10 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dq_kernel(WinP 
               const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + (kt * 16 + lq) * RS + gq * 8);
               const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
               const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+              const f32x4 bt = bias_tile(kt);
               f32x4 sv;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) sv[r] = fmaf(a[r], scale * 1.4426950408889634f, breg[kt][r]);   // log2 domain; -inf on padded keys
+              for (int r = 0; r < 4; ++r) sv[r] = fmaf(a[r], scale * 1.4426950408889634f, bt[r]);   // log2 domain; -inf on padded keys
               if (border) {
                 const int4 kg = *reinterpret_cast<const int4*>(S.kreg + kt * 16 + gq * 4);
                 sv[0] = kg.x != qreg ? sv[0] - 144.26950408889634f : sv[0];
@@ -398,7 +450,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dq_kernel(WinP 
           const bf16x8 dsf = pack8(ds[0], ds[1]);
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt)
-            dqacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Kt, dt * 16 + lq, 2 * t2, gq), dsf, dqacc[dt], 0, 0, 0);
+            dqacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<MTT>(Kt, dt * 16 + lq, 2 * t2, gq), dsf, dqacc[dt], 0, 0, 0);
         }
       }
     }
@@ -426,18 +478,21 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dq_kernel(WinP 
 }
 
 // ================================================================ backward pass B: dK, dV ======================
-template <int MAXC, int NTC = 0>   // MAXC: 16-byte staging chunks per thread; NTC: key/query tiles if known at compile time (9 for 12x12 windows)
-__global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dkv_kernel(WinP p) {
+// MAXC: 16-byte staging chunks per thread; NTC: key/query tiles if known at compile time (9 for 12x12 windows);
+// MTT: tile capacity (10 / 21); BREG: window-invariant bias slice in registers (else LDS look-ups per score)
+template <int MAXC, int NTC = 0, int MTT = 10, bool BREG = true>
+__global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dkv_kernel(WinP p) {
+  WIN_DIMS(MTT);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nb = (2 * p.ws - 1) * (2 * p.ws - 1);
-  Smem S = carve(smem, nb, 2, 2);
+  Smem S = carve<MTT>(smem, nb, 2, 2);
   bf16* Qs = S.a0; bf16* dOs = S.a1; bf16* Qt = S.t0; bf16* dOt = S.t1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gq = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y, C = p.C, ld = 3 * C;
   const int qo = p.hmajor ? h * 96 : h * 32, ko = p.hmajor ? h * 96 + 32 : C + h * 32, vo = p.hmajor ? h * 96 + 64 : 2 * C + h * 32;
   const int ntile = NTC ? NTC : (p.N + 15) >> 4;      // compile-time for the 12x12 window: guards fold, the 10th tile's code disappears
-  setup(p, S, h, nb, 2, 2);
+  setup<MTT>(p, S, h, nb, 2, 2);
   int spr[MAXC], spc[MAXC];
   bool sval[MAXC];
 #pragma unroll
@@ -458,14 +513,30 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dkv_kernel(WinP
   const int g0 = blockIdx.x * p.gpb, g1 = min(p.G, g0 + p.gpb);
   if (g0 >= g1) return;
   __syncthreads();
-  f32x4 breg[MT];                                       // window-invariant bias slice of this key strip
-#pragma unroll
-  for (int qt = 0; qt < MT; ++qt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ii = qt * 16 + gq * 4 + r;
-      breg[qt][r] = (qt < ntile && ii < p.N) ? S.btab[S.koff[ii] + kconst] * 1.4426950408889634f : 0.f;   // log2 domain
+  f32x4 breg[BREG ? MT : 1];                            // window-invariant bias slice of this key strip
+  auto bias_tile = [&](int qt) -> f32x4 {                 // log2 domain, 0 on padded queries (their lse is +inf)
+    if constexpr (BREG) {
+      return breg[qt];
+    } else {
+      const int4 ko = *reinterpret_cast<const int4*>(S.koff + qt * 16 + gq * 4);
+      const int i0 = qt * 16 + gq * 4;
+      f32x4 b;
+      b[0] = i0 + 0 < p.N ? S.btab[ko.x + kconst] * 1.4426950408889634f : 0.f;
+      b[1] = i0 + 1 < p.N ? S.btab[ko.y + kconst] * 1.4426950408889634f : 0.f;
+      b[2] = i0 + 2 < p.N ? S.btab[ko.z + kconst] * 1.4426950408889634f : 0.f;
+      b[3] = i0 + 3 < p.N ? S.btab[ko.w + kconst] * 1.4426950408889634f : 0.f;
+      return b;
     }
+  };
+  if constexpr (BREG) {
+#pragma unroll
+    for (int qt = 0; qt < MT; ++qt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ii = qt * 16 + gq * 4 + r;
+        breg[qt][r] = (qt < ntile && ii < p.N) ? S.btab[S.koff[ii] + kconst] * 1.4426950408889634f : 0.f;   // log2 domain
+      }
+  }
   Geo geo;
   geo.set(p, g0);
   bf16x8 qr[MAXC], dr[MAXC], kn, vn;
@@ -515,7 +586,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dkv_kernel(WinP
     const float gate = kval ? 1.f : 0.f;                 // lanes of padded keys contribute nothing
     {
 #pragma unroll
-      for (int t2 = 0; t2 < MT / 2; ++t2) {
+      for (int t2 = 0; t2 < MTP / 2; ++t2) {
         if (t2 * 2 < ntile) {
           f32x4 ds[2], pd[2];
 #pragma unroll
@@ -531,9 +602,10 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dkv_kernel(WinP
               const float4 l4 = *reinterpret_cast<const float4*>(S.lse + qt * 16 + gq * 4);
               const float4 d4 = *reinterpret_cast<const float4*>(S.dlt + qt * 16 + gq * 4);
               const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+              const f32x4 bt = bias_tile(qt);
               f32x4 sv;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) sv[r] = fmaf(a[r], scale * 1.4426950408889634f, breg[qt][r]);
+              for (int r = 0; r < 4; ++r) sv[r] = fmaf(a[r], scale * 1.4426950408889634f, bt[r]);
               if (border) {
                 const int4 qg = *reinterpret_cast<const int4*>(S.kreg + qt * 16 + gq * 4);
                 sv[0] = qg.x != kreg ? sv[0] - 144.26950408889634f : sv[0];
@@ -552,8 +624,8 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 256) void win_bwd_dkv_kernel(WinP
           const bf16x8 dsf = pack8(ds[0], ds[1]), pf = pack8(pd[0], pd[1]);
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt) {
-            dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Qt, dt * 16 + lq, 2 * t2, gq), dsf, dkacc[dt], 0, 0, 0);
-            dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(dOt, dt * 16 + lq, 2 * t2, gq), pf, dvacc[dt], 0, 0, 0);
+            dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<MTT>(Qt, dt * 16 + lq, 2 * t2, gq), dsf, dkacc[dt], 0, 0, 0);
+            dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<MTT>(dOt, dt * 16 + lq, 2 * t2, gq), pf, dvacc[dt], 0, 0, 0);
           }
         }
       }
@@ -608,16 +680,20 @@ void ensure_attrs() {
   hipFuncSetAttribute((const void*)win_fwd_kernel<1, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   hipFuncSetAttribute((const void*)win_bwd_dq_kernel<1, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   hipFuncSetAttribute((const void*)win_bwd_dkv_kernel<1, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)win_fwd_kernel<3, 0, 21, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)win_bwd_dq_kernel<3, 0, 21, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)win_bwd_dkv_kernel<3, 0, 21, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   attrs_set = true;
 }
 
 // waves per workgroup / strip groups: small workgroups (<= 4 waves) so that several co-reside on a CU and one group's
 // barrier / staging phases overlap the others' MFMA phases (one 9-wave workgroup per CU left the CU idle at barriers)
 void strip_geometry(int N, int& nw, int& sg) {
-  // One workgroup per (window run, head) with one wave per 16-query strip: each thread stages exactly one 16-byte chunk
-  // (MAXC = 1).  A split into <=4-wave strip groups (MAXC = 3, several workgroups per CU) measured no faster.
-  nw = cdiv(N, 16);
-  sg = 1;
+  // N <= 160: one workgroup per (window run, head) with one wave per 16-query strip: each thread stages exactly one 16-byte
+  // chunk (MAXC = 1).  A split into <=4-wave strip groups (MAXC = 3, several workgroups per CU) measured no faster.
+  // 160 < N <= 336 (18x18 windows: 21 strips): strip groups of 7 waves, each staging the whole window (MAXC = 3).
+  if (N <= 160) { nw = cdiv(N, 16); sg = 1; }
+  else { nw = 7; sg = cdiv(cdiv(N, 16), 7); }
 }
 
 // which kernels use the compile-time tile count for 12x12 windows (bit 0 forward, 1 dQ pass, 2 dK/dV pass).  Measured at
@@ -638,13 +714,17 @@ int blocks_for(int G, int heads) {
   return nz > G ? G : nz;
 }
 
+bool big_window(int N) { return N > 160; }
+
 WinP make(const void* qkv, int B, int Hres, int Wres, int C, int heads, int ws, int shift, int hmajor) {
   WinP p{};
   p.qkv = (const bf16*)qkv;
   p.B = B; p.Hres = Hres; p.Wres = Wres; p.C = C; p.heads = heads; p.ws = ws; p.shift = shift;
   p.hmajor = hmajor;
   p.nWw = Wres / ws; p.nWh = Hres / ws; p.nW = p.nWw * p.nWh; p.G = B * p.nW; p.N = ws * ws;
-  const int nz = blocks_for(p.G, heads);
+  int nw, sg;
+  strip_geometry(p.N, nw, sg);
+  const int nz = blocks_for(p.G, heads * sg);            // about one workgroup per CU in total
   p.gpb = cdiv(p.G, nz);
   return p;
 }
@@ -660,8 +740,9 @@ int fiber_win_fwd_launch(const void* qkv, const float* bias_table, void* o, floa
   const int nb = (2 * ws - 1) * (2 * ws - 1);
   int nw, sg;
   strip_geometry(p.N, nw, sg);
-  if (p.N == 144 && (ntc_mask() & 1)) hipLaunchKernelGGL((win_fwd_kernel<1, 9>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes(nb, 1, 1), st, p);
-  else hipLaunchKernelGGL((win_fwd_kernel<1, 0>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes(nb, 1, 1), st, p);
+  if (big_window(p.N)) hipLaunchKernelGGL((win_fwd_kernel<3, 0, 21, false>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 1, 1), st, p);
+  else if (p.N == 144 && (ntc_mask() & 1)) hipLaunchKernelGGL((win_fwd_kernel<1, 9>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 1, 1), st, p);
+  else hipLaunchKernelGGL((win_fwd_kernel<1, 0>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 1, 1), st, p);
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }
@@ -686,14 +767,16 @@ int fiber_win_bwd_launch(const void* qkv, const float* bias_table, const void* o
   hipLaunchKernelGGL(win_delta_kernel, dim3((int)(g > 4096 ? 4096 : g)), dim3(256), 0, st, (const bf16*)o, (const bf16*)dout, delta_ws, nvec, heads);
   FIBER_CHECK_LAUNCH();
   const int gz = cdiv(p.G, p.gpb);
-  if (p.N == 144 && (ntc_mask() & 2)) hipLaunchKernelGGL((win_bwd_dq_kernel<1, 9>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes(nb, 2, 1), st, p);
-  else hipLaunchKernelGGL((win_bwd_dq_kernel<1, 0>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes(nb, 2, 1), st, p);
+  if (big_window(p.N)) hipLaunchKernelGGL((win_bwd_dq_kernel<3, 0, 21, false>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2, 1), st, p);
+  else if (p.N == 144 && (ntc_mask() & 2)) hipLaunchKernelGGL((win_bwd_dq_kernel<1, 9>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2, 1), st, p);
+  else hipLaunchKernelGGL((win_bwd_dq_kernel<1, 0>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2, 1), st, p);
   FIBER_CHECK_LAUNCH();
   if (hipMemsetAsync(dbias_table, 0, (size_t)nb * heads * sizeof(float), st) != hipSuccess) return FIBER_ELAUNCH;
   hipLaunchKernelGGL(win_dbias_scatter_kernel, dim3(p.N, heads), dim3(256), 0, st, dbias_ws, dbias_table, gz, heads, ws);
   FIBER_CHECK_LAUNCH();
-  if (p.N == 144 && (ntc_mask() & 4)) hipLaunchKernelGGL((win_bwd_dkv_kernel<1, 9>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes(nb, 2, 2), st, p);
-  else hipLaunchKernelGGL((win_bwd_dkv_kernel<1, 0>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes(nb, 2, 2), st, p);
+  if (big_window(p.N)) hipLaunchKernelGGL((win_bwd_dkv_kernel<3, 0, 21, false>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2, 2), st, p);
+  else if (p.N == 144 && (ntc_mask() & 4)) hipLaunchKernelGGL((win_bwd_dkv_kernel<1, 9>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2, 2), st, p);
+  else hipLaunchKernelGGL((win_bwd_dkv_kernel<1, 0>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2, 2), st, p);
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }
