@@ -54,6 +54,20 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16* tr, int d, int t0, int g) 
   for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi[e]; }
   return o;
 }
+// Same operand out of a ROW-MAJOR [token][32] image (row stride RS): ds_read_b64_tr_b16 hands lane l of a 16-lane group
+// column l of the 4x16 block whose (row l>>2, 4-column piece l&3) address that lane supplies, so the transposed copy of the
+// image never has to be written (8 ds_write_b16 per staged chunk less).
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ bf16x8 trr_frag(const bf16* rm, int d0, int t0, int g, int l) {
+  const bf16* a = rm + (t0 * 16 + g * 4 + (l >> 2)) * RS + d0 + (l & 3) * 4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + 16 * RS));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi[e]; }
+  return __builtin_bit_cast(bf16x8, o);
+}
 __device__ __forceinline__ bf16x8 zero8() {
   bf16x8 z;
 #pragma unroll
@@ -140,14 +154,14 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
   WIN_DIMS(MTT);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nb = (2 * p.ws - 1) * (2 * p.ws - 1);
-  Smem S = carve<MTT>(smem, nb, 1, 1);
-  bf16* Ks = S.a0; bf16* Vt = S.t0;
+  Smem S = carve<MTT>(smem, nb, 2, 0);
+  bf16* Ks = S.a0; bf16* Vs = S.a1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gq = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y, C = p.C, ld = 3 * C;
   const int qo = p.hmajor ? h * 96 : h * 32, ko = p.hmajor ? h * 96 + 32 : C + h * 32, vo = p.hmajor ? h * 96 + 64 : 2 * C + h * 32;
   const int ntile = NTC ? NTC : (p.N + 15) >> 4;      // compile-time for the 12x12 window: guards fold, the 10th tile's code disappears
-  setup<MTT>(p, S, h, nb, 1, 1);
+  setup<MTT>(p, S, h, nb, 2, 0);
 
   // this thread's staging chunks: chunk id = tid + c*blockDim -> (row = id>>2 of the window, 16-byte piece id&3)
   int spr[MAXC], spc[MAXC];
@@ -223,8 +237,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
       if (sval[c]) {
         const int id = tid + c * blockDim.x, sr = id >> 2, sc = id & 3;
         *reinterpret_cast<bf16x8*>(Ks + sr * RS + sc * 8) = kr[c];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) Vt[(sc * 8 + e) * TS + sr] = vr[c][e];
+        *reinterpret_cast<bf16x8*>(Vs + sr * RS + sc * 8) = vr[c];
       }
     }
     const bool border = geo.border;
@@ -285,7 +298,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
           const bf16x8 pf = pack8(s[2 * t2], s[2 * t2 + 1]);
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt)
-            oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<MTT>(Vt, dt * 16 + lq, 2 * t2, gq), pf, oacc[dt], 0, 0, 0);
+            oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trr_frag(Vs, dt * 16, 2 * t2, gq, lq), pf, oacc[dt], 0, 0, 0);
         }
       }
     }
@@ -311,14 +324,14 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
   WIN_DIMS(MTT);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nb = (2 * p.ws - 1) * (2 * p.ws - 1);
-  Smem S = carve<MTT>(smem, nb, 2, 1);
-  bf16* Ks = S.a0; bf16* Vs = S.a1; bf16* Kt = S.t0;
+  Smem S = carve<MTT>(smem, nb, 2, 0);
+  bf16* Ks = S.a0; bf16* Vs = S.a1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gq = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y, C = p.C, ld = 3 * C;
   const int qo = p.hmajor ? h * 96 : h * 32, ko = p.hmajor ? h * 96 + 32 : C + h * 32, vo = p.hmajor ? h * 96 + 64 : 2 * C + h * 32;
   const int ntile = NTC ? NTC : (p.N + 15) >> 4;      // compile-time for the 12x12 window: guards fold, the 10th tile's code disappears
-  setup<MTT>(p, S, h, nb, 2, 1);
+  setup<MTT>(p, S, h, nb, 2, 0);
   int spr[MAXC], spc[MAXC];
   bool sval[MAXC];
 #pragma unroll
@@ -396,8 +409,6 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
         const int id = tid + c * blockDim.x, sr = id >> 2, sc = id & 3;
         *reinterpret_cast<bf16x8*>(Ks + sr * RS + sc * 8) = kr[c];
         *reinterpret_cast<bf16x8*>(Vs + sr * RS + sc * 8) = vr[c];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) Kt[(sc * 8 + e) * TS + sr] = kr[c][e];
       }
     }
     const bool border = geo.border;
@@ -450,7 +461,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
           const bf16x8 dsf = pack8(ds[0], ds[1]);
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt)
-            dqacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<MTT>(Kt, dt * 16 + lq, 2 * t2, gq), dsf, dqacc[dt], 0, 0, 0);
+            dqacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trr_frag(Ks, dt * 16, 2 * t2, gq, lq), dsf, dqacc[dt], 0, 0, 0);
         }
       }
     }
@@ -485,14 +496,14 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dkv_kernel(WinP
   WIN_DIMS(MTT);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nb = (2 * p.ws - 1) * (2 * p.ws - 1);
-  Smem S = carve<MTT>(smem, nb, 2, 2);
-  bf16* Qs = S.a0; bf16* dOs = S.a1; bf16* Qt = S.t0; bf16* dOt = S.t1;
+  Smem S = carve<MTT>(smem, nb, 2, 0);
+  bf16* Qs = S.a0; bf16* dOs = S.a1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gq = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y, C = p.C, ld = 3 * C;
   const int qo = p.hmajor ? h * 96 : h * 32, ko = p.hmajor ? h * 96 + 32 : C + h * 32, vo = p.hmajor ? h * 96 + 64 : 2 * C + h * 32;
   const int ntile = NTC ? NTC : (p.N + 15) >> 4;      // compile-time for the 12x12 window: guards fold, the 10th tile's code disappears
-  setup<MTT>(p, S, h, nb, 2, 2);
+  setup<MTT>(p, S, h, nb, 2, 0);
   int spr[MAXC], spc[MAXC];
   bool sval[MAXC];
 #pragma unroll
@@ -565,8 +576,6 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dkv_kernel(WinP
         const int id = tid + c * blockDim.x, sr = id >> 2, sc = id & 3;
         *reinterpret_cast<bf16x8*>(Qs + sr * RS + sc * 8) = qr[c];
         *reinterpret_cast<bf16x8*>(dOs + sr * RS + sc * 8) = dr[c];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { Qt[(sc * 8 + e) * TS + sr] = qr[c][e]; dOt[(sc * 8 + e) * TS + sr] = dr[c][e]; }
         if (sc == 0) { S.lse[sr] = lser[c] * 1.4426950408889634f; S.dlt[sr] = dltr[c]; }   // lse staged in the log2 domain
       }
     }
@@ -624,8 +633,8 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dkv_kernel(WinP
           const bf16x8 dsf = pack8(ds[0], ds[1]), pf = pack8(pd[0], pd[1]);
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt) {
-            dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<MTT>(Qt, dt * 16 + lq, 2 * t2, gq), dsf, dkacc[dt], 0, 0, 0);
-            dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<MTT>(dOt, dt * 16 + lq, 2 * t2, gq), pf, dvacc[dt], 0, 0, 0);
+            dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trr_frag(Qs, dt * 16, 2 * t2, gq, lq), dsf, dkacc[dt], 0, 0, 0);
+            dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trr_frag(dOs, dt * 16, 2 * t2, gq, lq), pf, dvacc[dt], 0, 0, 0);
           }
         }
       }
@@ -740,9 +749,9 @@ int fiber_win_fwd_launch(const void* qkv, const float* bias_table, void* o, floa
   const int nb = (2 * ws - 1) * (2 * ws - 1);
   int nw, sg;
   strip_geometry(p.N, nw, sg);
-  if (big_window(p.N)) hipLaunchKernelGGL((win_fwd_kernel<3, 0, 21, false>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 1, 1), st, p);
-  else if (p.N == 144 && (ntc_mask() & 1)) hipLaunchKernelGGL((win_fwd_kernel<1, 9>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 1, 1), st, p);
-  else hipLaunchKernelGGL((win_fwd_kernel<1, 0>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 1, 1), st, p);
+  if (big_window(p.N)) hipLaunchKernelGGL((win_fwd_kernel<3, 0, 21, false>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2, 0), st, p);
+  else if (p.N == 144 && (ntc_mask() & 1)) hipLaunchKernelGGL((win_fwd_kernel<1, 9>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2, 0), st, p);
+  else hipLaunchKernelGGL((win_fwd_kernel<1, 0>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2, 0), st, p);
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }
@@ -767,16 +776,16 @@ int fiber_win_bwd_launch(const void* qkv, const float* bias_table, const void* o
   hipLaunchKernelGGL(win_delta_kernel, dim3((int)(g > 4096 ? 4096 : g)), dim3(256), 0, st, (const bf16*)o, (const bf16*)dout, delta_ws, nvec, heads);
   FIBER_CHECK_LAUNCH();
   const int gz = cdiv(p.G, p.gpb);
-  if (big_window(p.N)) hipLaunchKernelGGL((win_bwd_dq_kernel<3, 0, 21, false>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2, 1), st, p);
-  else if (p.N == 144 && (ntc_mask() & 2)) hipLaunchKernelGGL((win_bwd_dq_kernel<1, 9>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2, 1), st, p);
-  else hipLaunchKernelGGL((win_bwd_dq_kernel<1, 0>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2, 1), st, p);
+  if (big_window(p.N)) hipLaunchKernelGGL((win_bwd_dq_kernel<3, 0, 21, false>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2, 0), st, p);
+  else if (p.N == 144 && (ntc_mask() & 2)) hipLaunchKernelGGL((win_bwd_dq_kernel<1, 9>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2, 0), st, p);
+  else hipLaunchKernelGGL((win_bwd_dq_kernel<1, 0>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2, 0), st, p);
   FIBER_CHECK_LAUNCH();
   if (hipMemsetAsync(dbias_table, 0, (size_t)nb * heads * sizeof(float), st) != hipSuccess) return FIBER_ELAUNCH;
   hipLaunchKernelGGL(win_dbias_scatter_kernel, dim3(p.N, heads), dim3(256), 0, st, dbias_ws, dbias_table, gz, heads, ws);
   FIBER_CHECK_LAUNCH();
-  if (big_window(p.N)) hipLaunchKernelGGL((win_bwd_dkv_kernel<3, 0, 21, false>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2, 2), st, p);
-  else if (p.N == 144 && (ntc_mask() & 4)) hipLaunchKernelGGL((win_bwd_dkv_kernel<1, 9>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2, 2), st, p);
-  else hipLaunchKernelGGL((win_bwd_dkv_kernel<1, 0>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2, 2), st, p);
+  if (big_window(p.N)) hipLaunchKernelGGL((win_bwd_dkv_kernel<3, 0, 21, false>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2, 0), st, p);
+  else if (p.N == 144 && (ntc_mask() & 4)) hipLaunchKernelGGL((win_bwd_dkv_kernel<1, 9>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2, 0), st, p);
+  else hipLaunchKernelGGL((win_bwd_dkv_kernel<1, 0>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2, 0), st, p);
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }
