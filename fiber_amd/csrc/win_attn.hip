@@ -258,26 +258,58 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
     float mx = -INFINITY, sum;
     f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     {
+      // Explicit software pipeline: the compiler's own schedule put every ds_read right before the MFMA that consumes it
+      // (s_waitcnt lgkmcnt(0) per tile), and with ~2 waves per SIMD nothing hid that latency.  All K fragments are
+      // requested first, the MT independent QK^T MFMAs issue back to back, and the V^T fragments are requested before the
+      // exp2 pass so that they land while the VALU works.  Padded tiles read zero rows (harmless) and carry bias = -inf.
+      constexpr int GK = (NTC || MT > 10) ? 5 : 3, NG = (MT + GK - 1) / GK;        // K fragments in flight: GK tiles ahead of the MFMAs
+      constexpr int VE = MT > 10 ? 0 : (NTC ? 3 : 1);                // V^T tile pairs requested before the exp2 pass
+      bf16x8 kf[2][GK];
+#pragma unroll
+      for (int u = 0; u < GK; ++u) kf[0][u] = *reinterpret_cast<const bf16x8*>(Ks + (u * 16 + lq) * RS + gq * 8);
+#pragma unroll
+      for (int gi = 0; gi < NG; ++gi) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (gi + 1 < NG)
+#pragma unroll
+          for (int u = 0; u < GK; ++u)
+            if ((gi + 1) * GK + u < MT) kf[(gi + 1) & 1][u] = *reinterpret_cast<const bf16x8*>(Ks + (((gi + 1) * GK + u) * 16 + lq) * RS + gq * 8);
+#pragma unroll
+        for (int u = 0; u < GK; ++u) {
+          const int kt = gi * GK + u;
+          if (kt < MT && kt < ntile) s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[gi & 1][u], qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);   // S^T[key][query]
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 vf[MTP / 2][2];
+#pragma unroll
+      for (int t2 = 0; t2 < VE; ++t2)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) vf[t2][dt] = trr_frag(Vs, dt * 16, 2 * t2, gq, lq);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kt = 0; kt < MT; ++kt) {
         if (kt < ntile) {
-          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 16 + lq) * RS + gq * 8);
-          const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);   // S^T[key][query]
           const f32x4 bt = bias_tile(kt);
-          f32x4 v;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaf(a[r], scale2, bt[r]);
-          if (border) {
-            const int4 kg = *reinterpret_cast<const int4*>(S.kreg + kt * 16 + gq * 4);
-            v[0] = kg.x != qreg ? v[0] - 144.26950408889634f : v[0];     // -100 * log2(e)
-            v[1] = kg.y != qreg ? v[1] - 144.26950408889634f : v[1];
-            v[2] = kg.z != qreg ? v[2] - 144.26950408889634f : v[2];
-            v[3] = kg.w != qreg ? v[3] - 144.26950408889634f : v[3];
-          }
-          s[kt] = v;
-          mx = fmaxf(mx, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+          for (int r = 0; r < 4; ++r) s[kt][r] = fmaf(s[kt][r], scale2, bt[r]);
         }
       }
+      if (border) {                                       // one wave-uniform branch per window (swin_transformer.py:327-350)
+#pragma unroll
+        for (int kt = 0; kt < MT; ++kt) {
+          if (kt < ntile) {
+            const int4 kg = *reinterpret_cast<const int4*>(S.kreg + kt * 16 + gq * 4);
+            s[kt][0] = kg.x != qreg ? s[kt][0] - 144.26950408889634f : s[kt][0];     // -100 * log2(e)
+            s[kt][1] = kg.y != qreg ? s[kt][1] - 144.26950408889634f : s[kt][1];
+            s[kt][2] = kg.z != qreg ? s[kt][2] - 144.26950408889634f : s[kt][2];
+            s[kt][3] = kg.w != qreg ? s[kt][3] - 144.26950408889634f : s[kt][3];
+          }
+        }
+      }
+#pragma unroll
+      for (int kt = 0; kt < MT; ++kt)
+        if (kt < ntile) mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
       mx = g4max(mx);
       float s0 = 0.f, s1 = 0.f;
 #pragma unroll
@@ -294,11 +326,15 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
       sum = g4sum(s0 + s1);
 #pragma unroll
       for (int t2 = 0; t2 < MTP / 2; ++t2) {
+        if (t2 + VE < MTP / 2) {                           // keep VE pairs of V^T fragments ahead of the PV MFMAs
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) vf[t2 + VE][dt] = trr_frag(Vs, dt * 16, 2 * (t2 + VE), gq, lq);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         if (t2 * 2 < ntile) {
           const bf16x8 pf = pack8(s[2 * t2], s[2 * t2 + 1]);
 #pragma unroll
-          for (int dt = 0; dt < 2; ++dt)
-            oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trr_frag(Vs, dt * 16, 2 * t2, gq, lq), pf, oacc[dt], 0, 0, 0);
+          for (int dt = 0; dt < 2; ++dt) oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[t2][dt], pf, oacc[dt], 0, 0, 0);
         }
       }
     }
