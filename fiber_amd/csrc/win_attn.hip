@@ -75,6 +75,13 @@ __device__ __forceinline__ bf16x8 zero8() {
   return z;
 }
 
+// uniform base pointer + 32-bit BYTE offset: the form the backend turns into `global_load/store v, voff, s[base:base+1]`
+template <typename T>
+__device__ __forceinline__ T* at(T* base, unsigned elem_off) {
+  using C = std::conditional_t<std::is_const<T>::value, const char, char>;
+  return reinterpret_cast<T*>(reinterpret_cast<C*>(base) + elem_off * (unsigned)sizeof(T));
+}
+
 // window g, window-local (pr,pc) -> token row of the [B*H*W] tensors and shift-mask region label
 struct Geo {
   int b, wr, wc;
@@ -91,12 +98,15 @@ struct Geo {
     if (++wc == p.nWw) { wc = 0; if (++wr == p.nWh) { wr = 0; ++b; } }
     border = p.shift > 0 && (wr == p.nWh - 1 || wc == p.nWw - 1);
   }
-  __device__ __forceinline__ int tok(const WinP& p, int pr, int pc) const {
+  // Token row = img() + pix(): the image base is wave-uniform (scalar 64-bit pointer arithmetic), the pixel offset is a
+  // 32-bit per-lane value, so every global access is `saddr + 32-bit voffset` and no lane carries 64-bit addresses.
+  __device__ __forceinline__ unsigned pix(const WinP& p, int pr, int pc) const {
     int r = wr * p.ws + pr + p.shift, c = wc * p.ws + pc + p.shift;
     r = r >= p.Hres ? r - p.Hres : r;
     c = c >= p.Wres ? c - p.Wres : c;
-    return (b * p.Hres + r) * p.Wres + c;
+    return (unsigned)(r * p.Wres + c);
   }
+  __device__ __forceinline__ size_t img(const WinP& p) const { return (size_t)b * p.Hres * p.Wres; }
   __device__ __forceinline__ int reg(const WinP& p, int pr, int pc) const {
     return region_of(wr * p.ws + pr, p.Hres, p.ws, p.shift) * 3 + region_of(wc * p.ws + pc, p.Wres, p.ws, p.shift);
   }
@@ -138,7 +148,7 @@ __device__ __forceinline__ void setup(const WinP& p, const Smem& S, int h, int n
     const int pr = jj / p.ws, pc = jj - pr * p.ws;
     S.koff[j] = pr * (2 * p.ws - 1) + pc;
     S.kreg[j] = 0;
-    S.lse[j] = INFINITY;
+    S.lse[j] = -INFINITY;                              // dK/dV pass: staged as -lse/scale (accumulator seed); padded queries -> exp2(-inf) = 0
     S.dlt[j] = 0.f;
   }
   const int words = (n_rm * MAXN * RS + n_tr * 32 * TS) / 2;
@@ -216,18 +226,20 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
   Geo geo;
   geo.set(p, g0);
   bf16x8 kr[MAXC], vr[MAXC], qn;
-  int qtok = geo.tok(p, qpr, qpc);
+  unsigned qpix = geo.pix(p, qpr, qpc);
+  size_t qimg = geo.img(p);
   auto prefetch = [&]() {
+    const bf16* base = p.qkv + qimg * ld;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
       if (sval[c]) {
-        const int sc = (tid + c * blockDim.x) & 3;
-        const int st = geo.tok(p, spr[c], spc[c]);
-        kr[c] = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + ko + sc * 8);
-        vr[c] = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + vo + sc * 8);
+        const unsigned sc = (tid + c * blockDim.x) & 3;
+        const unsigned st = geo.pix(p, spr[c], spc[c]) * ld + sc * 8;
+        kr[c] = *reinterpret_cast<const bf16x8*>(at(base, st + ko));
+        vr[c] = *reinterpret_cast<const bf16x8*>(at(base, st + vo));
       }
     }
-    qn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)qtok * ld + qo + gq * 8);
+    qn = *reinterpret_cast<const bf16x8*>(at(base, qpix * ld + qo + gq * 8));
   };
   prefetch();
   for (int g = g0; g < g1; ++g) {
@@ -244,11 +256,13 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
     if (border) for (int t = tid; t < p.N; t += blockDim.x) { const int pr = t / p.ws; S.kreg[t] = geo.reg(p, pr, t - pr * p.ws); }
     const int qreg = border ? geo.reg(p, qpr, qpc) : 0;
     const bf16x8 qf = qn;
-    const int otok = qtok;
+    const unsigned opix = qpix;
+    const size_t oimg = qimg;
     __syncthreads();
     if (g + 1 < g1) {                                  // prefetch next window while this one computes
       geo.next(p);
-      qtok = geo.tok(p, qpr, qpc);
+      qpix = geo.pix(p, qpr, qpc);
+      qimg = geo.img(p);
       prefetch();
     }
     // The body is instantiated twice (BORDER true/false) and selected by a wave-uniform branch per window: only windows
@@ -345,9 +359,9 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
         bf16x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = f2bf(oacc[dt][r] * inv);
-        *reinterpret_cast<bf16x4*>(p.o + (size_t)otok * C + h * 32 + dt * 16 + gq * 4) = o;
+        *reinterpret_cast<bf16x4*>(at(p.o + oimg * C, opix * C + h * 32 + dt * 16 + gq * 4)) = o;
       }
-      if (gq == 0) p.lse[(size_t)otok * p.heads + h] = mx * 0.6931471805599453f + __logf(sum);
+      if (gq == 0) *at(p.lse + oimg * p.heads, opix * p.heads + h) = mx * 0.6931471805599453f + __logf(sum);
     }
   }
 }
@@ -384,18 +398,22 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
   const int qoff = (qpr + p.ws - 1) * (2 * p.ws - 1) + qpc + p.ws - 1;
   const float scale = 0.17677669529663687f;
 
-  f32x4 dbacc[MTP], breg[BREG ? MT : 1];
-  auto bias_tile = [&](int kt) -> f32x4 {                 // log2 domain, -inf on padded keys
+  // BREG: this lane's window-invariant bias slice lives in an LDS slab ([wave][tile][lane] x f32x4, one conflict-free
+  // ds_read_b128 per tile) -- this kernel also carries the dbias accumulators, and 36 more registers for the slice left
+  // nothing for keeping LDS operands in flight.
+  f32x4* slab = reinterpret_cast<f32x4*>(S.a1 + MAXN * RS) + wave * MT * 64 + lane;
+  f32x4 dbacc[MTP];
+  auto bias_tile = [&](int kt) -> f32x4 {                 // bias / scale (the seed of the q.k accumulator), -inf on padded keys
     if constexpr (BREG) {
-      return breg[kt];
+      return slab[kt * 64];
     } else {
       const int4 ko = *reinterpret_cast<const int4*>(S.koff + kt * 16 + gq * 4);
       const int j0 = kt * 16 + gq * 4;
       f32x4 b;
-      b[0] = j0 + 0 < p.N ? S.btab[qoff - ko.x] * 1.4426950408889634f : -INFINITY;
-      b[1] = j0 + 1 < p.N ? S.btab[qoff - ko.y] * 1.4426950408889634f : -INFINITY;
-      b[2] = j0 + 2 < p.N ? S.btab[qoff - ko.z] * 1.4426950408889634f : -INFINITY;
-      b[3] = j0 + 3 < p.N ? S.btab[qoff - ko.w] * 1.4426950408889634f : -INFINITY;
+      b[0] = j0 + 0 < p.N ? S.btab[qoff - ko.x] * 5.656854249492381f : -INFINITY;
+      b[1] = j0 + 1 < p.N ? S.btab[qoff - ko.y] * 5.656854249492381f : -INFINITY;
+      b[2] = j0 + 2 < p.N ? S.btab[qoff - ko.z] * 5.656854249492381f : -INFINITY;
+      b[3] = j0 + 3 < p.N ? S.btab[qoff - ko.w] * 5.656854249492381f : -INFINITY;
       return b;
     }
   };
@@ -404,11 +422,13 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
   for (int kt = 0; kt < MT; ++kt) {
     dbacc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (BREG) {
+      f32x4 b;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int jj = kt * 16 + gq * 4 + r;
-        breg[kt][r] = (kt < ntile && jj < p.N) ? S.btab[qoff - S.koff[jj]] * 1.4426950408889634f : -INFINITY;   // window-invariant bias slice, log2 domain
+        b[r] = (kt < ntile && jj < p.N) ? S.btab[qoff - S.koff[jj]] * 5.656854249492381f : -INFINITY;   // window-invariant bias slice
       }
+      slab[kt * 64] = b;                                  // read back by the same lane only: no barrier needed
     }
   }
 
@@ -416,25 +436,28 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
   Geo geo;
   bf16x8 kr[MAXC], vr[MAXC], qn = zero8(), don = zero8();
   float lsen = 0.f, dltn = 0.f;
-  int qtok = 0;
+  unsigned qpix = 0;
+  size_t qimg = 0;
   auto prefetch = [&]() {
+    const bf16* base = p.qkv + qimg * ld;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
       if (sval[c]) {
-        const int sc = (tid + c * blockDim.x) & 3;
-        const int st = geo.tok(p, spr[c], spc[c]);
-        kr[c] = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + ko + sc * 8);
-        vr[c] = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + vo + sc * 8);
+        const unsigned sc = (tid + c * blockDim.x) & 3;
+        const unsigned st = geo.pix(p, spr[c], spc[c]) * ld + sc * 8;
+        kr[c] = *reinterpret_cast<const bf16x8*>(at(base, st + ko));
+        vr[c] = *reinterpret_cast<const bf16x8*>(at(base, st + vo));
       }
     }
-    qn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)qtok * ld + qo + gq * 8);
-    don = *reinterpret_cast<const bf16x8*>(p.dout + (size_t)qtok * C + h * 32 + gq * 8);
-    lsen = p.lse[(size_t)qtok * p.heads + h];
-    dltn = p.delta[(size_t)qtok * p.heads + h];
+    qn = *reinterpret_cast<const bf16x8*>(at(base, qpix * ld + qo + gq * 8));
+    don = *reinterpret_cast<const bf16x8*>(at(p.dout + qimg * C, qpix * C + h * 32 + gq * 8));
+    lsen = *at(p.lse + qimg * p.heads, qpix * p.heads + h);
+    dltn = *at(p.delta + qimg * p.heads, qpix * p.heads + h);
   };
   if (g0 < g1) {
     geo.set(p, g0);
-    qtok = geo.tok(p, qpr, qpc);
+    qpix = geo.pix(p, qpr, qpc);
+    qimg = geo.img(p);
     prefetch();
   }
   for (int g = g0; g < g1; ++g) {
@@ -451,44 +474,65 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
     if (border) for (int t = tid; t < p.N; t += blockDim.x) { const int pr = t / p.ws; S.kreg[t] = geo.reg(p, pr, t - pr * p.ws); }
     const int qreg = border ? geo.reg(p, qpr, qpc) : 0;
     const bf16x8 qf = qn, dof = don;
-    const float lse = lsen * 1.4426950408889634f, dlt = dltn;
-    const int otok = qtok;
+    // Accumulator seeds: q.k + bias/scale and dP - delta come straight out of the MFMAs, log2 p = that * scale*log2e - lse*log2e
+    // is one fma; the lanes of padded queries get lse = +inf so that their p (and with it ds, dbias) is exactly 0.
+    const float nlse = qval ? lsen * -1.4426950408889634f : -INFINITY, dc = -dltn;
+    const f32x4 dseed = {dc, dc, dc, dc};
+    const unsigned opix = qpix;
+    const size_t oimg = qimg;
     __syncthreads();
     if (g + 1 < g1) {
       geo.next(p);
-      qtok = geo.tok(p, qpr, qpc);
+      qpix = geo.pix(p, qpr, qpc);
+      qimg = geo.img(p);
       prefetch();
     }
     f32x4 dqacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    const float gate = qval ? 1.f : 0.f;                 // lanes of padded queries contribute nothing
-    {
+    // Two copies of the body (with / without the shift-mask compares) behind one wave-uniform branch; the LDS operands of a
+    // key-tile pair are requested together (padded tiles read zero rows and carry bias = -inf).
+    auto body = [&](auto border_t) {
+      constexpr bool BORDER = decltype(border_t)::value;
 #pragma unroll
       for (int t2 = 0; t2 < MTP / 2; ++t2) {
         if (t2 * 2 < ntile) {
+          bf16x8 kf[2], vf[2], kt_[2];
+          f32x4 sa[2], sdp[2];
+          int4 kg[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int kt = 2 * t2 + u;
+            kf[u] = *reinterpret_cast<const bf16x8*>(Ks + (kt * 16 + lq) * RS + gq * 8);
+            vf[u] = *reinterpret_cast<const bf16x8*>(Vs + (kt * 16 + lq) * RS + gq * 8);
+            sa[u] = kt < MT ? bias_tile(kt) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (BORDER) kg[u] = *reinterpret_cast<const int4*>(S.kreg + kt * 16 + gq * 4);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            sa[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[u], qf, sa[u], 0, 0, 0);
+            sdp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[u], dof, dseed, 0, 0, 0);
+          }
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) kt_[dt] = trr_frag(Ks, dt * 16, 2 * t2, gq, lq);   // lands during the VALU pass
+          __builtin_amdgcn_sched_barrier(0);
           f32x4 ds[2];
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             const int kt = 2 * t2 + u;
             ds[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (kt < ntile) {
-              const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 16 + lq) * RS + gq * 8);
-              const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + (kt * 16 + lq) * RS + gq * 8);
-              const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-              const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-              const f32x4 bt = bias_tile(kt);
               f32x4 sv;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) sv[r] = fmaf(a[r], scale * 1.4426950408889634f, bt[r]);   // log2 domain; -inf on padded keys
-              if (border) {
-                const int4 kg = *reinterpret_cast<const int4*>(S.kreg + kt * 16 + gq * 4);
-                sv[0] = kg.x != qreg ? sv[0] - 144.26950408889634f : sv[0];
-                sv[1] = kg.y != qreg ? sv[1] - 144.26950408889634f : sv[1];
-                sv[2] = kg.z != qreg ? sv[2] - 144.26950408889634f : sv[2];
-                sv[3] = kg.w != qreg ? sv[3] - 144.26950408889634f : sv[3];
+              for (int r = 0; r < 4; ++r) sv[r] = fmaf(sa[u][r], scale * 1.4426950408889634f, nlse);   // log2 p; -inf on padded keys
+              if constexpr (BORDER) {
+                sv[0] = kg[u].x != qreg ? sv[0] - 144.26950408889634f : sv[0];
+                sv[1] = kg[u].y != qreg ? sv[1] - 144.26950408889634f : sv[1];
+                sv[2] = kg[u].z != qreg ? sv[2] - 144.26950408889634f : sv[2];
+                sv[3] = kg[u].w != qreg ? sv[3] - 144.26950408889634f : sv[3];
               }
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                const float d = __builtin_amdgcn_exp2f(sv[r] - lse) * (dp[r] - dlt) * gate;
+                const float d = __builtin_amdgcn_exp2f(sv[r]) * sdp[u][r];
                 ds[u][r] = d;
                 dbacc[kt][r] += d;
               }
@@ -496,18 +540,18 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
           }
           const bf16x8 dsf = pack8(ds[0], ds[1]);
 #pragma unroll
-          for (int dt = 0; dt < 2; ++dt)
-            dqacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trr_frag(Ks, dt * 16, 2 * t2, gq, lq), dsf, dqacc[dt], 0, 0, 0);
+          for (int dt = 0; dt < 2; ++dt) dqacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_[dt], dsf, dqacc[dt], 0, 0, 0);
         }
       }
-    }
+    };
+    if (border) body(std::true_type{}); else body(std::false_type{});
     if (qval) {
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         bf16x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = f2bf(dqacc[dt][r] * scale);
-        *reinterpret_cast<bf16x4*>(p.dqkv + (size_t)otok * ld + qo + dt * 16 + gq * 4) = o;
+        *reinterpret_cast<bf16x4*>(at(p.dqkv + oimg * ld, opix * ld + qo + dt * 16 + gq * 4)) = o;
       }
     }
   }
@@ -581,27 +625,30 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dkv_kernel(WinP
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ii = qt * 16 + gq * 4 + r;
-        breg[qt][r] = (qt < ntile && ii < p.N) ? S.btab[S.koff[ii] + kconst] * 1.4426950408889634f : 0.f;   // log2 domain
+        // log2 domain; -inf on the lanes of padded keys (they contribute nothing), 0 on padded queries (their seed is -inf)
+        breg[qt][r] = !kval ? -INFINITY : (qt < ntile && ii < p.N) ? S.btab[S.koff[ii] + kconst] * 1.4426950408889634f : 0.f;
       }
   }
   Geo geo;
   geo.set(p, g0);
   bf16x8 qr[MAXC], dr[MAXC], kn, vn;
   float lser[MAXC], dltr[MAXC];
-  int ktok = geo.tok(p, kpr, kpc);
+  unsigned kpix = geo.pix(p, kpr, kpc);
+  size_t kimg = geo.img(p);
   auto prefetch = [&]() {
+    const bf16* base = p.qkv + kimg * ld;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
       if (sval[c]) {
-        const int sc = (tid + c * blockDim.x) & 3;
-        const int st = geo.tok(p, spr[c], spc[c]);
-        qr[c] = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)st * ld + qo + sc * 8);
-        dr[c] = *reinterpret_cast<const bf16x8*>(p.dout + (size_t)st * C + h * 32 + sc * 8);
-        if (sc == 0) { lser[c] = p.lse[(size_t)st * p.heads + h]; dltr[c] = p.delta[(size_t)st * p.heads + h]; }
+        const unsigned sc = (tid + c * blockDim.x) & 3;
+        const unsigned st = geo.pix(p, spr[c], spc[c]);
+        qr[c] = *reinterpret_cast<const bf16x8*>(at(base, st * ld + qo + sc * 8));
+        dr[c] = *reinterpret_cast<const bf16x8*>(at(p.dout + kimg * C, st * C + h * 32 + sc * 8));
+        if (sc == 0) { lser[c] = *at(p.lse + kimg * p.heads, st * p.heads + h); dltr[c] = *at(p.delta + kimg * p.heads, st * p.heads + h); }
       }
     }
-    kn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)ktok * ld + ko + gq * 8);
-    vn = *reinterpret_cast<const bf16x8*>(p.qkv + (size_t)ktok * ld + vo + gq * 8);
+    kn = *reinterpret_cast<const bf16x8*>(at(base, kpix * ld + ko + gq * 8));
+    vn = *reinterpret_cast<const bf16x8*>(at(base, kpix * ld + vo + gq * 8));
   };
   prefetch();
   for (int g = g0; g < g1; ++g) {
@@ -612,77 +659,108 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dkv_kernel(WinP
         const int id = tid + c * blockDim.x, sr = id >> 2, sc = id & 3;
         *reinterpret_cast<bf16x8*>(Qs + sr * RS + sc * 8) = qr[c];
         *reinterpret_cast<bf16x8*>(dOs + sr * RS + sc * 8) = dr[c];
-        if (sc == 0) { S.lse[sr] = lser[c] * 1.4426950408889634f; S.dlt[sr] = dltr[c]; }   // lse staged in the log2 domain
+        // seeds of the S and dP accumulators: (q.k - lse/scale) * scale*log2e + bias = log2 p, and dP - delta come out of the MFMAs
+        if (sc == 0) { S.lse[sr] = lser[c] * -5.656854249492381f; S.dlt[sr] = -dltr[c]; }
       }
     }
     const bool border = geo.border;
     if (border) for (int t = tid; t < p.N; t += blockDim.x) { const int pr = t / p.ws; S.kreg[t] = geo.reg(p, pr, t - pr * p.ws); }
     const int kreg = border ? geo.reg(p, kpr, kpc) : 0;
     const bf16x8 kf = kn, vf = vn;
-    const int otok = ktok;
+    const unsigned opix = kpix;
+    const size_t oimg = kimg;
     __syncthreads();
     if (g + 1 < g1) {
       geo.next(p);
-      ktok = geo.tok(p, kpr, kpc);
+      kpix = geo.pix(p, kpr, kpc);
+      kimg = geo.img(p);
       prefetch();
     }
     f32x4 dkacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     f32x4 dvacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    const float gate = kval ? 1.f : 0.f;                 // lanes of padded keys contribute nothing
-    {
+    const float gate = kval ? 1.f : 0.f;                 // lanes of padded keys contribute nothing (folded into breg when BREG)
+    // The per-window body exists twice (with / without the shift-mask compares, swin_transformer.py:327-350) behind ONE
+    // wave-uniform branch, so each copy is a single basic block; every LDS operand of a query-tile pair is requested at the
+    // top of the pair (one exposed LDS latency per pair instead of one per MFMA).  Padded tiles read zero rows.
+    auto body = [&](auto border_t) {
+      constexpr bool BORDER = decltype(border_t)::value;
 #pragma unroll
       for (int t2 = 0; t2 < MTP / 2; ++t2) {
         if (t2 * 2 < ntile) {
+          bf16x8 qf[2], df[2], qt[2], dt_[2];
+          f32x4 l4[2], d4[2];
+          int4 qg[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int qi = 2 * t2 + u;
+            qf[u] = *reinterpret_cast<const bf16x8*>(Qs + (qi * 16 + lq) * RS + gq * 8);
+            df[u] = *reinterpret_cast<const bf16x8*>(dOs + (qi * 16 + lq) * RS + gq * 8);
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int qi = 2 * t2 + u;
+            l4[u] = *reinterpret_cast<const f32x4*>(S.lse + qi * 16 + gq * 4);
+            d4[u] = *reinterpret_cast<const f32x4*>(S.dlt + qi * 16 + gq * 4);
+            if constexpr (BORDER) qg[u] = *reinterpret_cast<const int4*>(S.kreg + qi * 16 + gq * 4);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          f32x4 sa[2], sdp[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            sa[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[u], kf, l4[u], 0, 0, 0);     // S[query][key] - lse/scale
+            sdp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[u], vf, d4[u], 0, 0, 0);    // dP[query][key] - delta
+          }
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {                   // transposed operands of the dK / dV MFMAs land during the VALU pass
+            qt[dt] = trr_frag(Qs, dt * 16, 2 * t2, gq, lq);
+            dt_[dt] = trr_frag(dOs, dt * 16, 2 * t2, gq, lq);
+          }
+          __builtin_amdgcn_sched_barrier(0);
           f32x4 ds[2], pd[2];
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
-            const int qt = 2 * t2 + u;
+            const int qi = 2 * t2 + u;
             ds[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             pd[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (qt < ntile) {
-              const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + (qt * 16 + lq) * RS + gq * 8);
-              const bf16x8 df = *reinterpret_cast<const bf16x8*>(dOs + (qt * 16 + lq) * RS + gq * 8);
-              const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);   // S[query][key]
-              const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);  // dP[query][key]
-              const float4 l4 = *reinterpret_cast<const float4*>(S.lse + qt * 16 + gq * 4);
-              const float4 d4 = *reinterpret_cast<const float4*>(S.dlt + qt * 16 + gq * 4);
-              const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
-              const f32x4 bt = bias_tile(qt);
+            if (qi < ntile) {
+              const f32x4 a = sa[u], dp = sdp[u];
+              const f32x4 bt = bias_tile(qi);
               f32x4 sv;
 #pragma unroll
               for (int r = 0; r < 4; ++r) sv[r] = fmaf(a[r], scale * 1.4426950408889634f, bt[r]);
-              if (border) {
-                const int4 qg = *reinterpret_cast<const int4*>(S.kreg + qt * 16 + gq * 4);
-                sv[0] = qg.x != kreg ? sv[0] - 144.26950408889634f : sv[0];
-                sv[1] = qg.y != kreg ? sv[1] - 144.26950408889634f : sv[1];
-                sv[2] = qg.z != kreg ? sv[2] - 144.26950408889634f : sv[2];
-                sv[3] = qg.w != kreg ? sv[3] - 144.26950408889634f : sv[3];
+              if constexpr (BORDER) {
+                sv[0] = qg[u].x != kreg ? sv[0] - 144.26950408889634f : sv[0];
+                sv[1] = qg[u].y != kreg ? sv[1] - 144.26950408889634f : sv[1];
+                sv[2] = qg[u].z != kreg ? sv[2] - 144.26950408889634f : sv[2];
+                sv[3] = qg[u].w != kreg ? sv[3] - 144.26950408889634f : sv[3];
               }
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                const float pr = __builtin_amdgcn_exp2f(sv[r] - ll[r]) * gate;     // padded queries carry lse = +inf -> 0
+                float pr = __builtin_amdgcn_exp2f(sv[r]);
+                if constexpr (!BREG) pr *= gate;
                 pd[u][r] = pr;
-                ds[u][r] = pr * (dp[r] - dd[r]);
+                ds[u][r] = pr * dp[r];
               }
             }
           }
           const bf16x8 dsf = pack8(ds[0], ds[1]), pf = pack8(pd[0], pd[1]);
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt) {
-            dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trr_frag(Qs, dt * 16, 2 * t2, gq, lq), dsf, dkacc[dt], 0, 0, 0);
-            dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trr_frag(dOs, dt * 16, 2 * t2, gq, lq), pf, dvacc[dt], 0, 0, 0);
+            dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt[dt], dsf, dkacc[dt], 0, 0, 0);
+            dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dt_[dt], pf, dvacc[dt], 0, 0, 0);
           }
         }
       }
-    }
+    };
+    if (border) body(std::true_type{}); else body(std::false_type{});
     if (kval) {
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         bf16x4 ok, ov;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ok[r] = f2bf(dkacc[dt][r] * scale); ov[r] = f2bf(dvacc[dt][r]); }
-        *reinterpret_cast<bf16x4*>(p.dqkv + (size_t)otok * ld + ko + dt * 16 + gq * 4) = ok;
-        *reinterpret_cast<bf16x4*>(p.dqkv + (size_t)otok * ld + vo + dt * 16 + gq * 4) = ov;
+        *reinterpret_cast<bf16x4*>(at(p.dqkv + oimg * ld, opix * ld + ko + dt * 16 + gq * 4)) = ok;
+        *reinterpret_cast<bf16x4*>(at(p.dqkv + oimg * ld, opix * ld + vo + dt * 16 + gq * 4)) = ov;
       }
     }
   }
@@ -745,7 +823,7 @@ void strip_geometry(int N, int& nw, int& sg) {
 // 512 images, stage 0 (tools/op_bench.py 512 attn): forward 1828 -> 1542 us; backward 7441 us with neither pass, 8837 with the
 // dQ pass on it (that kernel already sits at the 168-VGPR cap and spills more), 7301 with the dK/dV pass -> forward + dK/dV.
 int ntc_mask() {
-  static const int m = getenv("FIBER_WIN_NTC") ? atoi(getenv("FIBER_WIN_NTC")) : 5;
+  static const int m = getenv("FIBER_WIN_NTC") ? atoi(getenv("FIBER_WIN_NTC")) : 7;
   return m;
 }
 
@@ -812,9 +890,10 @@ int fiber_win_bwd_launch(const void* qkv, const float* bias_table, const void* o
   hipLaunchKernelGGL(win_delta_kernel, dim3((int)(g > 4096 ? 4096 : g)), dim3(256), 0, st, (const bf16*)o, (const bf16*)dout, delta_ws, nvec, heads);
   FIBER_CHECK_LAUNCH();
   const int gz = cdiv(p.G, p.gpb);
+  const size_t slab = (size_t)nw * 10 * 64 * sizeof(float) * 4;   // dQ pass: per-lane bias slices [wave][tile][lane] x f32x4
   if (big_window(p.N)) hipLaunchKernelGGL((win_bwd_dq_kernel<3, 0, 21, false>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2, 0), st, p);
-  else if (p.N == 144 && (ntc_mask() & 2)) hipLaunchKernelGGL((win_bwd_dq_kernel<1, 9>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2, 0), st, p);
-  else hipLaunchKernelGGL((win_bwd_dq_kernel<1, 0>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2, 0), st, p);
+  else if (p.N == 144 && (ntc_mask() & 2)) hipLaunchKernelGGL((win_bwd_dq_kernel<1, 9>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2, 0) + slab, st, p);
+  else hipLaunchKernelGGL((win_bwd_dq_kernel<1, 0>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2, 0) + slab, st, p);
   FIBER_CHECK_LAUNCH();
   if (hipMemsetAsync(dbias_table, 0, (size_t)nb * heads * sizeof(float), st) != hipSuccess) return FIBER_ELAUNCH;
   hipLaunchKernelGGL(win_dbias_scatter_kernel, dim3(p.N, heads), dim3(256), 0, st, dbias_ws, dbias_table, gz, heads, ws);
