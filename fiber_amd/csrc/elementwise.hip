@@ -152,16 +152,32 @@ __global__ __launch_bounds__(256) void rowscale_colsum_kernel(const bf16* __rest
   if (gc < N) out[(size_t)blockIdx.y * N + gc] = t;
 }
 
+// out[c] = sum_y part[y, c].  The slab count reaches 512 while N can be as small as 128, so the work is spread over 16 row
+// lanes x 16 columns per block (N/16 blocks) with four independent loads in flight per thread: the previous 64-column x
+// 4-lane shape ran 2 blocks of 128 dependent loads each (25 us of pure latency per call, ~210 calls per step).
 __global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ part, float* __restrict__ out, int slabs, int N) {
-  __shared__ float red[4][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  float s = 0.f;
-  if (c < N)
-    for (int y = rl; y < slabs; y += 4) s += part[(size_t)y * N + c];
-  red[rl][cl] = s;
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < N) {
+    int y = rl;
+    for (; y + 48 < slabs; y += 64) {
+      s0 += part[(size_t)y * N + c];
+      s1 += part[(size_t)(y + 16) * N + c];
+      s2 += part[(size_t)(y + 32) * N + c];
+      s3 += part[(size_t)(y + 48) * N + c];
+    }
+    for (; y < slabs; y += 16) s0 += part[(size_t)y * N + c];
+  }
+  red[rl][cl] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (rl == 0 && c < N) out[c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+  if (rl == 0 && c < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += red[r][cl];
+    out[c] = t;
+  }
 }
 
 __global__ __launch_bounds__(256) void dropout_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, size_t nvec,
@@ -252,7 +268,7 @@ extern "C" int fiber_colsum_bf16(const void* x, float* out, float* workspace, in
   hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, stream, (const bf16*)x, gy > 1 ? workspace : out, M, N, ld, rpb);
   FIBER_CHECK_LAUNCH();
   if (gy > 1) {
-    hipLaunchKernelGGL(colsum_fold_kernel, dim3(cdiv(N, 64)), dim3(256), 0, stream, workspace, out, gy, N);
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3(cdiv(N, 16)), dim3(256), 0, stream, workspace, out, gy, N);
     FIBER_CHECK_LAUNCH();
   }
   return FIBER_OK;
@@ -272,7 +288,7 @@ extern "C" int fiber_gelu_bwd_colsum_bf16(const void* dgelu, const void* h_pre, 
                      gy > 1 ? workspace : db, M, N, rpb);
   FIBER_CHECK_LAUNCH();
   if (gy > 1) {
-    hipLaunchKernelGGL(colsum_fold_kernel, dim3(cdiv(N, 64)), dim3(256), 0, stream, workspace, db, gy, N);
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3(cdiv(N, 16)), dim3(256), 0, stream, workspace, db, gy, N);
     FIBER_CHECK_LAUNCH();
   }
   return FIBER_OK;
@@ -292,7 +308,7 @@ extern "C" int fiber_rowscale_colsum_bf16(const void* x, const float* scale, voi
                      gy > 1 ? workspace : db, M, N, rpb, rows_per_sample);
   FIBER_CHECK_LAUNCH();
   if (gy > 1) {
-    hipLaunchKernelGGL(colsum_fold_kernel, dim3(cdiv(N, 64)), dim3(256), 0, stream, workspace, db, gy, N);
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3(cdiv(N, 16)), dim3(256), 0, stream, workspace, db, gy, N);
     FIBER_CHECK_LAUNCH();
   }
   return FIBER_OK;
@@ -301,7 +317,7 @@ extern "C" int fiber_rowscale_colsum_bf16(const void* x, const float* scale, voi
 // out[n] = sum_r part[r, n]  (fold of per-tile / per-slab partial rows, fp32)
 extern "C" int fiber_fold_rows_f32(const float* part, float* out, int rows, int N, hipStream_t stream) {
   if (rows <= 0 || N <= 0) return FIBER_OK;
-  hipLaunchKernelGGL(colsum_fold_kernel, dim3(cdiv(N, 64)), dim3(256), 0, stream, part, out, rows, N);
+  hipLaunchKernelGGL(colsum_fold_kernel, dim3(cdiv(N, 16)), dim3(256), 0, stream, part, out, rows, N);
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }

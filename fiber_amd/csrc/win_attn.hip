@@ -68,6 +68,25 @@ __device__ __forceinline__ bf16x8 trr_frag(const bf16* rm, int d0, int t0, int g
   for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi[e]; }
   return __builtin_bit_cast(bf16x8, o);
 }
+// max of three without the canonicalising v_max_f32 x, x that fmaxf() drags in for every operand (inputs are never sNaN here)
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// element-wise helpers on f32x4 with the natural (0,1)(2,3) pairing -> v_pk_fma_f32 / v_pk_mul_f32 and aligned v_cvt_pk_bf16_f32
+// (the SLP vectoriser otherwise pairs lanes (1,2) and pays v_alignbit/v_perm shuffles before every pack)
+__device__ __forceinline__ f32x4 fma4(f32x4 a, float b, f32x4 c) { return __builtin_elementwise_fma(a, f32x4{b, b, b, b}, c); }
+__device__ __forceinline__ f32x4 fma4(f32x4 a, float b, float c) { return __builtin_elementwise_fma(a, f32x4{b, b, b, b}, f32x4{c, c, c, c}); }
+__device__ __forceinline__ f32x4 exp2x4(f32x4 a) {
+  return f32x4{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1]), __builtin_amdgcn_exp2f(a[2]), __builtin_amdgcn_exp2f(a[3])};
+}
+// shift-mask term: -100 (natural-log logits) on keys of another shift region, as arithmetic on float region labels:
+// pen * (region_a - region_b)^2 is 0 when equal and <= pen otherwise (masked probabilities underflow to 0 either way)
+__device__ __forceinline__ f32x4 region_mask(f32x4 sv, f32x4 ra, float rb, float pen) {
+  const f32x4 d = ra - rb;
+  return __builtin_elementwise_fma(d * d, f32x4{pen, pen, pen, pen}, sv);
+}
 __device__ __forceinline__ bf16x8 zero8() {
   bf16x8 z;
 #pragma unroll
@@ -102,8 +121,8 @@ struct Geo {
   // 32-bit per-lane value, so every global access is `saddr + 32-bit voffset` and no lane carries 64-bit addresses.
   __device__ __forceinline__ unsigned pix(const WinP& p, int pr, int pc) const {
     int r = wr * p.ws + pr + p.shift, c = wc * p.ws + pc + p.shift;
-    r = r >= p.Hres ? r - p.Hres : r;
-    c = c >= p.Wres ? c - p.Wres : c;
+    r = (int)min((unsigned)r, (unsigned)(r - p.Hres));   // r >= Hres ? r - Hres : r without a v_cndmask (17 cycles per
+    c = (int)min((unsigned)c, (unsigned)(c - p.Wres));   // wave-instruction on gfx950, tools/valu_probe.hip)
     return (unsigned)(r * p.Wres + c);
   }
   __device__ __forceinline__ size_t img(const WinP& p) const { return (size_t)b * p.Hres * p.Wres; }
@@ -140,15 +159,18 @@ size_t smem_bytes(int nb, int n_rm, int n_tr) {
 
 // common per-block setup: bias column of this head, key offsets, zeroed LDS tiles (padding rows stay zero forever)
 template <int MTT>
-__device__ __forceinline__ void setup(const WinP& p, const Smem& S, int h, int nb, int n_rm, int n_tr) {
+__device__ __forceinline__ void setup(const WinP& p, const Smem& S, int h, int nb, int n_rm, int n_tr, float bias_mul, float lse_valid) {
   WIN_DIMS(MTT);
-  for (int t = threadIdx.x; t < nb; t += blockDim.x) S.btab[t] = p.bias_table[(size_t)t * p.heads + h];
+  // bias column of this head, pre-multiplied into the domain the kernel adds it in (bias/scale or bias*log2e)
+  for (int t = threadIdx.x; t < nb; t += blockDim.x) S.btab[t] = p.bias_table[(size_t)t * p.heads + h] * bias_mul;
   for (int j = threadIdx.x; j < MAXN; j += blockDim.x) {
     const int jj = j < p.N ? j : 0;
     const int pr = jj / p.ws, pc = jj - pr * p.ws;
     S.koff[j] = pr * (2 * p.ws - 1) + pc;
     S.kreg[j] = 0;
-    S.lse[j] = -INFINITY;                              // dK/dV pass: staged as -lse/scale (accumulator seed); padded queries -> exp2(-inf) = 0
+    // dK/dV pass: -lse/scale of each query is staged here per window (accumulator seed), padded queries keep -inf -> p = 0;
+    // forward / dQ pass: the same table is the additive key-padding mask (0 on valid keys, -inf on padded ones)
+    S.lse[j] = j < p.N ? lse_valid : -INFINITY;
     S.dlt[j] = 0.f;
   }
   const int words = (n_rm * MAXN * RS + n_tr * 32 * TS) / 2;
@@ -170,8 +192,10 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
   const int gq = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y, C = p.C, ld = 3 * C;
   const int qo = p.hmajor ? h * 96 : h * 32, ko = p.hmajor ? h * 96 + 32 : C + h * 32, vo = p.hmajor ? h * 96 + 64 : 2 * C + h * 32;
-  const int ntile = NTC ? NTC : (p.N + 15) >> 4;      // compile-time for the 12x12 window: guards fold, the 10th tile's code disappears
-  setup<MTT>(p, S, h, nb, 2, 0);
+  // compile-time for the 12x12 window (guards fold, the 10th tile's code disappears) and for the 21-tile variant (18x18
+  // windows fill it; padded tiles of smaller windows carry bias = -inf and zero rows, so running them is only wasted work)
+  const int ntile = NTC ? NTC : MT > 10 ? MT : (p.N + 15) >> 4;
+  setup<MTT>(p, S, h, nb, 2, 0, 5.656854249492381f, 0.f);
 
   // this thread's staging chunks: chunk id = tid + c*blockDim -> (row = id>>2 of the window, 16-byte piece id&3)
   int spr[MAXC], spc[MAXC];
@@ -195,22 +219,18 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
   if (g0 >= g1) return;
   // The wave owns the same query strip in every window it visits, so its slice of the relative-position bias
   // (bias_table[rel_index(i, j)], swin_transformer.py:208-211) is window-invariant: gather it ONCE into registers
-  // (-inf for padded keys) and the per-score work becomes a single fma.
+  // (-inf for padded keys), pre-divided by the scale, and hand it to the QK^T MFMA as its accumulator seed.
   __syncthreads();
   f32x4 breg[BREG ? MT : 1];
-  // bias of key tile kt for this lane's query, log2 domain, -inf on padded keys
+  // bias / scale of key tile kt for this lane's query, -inf on padded keys
   auto bias_tile = [&](int kt) -> f32x4 {
     if constexpr (BREG) {
       return breg[kt];
     } else {
+      // branch-free: padded keys look up entry koff = 0 and get -inf from the additive padding mask
       const int4 ko = *reinterpret_cast<const int4*>(S.koff + kt * 16 + gq * 4);
-      const int j0 = kt * 16 + gq * 4;
-      f32x4 b;
-      b[0] = j0 + 0 < p.N ? S.btab[qoff - ko.x] * 1.4426950408889634f : -INFINITY;
-      b[1] = j0 + 1 < p.N ? S.btab[qoff - ko.y] * 1.4426950408889634f : -INFINITY;
-      b[2] = j0 + 2 < p.N ? S.btab[qoff - ko.z] * 1.4426950408889634f : -INFINITY;
-      b[3] = j0 + 3 < p.N ? S.btab[qoff - ko.w] * 1.4426950408889634f : -INFINITY;
-      return b;
+      const f32x4 b = {S.btab[qoff - ko.x], S.btab[qoff - ko.y], S.btab[qoff - ko.z], S.btab[qoff - ko.w]};
+      return b + *reinterpret_cast<const f32x4*>(S.lse + kt * 16 + gq * 4);
     }
   };
   if constexpr (BREG) {
@@ -219,7 +239,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int jj = kt * 16 + gq * 4 + r;
-        breg[kt][r] = (kt < ntile && jj < p.N) ? S.btab[qoff - S.koff[jj]] * 1.4426950408889634f : -INFINITY;   // log2 domain
+        breg[kt][r] = (kt < ntile && jj < p.N) ? S.btab[qoff - S.koff[jj]] : -INFINITY;
       }
   }
   const float scale2 = scale * 1.4426950408889634f;     // scores kept in the log2 domain: exp is a bare v_exp_f32
@@ -253,8 +273,9 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
       }
     }
     const bool border = geo.border;
-    if (border) for (int t = tid; t < p.N; t += blockDim.x) { const int pr = t / p.ws; S.kreg[t] = geo.reg(p, pr, t - pr * p.ws); }
-    const int qreg = border ? geo.reg(p, qpr, qpc) : 0;
+    float* kregf = reinterpret_cast<float*>(S.kreg);     // shift-region labels as floats (padding rows stay 0)
+    if (border) for (int t = tid; t < p.N; t += blockDim.x) { const int pr = t / p.ws; kregf[t] = (float)geo.reg(p, pr, t - pr * p.ws); }
+    const float qregf = border ? (float)geo.reg(p, qpr, qpc) : 0.f;
     const bf16x8 qf = qn;
     const unsigned opix = qpix;
     const size_t oimg = qimg;
@@ -291,7 +312,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
 #pragma unroll
         for (int u = 0; u < GK; ++u) {
           const int kt = gi * GK + u;
-          if (kt < MT && kt < ntile) s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[gi & 1][u], qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);   // S^T[key][query]
+          if (kt < MT && kt < ntile) s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[gi & 1][u], qf, bias_tile(kt), 0, 0, 0);   // S^T[key][query] + bias / scale
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -301,36 +322,29 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) vf[t2][dt] = trr_frag(Vs, dt * 16, 2 * t2, gq, lq);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int kt = 0; kt < MT; ++kt) {
-        if (kt < ntile) {
-          const f32x4 bt = bias_tile(kt);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) s[kt][r] = fmaf(s[kt][r], scale2, bt[r]);
-        }
-      }
+      // VALU diet (a plain VALU op is ~4.3 cycles per wave on a SIMD, v_exp_f32 8.4, v_cndmask_b32 17): the softmax works on
+      // t = q.k + bias/scale straight out of the MFMA; p = exp2(t * scale*log2e - max) is ONE packed fma + exp2 per score.
       if (border) {                                       // one wave-uniform branch per window (swin_transformer.py:327-350)
 #pragma unroll
         for (int kt = 0; kt < MT; ++kt) {
           if (kt < ntile) {
-            const int4 kg = *reinterpret_cast<const int4*>(S.kreg + kt * 16 + gq * 4);
-            s[kt][0] = kg.x != qreg ? s[kt][0] - 144.26950408889634f : s[kt][0];     // -100 * log2(e)
-            s[kt][1] = kg.y != qreg ? s[kt][1] - 144.26950408889634f : s[kt][1];
-            s[kt][2] = kg.z != qreg ? s[kt][2] - 144.26950408889634f : s[kt][2];
-            s[kt][3] = kg.w != qreg ? s[kt][3] - 144.26950408889634f : s[kt][3];
+            s[kt] = region_mask(s[kt], *reinterpret_cast<const f32x4*>(kregf + kt * 16 + gq * 4), qregf, -565.6854249492381f);   // -100 / scale
           }
         }
       }
+      float m0 = -INFINITY, m1 = -INFINITY;
 #pragma unroll
       for (int kt = 0; kt < MT; ++kt)
-        if (kt < ntile) mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
-      mx = g4max(mx);
+        if (kt < ntile) { m0 = max3(m0, s[kt][0], s[kt][1]); m1 = max3(m1, s[kt][2], s[kt][3]); }
+      mx = g4max(max3(m0, m1, m1));
+      const float nm = -mx * scale2;
       float s0 = 0.f, s1 = 0.f;
 #pragma unroll
       for (int kt = 0; kt < MTP; ++kt) {
         if (kt < ntile) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - mx);
+          const f32x2 e0 = __builtin_elementwise_fma(f32x2{s[kt][0], s[kt][1]}, f32x2{scale2, scale2}, f32x2{nm, nm});
+          const f32x2 e1 = __builtin_elementwise_fma(f32x2{s[kt][2], s[kt][3]}, f32x2{scale2, scale2}, f32x2{nm, nm});
+          s[kt] = f32x4{__builtin_amdgcn_exp2f(e0.x), __builtin_amdgcn_exp2f(e0.y), __builtin_amdgcn_exp2f(e1.x), __builtin_amdgcn_exp2f(e1.y)};
           s0 += s[kt][0] + s[kt][1];
           s1 += s[kt][2] + s[kt][3];
         } else {
@@ -353,7 +367,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
       }
     }
     if (qval) {
-      const float inv = 1.f / sum;
+      const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         bf16x4 o;
@@ -361,7 +375,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
         for (int r = 0; r < 4; ++r) o[r] = f2bf(oacc[dt][r] * inv);
         *reinterpret_cast<bf16x4*>(at(p.o + oimg * C, opix * C + h * 32 + dt * 16 + gq * 4)) = o;
       }
-      if (gq == 0) *at(p.lse + oimg * p.heads, opix * p.heads + h) = mx * 0.6931471805599453f + __logf(sum);
+      if (gq == 0) *at(p.lse + oimg * p.heads, opix * p.heads + h) = mx * scale + __logf(sum);
     }
   }
 }
@@ -380,8 +394,10 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
   const int gq = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y, C = p.C, ld = 3 * C;
   const int qo = p.hmajor ? h * 96 : h * 32, ko = p.hmajor ? h * 96 + 32 : C + h * 32, vo = p.hmajor ? h * 96 + 64 : 2 * C + h * 32;
-  const int ntile = NTC ? NTC : (p.N + 15) >> 4;      // compile-time for the 12x12 window: guards fold, the 10th tile's code disappears
-  setup<MTT>(p, S, h, nb, 2, 0);
+  // compile-time for the 12x12 window (guards fold, the 10th tile's code disappears) and for the 21-tile variant (18x18
+  // windows fill it; padded tiles of smaller windows carry bias = -inf and zero rows, so running them is only wasted work)
+  const int ntile = NTC ? NTC : MT > 10 ? MT : (p.N + 15) >> 4;
+  setup<MTT>(p, S, h, nb, 2, 0, 5.656854249492381f, 0.f);
   int spr[MAXC], spc[MAXC];
   bool sval[MAXC];
 #pragma unroll
@@ -407,14 +423,10 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
     if constexpr (BREG) {
       return slab[kt * 64];
     } else {
+      // branch-free: padded keys look up entry koff = 0 and get -inf from the additive padding mask
       const int4 ko = *reinterpret_cast<const int4*>(S.koff + kt * 16 + gq * 4);
-      const int j0 = kt * 16 + gq * 4;
-      f32x4 b;
-      b[0] = j0 + 0 < p.N ? S.btab[qoff - ko.x] * 5.656854249492381f : -INFINITY;
-      b[1] = j0 + 1 < p.N ? S.btab[qoff - ko.y] * 5.656854249492381f : -INFINITY;
-      b[2] = j0 + 2 < p.N ? S.btab[qoff - ko.z] * 5.656854249492381f : -INFINITY;
-      b[3] = j0 + 3 < p.N ? S.btab[qoff - ko.w] * 5.656854249492381f : -INFINITY;
-      return b;
+      const f32x4 b = {S.btab[qoff - ko.x], S.btab[qoff - ko.y], S.btab[qoff - ko.z], S.btab[qoff - ko.w]};
+      return b + *reinterpret_cast<const f32x4*>(S.lse + kt * 16 + gq * 4);
     }
   };
   __syncthreads();
@@ -426,7 +438,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int jj = kt * 16 + gq * 4 + r;
-        b[r] = (kt < ntile && jj < p.N) ? S.btab[qoff - S.koff[jj]] * 5.656854249492381f : -INFINITY;   // window-invariant bias slice
+        b[r] = (kt < ntile && jj < p.N) ? S.btab[qoff - S.koff[jj]] : -INFINITY;   // window-invariant bias slice
       }
       slab[kt * 64] = b;                                  // read back by the same lane only: no barrier needed
     }
@@ -471,8 +483,9 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
       }
     }
     const bool border = geo.border;
-    if (border) for (int t = tid; t < p.N; t += blockDim.x) { const int pr = t / p.ws; S.kreg[t] = geo.reg(p, pr, t - pr * p.ws); }
-    const int qreg = border ? geo.reg(p, qpr, qpc) : 0;
+    float* kregf = reinterpret_cast<float*>(S.kreg);     // shift-region labels as floats (padding rows stay 0)
+    if (border) for (int t = tid; t < p.N; t += blockDim.x) { const int pr = t / p.ws; kregf[t] = (float)geo.reg(p, pr, t - pr * p.ws); }
+    const float qregf = border ? (float)geo.reg(p, qpr, qpc) : 0.f;
     const bf16x8 qf = qn, dof = don;
     // Accumulator seeds: q.k + bias/scale and dP - delta come straight out of the MFMAs, log2 p = that * scale*log2e - lse*log2e
     // is one fma; the lanes of padded queries get lse = +inf so that their p (and with it ds, dbias) is exactly 0.
@@ -492,55 +505,52 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
     // key-tile pair are requested together (padded tiles read zero rows and carry bias = -inf).
     auto body = [&](auto border_t) {
       constexpr bool BORDER = decltype(border_t)::value;
+      constexpr bool PIPE = NTC != 0;                      // explicit load placement only where the register budget allows it
 #pragma unroll
       for (int t2 = 0; t2 < MTP / 2; ++t2) {
         if (t2 * 2 < ntile) {
           bf16x8 kf[2], vf[2], kt_[2];
-          f32x4 sa[2], sdp[2];
-          int4 kg[2];
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
+          f32x4 sa[2], sdp[2], kg[2], ds[2];
+          auto loads = [&](int u) {
             const int kt = 2 * t2 + u;
             kf[u] = *reinterpret_cast<const bf16x8*>(Ks + (kt * 16 + lq) * RS + gq * 8);
             vf[u] = *reinterpret_cast<const bf16x8*>(Vs + (kt * 16 + lq) * RS + gq * 8);
             sa[u] = kt < MT ? bias_tile(kt) : f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (BORDER) kg[u] = *reinterpret_cast<const int4*>(S.kreg + kt * 16 + gq * 4);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
+            if constexpr (BORDER) kg[u] = *reinterpret_cast<const f32x4*>(kregf + kt * 16 + gq * 4);
+          };
+          auto mfmas = [&](int u) {
             sa[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[u], qf, sa[u], 0, 0, 0);
             sdp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[u], dof, dseed, 0, 0, 0);
-          }
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) kt_[dt] = trr_frag(Ks, dt * 16, 2 * t2, gq, lq);   // lands during the VALU pass
-          __builtin_amdgcn_sched_barrier(0);
-          f32x4 ds[2];
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
+          };
+          auto valu = [&](int u) {
             const int kt = 2 * t2 + u;
             ds[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (kt < ntile) {
-              f32x4 sv;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) sv[r] = fmaf(sa[u][r], scale * 1.4426950408889634f, nlse);   // log2 p; -inf on padded keys
-              if constexpr (BORDER) {
-                sv[0] = kg[u].x != qreg ? sv[0] - 144.26950408889634f : sv[0];
-                sv[1] = kg[u].y != qreg ? sv[1] - 144.26950408889634f : sv[1];
-                sv[2] = kg[u].z != qreg ? sv[2] - 144.26950408889634f : sv[2];
-                sv[3] = kg[u].w != qreg ? sv[3] - 144.26950408889634f : sv[3];
-              }
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float d = __builtin_amdgcn_exp2f(sv[r]) * sdp[u][r];
-                ds[u][r] = d;
-                dbacc[kt][r] += d;
-              }
+              f32x4 sv = fma4(sa[u], scale * 1.4426950408889634f, nlse);   // log2 p; -inf on padded keys
+              if constexpr (BORDER) sv = region_mask(sv, kg[u], qregf, -144.26950408889634f);
+              const f32x4 d = exp2x4(sv) * sdp[u];
+              ds[u] = d;
+              dbacc[kt] += d;
             }
+          };
+          if constexpr (PIPE) {
+            loads(0); loads(1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(0); mfmas(1);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) kt_[dt] = trr_frag(Ks, dt * 16, 2 * t2, gq, lq);   // lands during the VALU pass
+            __builtin_amdgcn_sched_barrier(0);
+            valu(0); valu(1);
+          } else {
+            loads(0); mfmas(0); valu(0);
+            loads(1); mfmas(1); valu(1);
           }
           const bf16x8 dsf = pack8(ds[0], ds[1]);
 #pragma unroll
-          for (int dt = 0; dt < 2; ++dt) dqacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_[dt], dsf, dqacc[dt], 0, 0, 0);
+          for (int dt = 0; dt < 2; ++dt) {
+            if constexpr (!PIPE) kt_[dt] = trr_frag(Ks, dt * 16, 2 * t2, gq, lq);
+            dqacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_[dt], dsf, dqacc[dt], 0, 0, 0);
+          }
         }
       }
     };
@@ -582,8 +592,10 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dkv_kernel(WinP
   const int gq = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y, C = p.C, ld = 3 * C;
   const int qo = p.hmajor ? h * 96 : h * 32, ko = p.hmajor ? h * 96 + 32 : C + h * 32, vo = p.hmajor ? h * 96 + 64 : 2 * C + h * 32;
-  const int ntile = NTC ? NTC : (p.N + 15) >> 4;      // compile-time for the 12x12 window: guards fold, the 10th tile's code disappears
-  setup<MTT>(p, S, h, nb, 2, 0);
+  // compile-time for the 12x12 window (guards fold, the 10th tile's code disappears) and for the 21-tile variant (18x18
+  // windows fill it; padded tiles of smaller windows carry bias = -inf and zero rows, so running them is only wasted work)
+  const int ntile = NTC ? NTC : MT > 10 ? MT : (p.N + 15) >> 4;
+  setup<MTT>(p, S, h, nb, 2, 0, 1.4426950408889634f, -INFINITY);
   int spr[MAXC], spc[MAXC];
   bool sval[MAXC];
 #pragma unroll
@@ -609,14 +621,9 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dkv_kernel(WinP
     if constexpr (BREG) {
       return breg[qt];
     } else {
+      // branch-free: padded queries look up entry koff = 0 (any finite value: their accumulator seed is -inf)
       const int4 ko = *reinterpret_cast<const int4*>(S.koff + qt * 16 + gq * 4);
-      const int i0 = qt * 16 + gq * 4;
-      f32x4 b;
-      b[0] = i0 + 0 < p.N ? S.btab[ko.x + kconst] * 1.4426950408889634f : 0.f;
-      b[1] = i0 + 1 < p.N ? S.btab[ko.y + kconst] * 1.4426950408889634f : 0.f;
-      b[2] = i0 + 2 < p.N ? S.btab[ko.z + kconst] * 1.4426950408889634f : 0.f;
-      b[3] = i0 + 3 < p.N ? S.btab[ko.w + kconst] * 1.4426950408889634f : 0.f;
-      return b;
+      return f32x4{S.btab[ko.x + kconst], S.btab[ko.y + kconst], S.btab[ko.z + kconst], S.btab[ko.w + kconst]};
     }
   };
   if constexpr (BREG) {
@@ -626,7 +633,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dkv_kernel(WinP
       for (int r = 0; r < 4; ++r) {
         const int ii = qt * 16 + gq * 4 + r;
         // log2 domain; -inf on the lanes of padded keys (they contribute nothing), 0 on padded queries (their seed is -inf)
-        breg[qt][r] = !kval ? -INFINITY : (qt < ntile && ii < p.N) ? S.btab[S.koff[ii] + kconst] * 1.4426950408889634f : 0.f;
+        breg[qt][r] = !kval ? -INFINITY : (qt < ntile && ii < p.N) ? S.btab[S.koff[ii] + kconst] : 0.f;
       }
   }
   Geo geo;
@@ -664,8 +671,9 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dkv_kernel(WinP
       }
     }
     const bool border = geo.border;
-    if (border) for (int t = tid; t < p.N; t += blockDim.x) { const int pr = t / p.ws; S.kreg[t] = geo.reg(p, pr, t - pr * p.ws); }
-    const int kreg = border ? geo.reg(p, kpr, kpc) : 0;
+    float* kregf = reinterpret_cast<float*>(S.kreg);     // shift-region labels as floats (padding rows stay 0)
+    if (border) for (int t = tid; t < p.N; t += blockDim.x) { const int pr = t / p.ws; kregf[t] = (float)geo.reg(p, pr, t - pr * p.ws); }
+    const float kregf_own = border ? (float)geo.reg(p, kpr, kpc) : 0.f;
     const bf16x8 kf = kn, vf = vn;
     const unsigned opix = kpix;
     const size_t oimg = kimg;
@@ -688,8 +696,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dkv_kernel(WinP
       for (int t2 = 0; t2 < MTP / 2; ++t2) {
         if (t2 * 2 < ntile) {
           bf16x8 qf[2], df[2], qt[2], dt_[2];
-          f32x4 l4[2], d4[2];
-          int4 qg[2];
+          f32x4 l4[2], d4[2], qg[2];
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             const int qi = 2 * t2 + u;
@@ -701,7 +708,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dkv_kernel(WinP
             const int qi = 2 * t2 + u;
             l4[u] = *reinterpret_cast<const f32x4*>(S.lse + qi * 16 + gq * 4);
             d4[u] = *reinterpret_cast<const f32x4*>(S.dlt + qi * 16 + gq * 4);
-            if constexpr (BORDER) qg[u] = *reinterpret_cast<const int4*>(S.kreg + qi * 16 + gq * 4);
+            if constexpr (BORDER) qg[u] = *reinterpret_cast<const f32x4*>(kregf + qi * 16 + gq * 4);
           }
           __builtin_amdgcn_sched_barrier(0);
           f32x4 sa[2], sdp[2];
@@ -723,24 +730,12 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dkv_kernel(WinP
             ds[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             pd[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (qi < ntile) {
-              const f32x4 a = sa[u], dp = sdp[u];
-              const f32x4 bt = bias_tile(qi);
-              f32x4 sv;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) sv[r] = fmaf(a[r], scale * 1.4426950408889634f, bt[r]);
-              if constexpr (BORDER) {
-                sv[0] = qg[u].x != kreg ? sv[0] - 144.26950408889634f : sv[0];
-                sv[1] = qg[u].y != kreg ? sv[1] - 144.26950408889634f : sv[1];
-                sv[2] = qg[u].z != kreg ? sv[2] - 144.26950408889634f : sv[2];
-                sv[3] = qg[u].w != kreg ? sv[3] - 144.26950408889634f : sv[3];
-              }
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                float pr = __builtin_amdgcn_exp2f(sv[r]);
-                if constexpr (!BREG) pr *= gate;
-                pd[u][r] = pr;
-                ds[u][r] = pr * dp[r];
-              }
+              f32x4 sv = fma4(sa[u], scale * 1.4426950408889634f, bias_tile(qi));
+              if constexpr (BORDER) sv = region_mask(sv, qg[u], kregf_own, -144.26950408889634f);
+              f32x4 pr = exp2x4(sv);
+              if constexpr (!BREG) pr *= gate;
+              pd[u] = pr;
+              ds[u] = pr * sdp[u];
             }
           }
           const bf16x8 dsf = pack8(ds[0], ds[1]), pf = pack8(pd[0], pd[1]);
