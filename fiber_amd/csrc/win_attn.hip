@@ -23,7 +23,11 @@ namespace {
 // Tile capacity is a template parameter MTT of every kernel / helper below: 10 tiles (N <= 160: the 12x12 windows of the 384^2
 // configurations, bias slice held in registers) or 21 tiles (N <= 336: the 18x18 windows of the 576^2 configuration, bias
 // looked up from LDS per score -- 84 more registers per lane do not exist).  MT / MAXN / TS are derived locally from it.
-constexpr int RS = 40;             // row stride (elements) of row-major LDS tiles: 32 + 8 pad (80 B, 16-B aligned)
+// Row stride (elements) of the row-major LDS tiles: 32 + 16 pad = 96 B = 24 banks.  Both read patterns are then conflict-free
+// (MI355X_MICROARCH.md LDS table): ds_read_b128 serves lanes {0-3,12-15,20-27}... per cycle, whose 16 row starts 24*row + 4*g
+// tile the 64 banks, and ds_read_b64_tr_b16 serves 32 lanes = 8 rows x 32 B per cycle, 24*row mod 64 being the 8 multiples
+// of 8.  The former 80-B stride was 2-way conflicted on both (SQ_LDS_BANK_CONFLICT = 43 % of SQ_LDS_IDX_ACTIVE).
+constexpr int RS = 48;
 // (tiles are consumed in pairs by the second MFMA of each pass: an odd capacity is rounded up for the pair loops, the
 // per-tile register arrays and the transposed-image stride, the extra tile being all zeros)
 #define WIN_DIMS(MTT) constexpr int MT = (MTT), MTP = ((MTT) + 1) & ~1, MAXN = MTP * 16, TS = MAXN + 8; (void)MT; (void)MTP; (void)MAXN; (void)TS
