@@ -77,11 +77,13 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
   return o;
 }
 
-// Stage `nrows` rows (row r of the chunk <-> global row rowmap[r]) of a [*, ld] bf16 matrix (head slice D wide) into LDS,
-// row-major (stride D+8) and/or transposed ([D][chp]).  Rows >= valid are zero filled.
-template <int D, bool RM, bool TR>
+// Stage `nrows` rows (row r of the chunk <-> global row rowmap[r]) of a [*, ld] bf16 matrix (head slice D wide) into a
+// row-major LDS image.  Rows >= valid are zero filled.  Row stride D+16 elements (96 B / 160 B): 24 or 40 banks per row, which
+// makes both ds_read_b128 (operand straight) and ds_read_b64_tr_b16 (operand transposed) conflict-free (MI355X_MICROARCH.md,
+// LDS table); no transposed copy of an image is ever written.
+template <int D>
 __device__ __forceinline__ void stage(const bf16* __restrict__ src, int ld, int hcol, const int* rowmap, int nrows,
-                                      int valid, bf16* rm, bf16* tr, int chp) {
+                                      int valid, bf16* rm) {
   constexpr int CPR = D / 8;
   for (int idx = threadIdx.x; idx < nrows * CPR; idx += blockDim.x) {
     const int r = idx / CPR, c = idx - r * CPR;
@@ -92,22 +94,24 @@ __device__ __forceinline__ void stage(const bf16* __restrict__ src, int ld, int 
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = f2bf(0.f);
     }
-    if (RM) *reinterpret_cast<bf16x8*>(rm + r * (D + 8) + c * 8) = v;
-    if (TR) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) tr[(c * 8 + e) * chp + r] = v[e];
-    }
+    *reinterpret_cast<bf16x8*>(rm + r * (D + 16) + c * 8) = v;
   }
 }
 
-// fragment of a transposed LDS image for MFMA operand A: row d, k-slots = keys {t0*16+g*4..+3} U {t0*16+16+g*4..+3}
-__device__ __forceinline__ bf16x8 tr_frag(const bf16* tr, int d, int t0, int g, int chp) {
-  const bf16x4 lo = *reinterpret_cast<const bf16x4*>(tr + d * chp + t0 * 16 + g * 4);
-  const bf16x4 hi = *reinterpret_cast<const bf16x4*>(tr + d * chp + t0 * 16 + 16 + g * 4);
-  bf16x8 o;
+// MFMA operand A = transposed fragment out of a ROW-MAJOR image: rows {t0*16+g*4..+3} U {t0*16+16+g*4..+3}, column d0 + l.
+// ds_read_b64_tr_b16 hands lane l of a 16-lane group column l of the 4x16 block whose (row l>>2, 4-column piece l&3)
+// address that lane supplies.
+template <int D>
+__device__ __forceinline__ bf16x8 trr_frag(const bf16* rm, int d0, int t0, int g, int l) {
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const bf16* a = rm + (t0 * 16 + g * 4 + (l >> 2)) * (D + 16) + d0 + (l & 3) * 4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + 16 * (D + 16)));
+  s16x8 o;
 #pragma unroll
   for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi[e]; }
-  return o;
+  return __builtin_bit_cast(bf16x8, o);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -127,15 +131,15 @@ __device__ __forceinline__ Lds carve(char* base, int nbias, int n_rm, int n_tr, 
   L.btab = reinterpret_cast<float*>(L.woff + CH);
   size_t off = (size_t)(5 * CH + ((nbias + 3) & ~3)) * 4;
   bf16* img = reinterpret_cast<bf16*>(base + off);
-  L.rm0 = img; img += (n_rm > 0) * chrows * (D + 8);
-  L.rm1 = img; img += (n_rm > 1) * chrows * (D + 8);
+  L.rm0 = img; img += (n_rm > 0) * chrows * (D + 16);
+  L.rm1 = img; img += (n_rm > 1) * chrows * (D + 16);
   L.tr0 = img; img += (n_tr > 0) * D * chp;
   L.tr1 = img;
   return L;
 }
 template <int D>
 size_t lds_bytes(int nbias, int n_rm, int n_tr, int chrows, int chp) {
-  return (size_t)(5 * CH + ((nbias + 3) & ~3)) * 4 + (size_t)n_rm * chrows * (D + 8) * 2 + (size_t)n_tr * D * chp * 2;
+  return (size_t)(5 * CH + ((nbias + 3) & ~3)) * 4 + (size_t)n_rm * chrows * (D + 16) * 2 + (size_t)n_tr * D * chp * 2;
 }
 
 // WINDOW mode: relative_position_index(i, j) = off(i) - off(j) + wconst with off(x) = row(x) * (2 ws - 1) + col(x)
@@ -155,7 +159,7 @@ __device__ __forceinline__ void fill_rowmeta(const AttnP& p, const Lds& L, int g
     float am = 0.f;
     if (j < len) {
       if (p.window) window_tok(p, g, j, tok, reg);
-      else { tok = g * len + j; if (keys && p.kmask) am = p.kmask[(size_t)g * len + j]; }
+      else { tok = g * len + j; if (keys && p.kmask) am = p.kmask[(size_t)g * len + j] * 1.4426950408889634f; }   // log2 domain
     } else {
       am = -INFINITY;
     }
@@ -171,12 +175,31 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = D / 32, DT = D / 16;
   const int nb = WINDOW ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
-  Lds L = carve<D>(smem, nb, 1, 1, p.chrows, p.chp);
-  bf16* Ks = L.rm0; bf16* Vt = L.tr0;
+  Lds L = carve<D>(smem, nb, 2, 0, p.chrows, p.chp);
+  bf16* Ks = L.rm0; bf16* Vs = L.rm1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int gq = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y, g = blockIdx.z;
-  const int strip = blockIdx.x * nw + wave;
+  for (int t = threadIdx.x; t < nb; t += blockDim.x) L.btab[t] = p.bias_table[(size_t)t * p.H + h] * 1.4426950408889634f;   // log2 domain
+  const int ntiles = (p.Lk + 15) / 16, nchunk = (ntiles + p.tpc_cap - 1) / p.tpc_cap, tpc = (ntiles + nchunk - 1) / nchunk;
+  const float sc2 = p.scale * 1.4426950408889634f;
+  const uint32_t thresh = (uint32_t)((double)p.p_drop * 4294967296.0);
+  const float inv_keep = 1.f / (1.f - p.p_drop);
+  // A key side that fits one chunk (text keys of the i2t cross-attention, text self-attention) is staged ONCE and the workgroup
+  // then walks query strips blockIdx.x*nw + wave, + gridDim.x*nw, ... without any further barrier: with one strip per wave the
+  // kernel was all per-workgroup set-up (row metadata, two barriers, staging) around a few MFMAs.
+  const bool once = nchunk == 1;
+  const int nstrips = (p.Lq + 15) / 16;
+  if (once) {
+    fill_rowmeta(p, L, g, 0, tpc * 16, p.Lk, true);
+    __syncthreads();
+    const int valid = min(tpc * 16, p.Lk);
+    stage<D>(p.k, p.ldk, h * D, L.rowmap, tpc * 16, valid, Ks);
+    stage<D>(p.v, p.ldv, h * D, L.rowmap, (tpc * 16 + 31) & ~31, valid, Vs);
+    __syncthreads();
+  }
+  for (int strip = blockIdx.x * nw + wave;; strip += gridDim.x * nw) {
+  if (once && strip >= nstrips) break;                  // (no barriers below in this mode)
   const int i = strip * 16 + lq;                      // this lane's query (window-local / sample-local)
   const bool qvalid = i < p.Lq;
   const int ioff = WINDOW ? win_off(p, qvalid ? i : 0) + win_const(p) : 0;   // this lane's query in relative-position offsets
@@ -185,31 +208,28 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnP p) {
     const int ic = qvalid ? i : p.Lq - 1;
     if (WINDOW) window_tok(p, g, ic, qtok, qreg); else qtok = g * p.Lq + ic;
   }
-  for (int t = threadIdx.x; t < nb; t += blockDim.x) L.btab[t] = p.bias_table[(size_t)t * p.H + h];
 
   bf16x8 qf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
     qf[ks] = *reinterpret_cast<const bf16x8*>(p.q + (size_t)qtok * p.ldq + h * D + ks * 32 + gq * 8);
 
-  const int ntiles = (p.Lk + 15) / 16, nchunk = (ntiles + p.tpc_cap - 1) / p.tpc_cap, tpc = (ntiles + nchunk - 1) / nchunk;
   float m = -INFINITY, lsum = 0.f;
   f32x4 oacc[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const uint32_t thresh = (uint32_t)((double)p.p_drop * 4294967296.0);
-  const float inv_keep = 1.f / (1.f - p.p_drop);
 
   for (int c = 0; c < nchunk; ++c) {
     const int kbase = c * tpc * 16;
-    __syncthreads();                                   // previous chunk fully consumed
-    fill_rowmeta(p, L, g, kbase, tpc * 16, p.Lk, true);
-    __syncthreads();
-    const int valid = min(tpc * 16, p.Lk - kbase);
-    stage<D, true, false>(p.k, p.ldk, h * D, L.rowmap, tpc * 16, valid, Ks, nullptr, p.chp);
-    stage<D, false, true>(p.v, p.ldv, h * D, L.rowmap, (tpc * 16 + 31) & ~31, valid, nullptr, Vt, p.chp);
-    __syncthreads();
-
+    if (!once) {
+      __syncthreads();                                 // previous chunk fully consumed
+      fill_rowmeta(p, L, g, kbase, tpc * 16, p.Lk, true);
+      __syncthreads();
+      const int valid = min(tpc * 16, p.Lk - kbase);
+      stage<D>(p.k, p.ldk, h * D, L.rowmap, tpc * 16, valid, Ks);
+      stage<D>(p.v, p.ldv, h * D, L.rowmap, (tpc * 16 + 31) & ~31, valid, Vs);
+      __syncthreads();
+    }
     f32x4 s[NKT];
     float cmax = -INFINITY;
 #pragma unroll
@@ -219,16 +239,16 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnP p) {
         f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 16 + lq) * (D + 8) + ks * 32 + gq * 8);
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 16 + lq) * (D + 16) + ks * 32 + gq * 8);
           a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], a, 0, 0, 0);   // S^T[key][query]
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int jl = kt * 16 + gq * 4 + r;
-          float v = a[r] * p.scale + L.addmask[jl];
+          float v = a[r] * sc2 + L.addmask[jl];               // scores in the log2 domain: exp is a bare v_exp_f32
           if (WINDOW) {
             v += L.btab[ioff - L.woff[jl]];
-            if (L.reg[jl] != qreg) v += -100.f;
+            if (L.reg[jl] != qreg) v += -144.26950408889634f;   // -100 * log2(e)
           }
           s[kt][r] = v;
           cmax = fmaxf(cmax, v);
@@ -237,14 +257,14 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnP p) {
     }
     cmax = group4_max(cmax);
     const float mnew = fmaxf(m, cmax);
-    const float alpha = __expf(m - mnew);             // m = -inf on the first chunk -> 0
+    const float alpha = __builtin_amdgcn_exp2f(m - mnew);   // m = -inf on the first chunk -> 0
     m = mnew;
     float psum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float e = kt < tpc ? __expf(s[kt][r] - mnew) : 0.f;
+        float e = kt < tpc ? __builtin_amdgcn_exp2f(s[kt][r] - mnew) : 0.f;
         psum += e;
         if (p.p_drop > 0.f) {
           const uint64_t idx = (((uint64_t)g * p.H + h) * p.Lq + (qvalid ? i : 0)) * p.Lk + kbase + kt * 16 + gq * 4 + r;
@@ -264,7 +284,7 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnP p) {
         const bf16x8 pf = pack8(s[2 * t2], s[2 * t2 + 1]);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-          const bf16x8 vf = tr_frag(Vt, dt * 16 + lq, 2 * t2, gq, p.chp);
+          const bf16x8 vf = trr_frag<D>(Vs, dt * 16, 2 * t2, gq, lq);
           oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, oacc[dt], 0, 0, 0);   // O^T[d][query]
         }
       }
@@ -280,7 +300,9 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnP p) {
       for (int r = 0; r < 4; ++r) o[r] = f2bf(oacc[dt][r] * inv);
       *reinterpret_cast<bf16x4*>(p.o + (size_t)qtok * p.ldo + h * D + dt * 16 + gq * 4) = o;
     }
-    if (gq == 0 && p.lse) p.lse[(size_t)qtok * p.H + h] = m + __logf(lsum);
+    if (gq == 0 && p.lse) p.lse[(size_t)qtok * p.H + h] = m * 0.6931471805599453f + __logf(lsum);
+  }
+  if (!once) break;
   }
 }
 
@@ -310,20 +332,17 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = D / 32, DT = D / 16;
   const int nb = WINDOW ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
-  Lds L = carve<D>(smem, nb, 2, 1, p.chrows, p.chp);
-  bf16* Ks = L.rm0; bf16* Vs = L.rm1; bf16* Kt = L.tr0;
+  Lds L = carve<D>(smem, nb, 2, 0, p.chrows, p.chp);
+  bf16* Ks = L.rm0; bf16* Vs = L.rm1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int gq = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y;
-  const int strip = blockIdx.x * nw + wave;
-  const int i = strip * 16 + lq;
-  const bool qvalid = i < p.Lq;
-  const int ioff = WINDOW ? win_off(p, qvalid ? i : 0) + win_const(p) : 0;   // this lane's query in relative-position offsets
-  for (int t = threadIdx.x; t < nb; t += blockDim.x) L.btab[t] = p.bias_table[(size_t)t * p.H + h];
+  for (int t = threadIdx.x; t < nb; t += blockDim.x) L.btab[t] = p.bias_table[(size_t)t * p.H + h] * 1.4426950408889634f;   // log2 domain
   const int ntiles = (p.Lk + 15) / 16, nchunk = (ntiles + p.tpc_cap - 1) / p.tpc_cap, tpc = (ntiles + nchunk - 1) / nchunk;
   const uint32_t thresh = (uint32_t)((double)p.p_drop * 4294967296.0);
   const float inv_keep = 1.f / (1.f - p.p_drop);
 
+  const float sc2 = p.scale * 1.4426950408889634f;
   const int g0 = blockIdx.z * p.groups_per_block, g1 = min(p.G, g0 + p.groups_per_block);
   // WINDOW mode walks key chunks outermost so that the per-lane dbias accumulator only ever spans one chunk
   // (N = 324 at 576^2 needs three); dQ is then accumulated across chunk passes by the lane that owns it.
@@ -334,6 +353,23 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
   for (int kt = 0; kt < NKT; ++kt) dbacc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int c_lo = WINDOW ? co : 0, c_hi = WINDOW ? co + 1 : nchunk;
   for (int g = g0; g < g1; ++g) {
+    // single-chunk key side without window bias (i2t cross-attention, text self-attention): stage once, then walk the query
+    // strips without further barriers (see attn_fwd_kernel)
+    const bool once = !WINDOW && nchunk == 1;
+    if (once) {
+      __syncthreads();
+      fill_rowmeta(p, L, g, 0, tpc * 16, p.Lk, true);
+      __syncthreads();
+      const int valid = min(tpc * 16, p.Lk);
+      stage<D>(p.k, p.ldk, h * D, L.rowmap, (tpc * 16 + 31) & ~31, valid, Ks);
+      stage<D>(p.v, p.ldv, h * D, L.rowmap, tpc * 16, valid, Vs);
+      __syncthreads();
+    }
+    for (int strip = blockIdx.x * nw + wave;; strip += gridDim.x * nw) {
+    if (once && strip >= (p.Lq + 15) / 16) break;
+    const int i = strip * 16 + lq;
+    const bool qvalid = i < p.Lq;
+    const int ioff = WINDOW ? win_off(p, qvalid ? i : 0) + win_const(p) : 0;   // this lane's query in relative-position offsets
     int qtok = 0, qreg = 0;
     {
       const int ic = qvalid ? i : p.Lq - 1;
@@ -345,20 +381,22 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
       qf[ks] = *reinterpret_cast<const bf16x8*>(p.q + (size_t)qtok * p.ldq + h * D + ks * 32 + gq * 8);
       dof[ks] = *reinterpret_cast<const bf16x8*>(p.dout + (size_t)qtok * p.lddo + h * D + ks * 32 + gq * 8);
     }
-    const float lse = p.lse[(size_t)qtok * p.H + h], dlt = p.delta[(size_t)qtok * p.H + h];
+    const float lse = p.lse[(size_t)qtok * p.H + h] * 1.4426950408889634f, dlt = p.delta[(size_t)qtok * p.H + h];   // lse in the log2 domain
     f32x4 dqacc[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) dqacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int c = c_lo; c < c_hi; ++c) {
       const int kbase = c * tpc * 16;
-      __syncthreads();
-      fill_rowmeta(p, L, g, kbase, tpc * 16, p.Lk, true);
-      __syncthreads();
-      const int valid = min(tpc * 16, p.Lk - kbase);
-      stage<D, true, true>(p.k, p.ldk, h * D, L.rowmap, (tpc * 16 + 31) & ~31, valid, Ks, Kt, p.chp);
-      stage<D, true, false>(p.v, p.ldv, h * D, L.rowmap, tpc * 16, valid, Vs, nullptr, p.chp);
-      __syncthreads();
+      if (!once) {
+        __syncthreads();
+        fill_rowmeta(p, L, g, kbase, tpc * 16, p.Lk, true);
+        __syncthreads();
+        const int valid = min(tpc * 16, p.Lk - kbase);
+        stage<D>(p.k, p.ldk, h * D, L.rowmap, (tpc * 16 + 31) & ~31, valid, Ks);
+        stage<D>(p.v, p.ldv, h * D, L.rowmap, tpc * 16, valid, Vs);
+        __syncthreads();
+      }
 #pragma unroll
       for (int t2 = 0; t2 < NKT / 2; ++t2) {
         if (t2 * 2 < tpc) {
@@ -371,20 +409,20 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
               f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
               for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 16 + lq) * (D + 8) + ks * 32 + gq * 8);
-                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + (kt * 16 + lq) * (D + 8) + ks * 32 + gq * 8);
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 16 + lq) * (D + 16) + ks * 32 + gq * 8);
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + (kt * 16 + lq) * (D + 16) + ks * 32 + gq * 8);
                 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], a, 0, 0, 0);     // S^T
                 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[ks], dp, 0, 0, 0);  // dP^T
               }
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const int jl = kt * 16 + gq * 4 + r;
-                float sv = a[r] * p.scale + L.addmask[jl];
+                float sv = a[r] * sc2 + L.addmask[jl];
                 if (WINDOW) {
                   sv += L.btab[ioff - L.woff[jl]];
-                  if (L.reg[jl] != qreg) sv += -100.f;
+                  if (L.reg[jl] != qreg) sv += -144.26950408889634f;
                 }
-                const float pr = __expf(sv - lse);
+                const float pr = __builtin_amdgcn_exp2f(sv - lse);
                 float dpe = dp[r];
                 if (p.p_drop > 0.f) {
                   const uint64_t idx = (((uint64_t)g * p.H + h) * p.Lq + (qvalid ? i : 0)) * p.Lk + kbase + jl;
@@ -402,7 +440,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
           const bf16x8 dsf = pack8(ds[0], ds[1]);
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
-            const bf16x8 ktf = tr_frag(Kt, dt * 16 + lq, 2 * t2, gq, p.chp);
+            const bf16x8 ktf = trr_frag<D>(Ks, dt * 16, 2 * t2, gq, lq);
             dqacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf, dqacc[dt], 0, 0, 0);   // dQ^T[d][query]
           }
         }
@@ -424,7 +462,11 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
         *dst = o;
       }
     }
+    if (!once) break;
+    }
   }
+  const int i = (blockIdx.x * nw + wave) * 16 + lq;     // (window mode: one strip per wave)
+  const bool qvalid = i < p.Lq;
   if (WINDOW && p.dbias_part && qvalid) {
     float* dst = p.dbias_part + (((size_t)blockIdx.z * p.H + h) * p.Lq + i) * p.Lk + co * tpc * 16;
 #pragma unroll
@@ -447,8 +489,8 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = D / 32, DT = D / 16;
   const int nb = WINDOW ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
-  Lds L = carve<D>(smem, nb, 2, 2, p.chrows, p.chp);
-  bf16* Qs = L.rm0; bf16* dOs = L.rm1; bf16* Qt = L.tr0; bf16* dOt = L.tr1;
+  Lds L = carve<D>(smem, nb, 2, 0, p.chrows, p.chp);
+  bf16* Qs = L.rm0; bf16* dOs = L.rm1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int gq = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y, g = blockIdx.z;
@@ -461,9 +503,9 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnP p) {
   {
     const int jc = kvalid ? j : p.Lk - 1;
     if (WINDOW) window_tok(p, g, jc, ktok, kreg);
-    else { ktok = g * p.Lk + jc; if (p.kmask) kadd = p.kmask[(size_t)g * p.Lk + jc]; }
+    else { ktok = g * p.Lk + jc; if (p.kmask) kadd = p.kmask[(size_t)g * p.Lk + jc] * 1.4426950408889634f; }
   }
-  for (int t = threadIdx.x; t < nb; t += blockDim.x) L.btab[t] = p.bias_table[(size_t)t * p.H + h];
+  for (int t = threadIdx.x; t < nb; t += blockDim.x) L.btab[t] = p.bias_table[(size_t)t * p.H + h] * 1.4426950408889634f;   // log2 domain
   bf16x8 kf[KS], vf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
@@ -473,6 +515,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnP p) {
   const int ntiles = (p.Lq + 15) / 16, nchunk = (ntiles + p.tpc_cap - 1) / p.tpc_cap, tpc = (ntiles + nchunk - 1) / nchunk;
   const uint32_t thresh = (uint32_t)((double)p.p_drop * 4294967296.0);
   const float inv_keep = 1.f / (1.f - p.p_drop);
+  const float sc2 = p.scale * 1.4426950408889634f;
   f32x4 dkacc[DT], dvacc[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) { dkacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -484,11 +527,11 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnP p) {
     __syncthreads();
     const int valid = min(tpc * 16, p.Lq - qbase);
     const int nst = (tpc * 16 + 31) & ~31;
-    stage<D, true, true>(p.q, p.ldq, h * D, L.rowmap, nst, valid, Qs, Qt, p.chp);
-    stage<D, true, true>(p.dout, p.lddo, h * D, L.rowmap, nst, valid, dOs, dOt, p.chp);
+    stage<D>(p.q, p.ldq, h * D, L.rowmap, nst, valid, Qs);
+    stage<D>(p.dout, p.lddo, h * D, L.rowmap, nst, valid, dOs);
     for (int r = threadIdx.x; r < tpc * 16; r += blockDim.x) {   // per-query lse (addmask slot) and delta (aux slot)
       const bool ok = r < valid;
-      L.addmask[r] = ok ? p.lse[(size_t)L.rowmap[r] * p.H + h] : INFINITY;   // +inf -> p = exp(-inf) = 0 for padded queries
+      L.addmask[r] = ok ? p.lse[(size_t)L.rowmap[r] * p.H + h] * 1.4426950408889634f : INFINITY;   // log2 domain; +inf -> p = exp2(-inf) = 0 for padded queries
       L.aux[r] = ok ? p.delta[(size_t)L.rowmap[r] * p.H + h] : 0.f;
     }
     __syncthreads();
@@ -505,8 +548,8 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnP p) {
             f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-              const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + (qt * 16 + lq) * (D + 8) + ks * 32 + gq * 8);
-              const bf16x8 df = *reinterpret_cast<const bf16x8*>(dOs + (qt * 16 + lq) * (D + 8) + ks * 32 + gq * 8);
+              const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + (qt * 16 + lq) * (D + 16) + ks * 32 + gq * 8);
+              const bf16x8 df = *reinterpret_cast<const bf16x8*>(dOs + (qt * 16 + lq) * (D + 16) + ks * 32 + gq * 8);
               a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[ks], a, 0, 0, 0);    // S[query][key]
               dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf[ks], dp, 0, 0, 0);  // dP[query][key]
             }
@@ -514,12 +557,12 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnP p) {
             for (int r = 0; r < 4; ++r) {
               const int il = qt * 16 + gq * 4 + r;      // chunk-local query
               const int ig = min(qbase + il, p.Lq - 1);
-              float sv = a[r] * p.scale + kadd;
+              float sv = a[r] * sc2 + kadd;
               if (WINDOW) {
                 sv += L.btab[L.woff[il] - joff];
-                if (L.reg[il] != kreg) sv += -100.f;
+                if (L.reg[il] != kreg) sv += -144.26950408889634f;
               }
-              float pr = kvalid ? __expf(sv - L.addmask[il]) : 0.f;
+              float pr = kvalid ? __builtin_amdgcn_exp2f(sv - L.addmask[il]) : 0.f;
               float dpe = dp[r], prd = pr;
               if (p.p_drop > 0.f) {
                 const uint64_t idx = (((uint64_t)g * p.H + h) * p.Lq + ig) * p.Lk + (kvalid ? j : 0);
@@ -535,8 +578,8 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnP p) {
         const bf16x8 dsf = pack8(ds[0], ds[1]), pf = pack8(pd[0], pd[1]);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-          const bf16x8 qtf = tr_frag(Qt, dt * 16 + lq, 2 * t2, gq, p.chp);
-          const bf16x8 dotf = tr_frag(dOt, dt * 16 + lq, 2 * t2, gq, p.chp);
+          const bf16x8 qtf = trr_frag<D>(Qs, dt * 16, 2 * t2, gq, lq);
+          const bf16x8 dotf = trr_frag<D>(dOs, dt * 16, 2 * t2, gq, lq);
           dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf, dkacc[dt], 0, 0, 0);   // dK^T[d][key]
           dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotf, pf, dvacc[dt], 0, 0, 0);   // dV^T[d][key]
         }
@@ -586,10 +629,23 @@ int pick_waves(int nstrips, int staged) {
 // workgroups (3-6 waves) per CU.
 void launch_geometry(AttnP& p, int staged_len, int nw, bool backward) {
   const int ntiles = cdiv(staged_len, 16);
-  p.tpc_cap = (backward && nw <= 4 && ntiles > 5 && !p.window) ? 5 : NKT;   // forward: one row-major + one transposed image only, shorter chunks just add barriers (t2i forward 388 -> 422 us)
+  // small workgroups want chunks short enough for three or four of them to share a CU's LDS: two row-major images of
+  // chrows x (D+16) plus 3.2 KB of tables.  Forward: 8 tiles (128 rows, 44 KB at D = 64 -> 3 workgroups; the full 160-row chunk
+  // leaves 2 and measured 386 -> 486 us on the t2i shape, 5-tile chunks add barriers: 422 us); backward: 5 tiles.
+  p.tpc_cap = (nw <= 4 && !p.window && ntiles > (backward ? 5 : 8)) ? (backward ? 5 : 8) : NKT;
   const int nchunk = cdiv(ntiles, p.tpc_cap), tpc = cdiv(ntiles, nchunk);
   p.chrows = (tpc * 16 + 31) & ~31;
   p.chp = p.chrows + 8;
+}
+
+// grid.x of the query-strip kernels.  When the staged side fits one chunk the kernels stage it once per workgroup and loop over
+// strips, so only as many workgroups per (head, group) are launched as it takes to fill the chip (~8 per CU overall).
+int strip_blocks(const AttnP& p, int staged_len, int nstrips, int nw, int hg, bool window_ok) {
+  const int full = cdiv(nstrips, nw);
+  const bool once = cdiv(cdiv(staged_len, 16), p.tpc_cap) == 1 && (window_ok || !p.window);
+  if (!once) return full;
+  const int want = cdiv(2048, hg);
+  return want < 1 ? 1 : (want < full ? want : full);
 }
 
 template <int D>
@@ -597,9 +653,10 @@ int launch_fwd(AttnP& p, hipStream_t st) {
   const int nstrips = cdiv(p.Lq, 16), nw = pick_waves(nstrips, p.Lk);
   const int nb = p.window ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
   launch_geometry(p, p.Lk, nw, false);
-  const size_t sh = lds_bytes<D>(nb, 1, 1, p.chrows, p.chp);
-  if (p.window) hipLaunchKernelGGL((attn_fwd_kernel<D, true>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), sh, st, p);
-  else hipLaunchKernelGGL((attn_fwd_kernel<D, false>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), sh, st, p);
+  const size_t sh = lds_bytes<D>(nb, 2, 0, p.chrows, p.chp);
+  const int gx = strip_blocks(p, p.Lk, nstrips, nw, p.H * p.G, true);
+  if (p.window) hipLaunchKernelGGL((attn_fwd_kernel<D, true>), dim3(gx, p.H, p.G), dim3(64 * nw), sh, st, p);
+  else hipLaunchKernelGGL((attn_fwd_kernel<D, false>), dim3(gx, p.H, p.G), dim3(64 * nw), sh, st, p);
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }
@@ -628,9 +685,9 @@ int launch_bwd(AttnP& p, float* delta, float* dbias_table, float* dbias_ws, int 
       p.dbias_part = dbias_ws;
     }
     launch_geometry(p, p.Lk, nw, true);
-    const size_t sh = lds_bytes<D>(nb, 2, 1, p.chrows, p.chp);
+    const size_t sh = lds_bytes<D>(nb, 2, 0, p.chrows, p.chp);
     if (p.window) hipLaunchKernelGGL((attn_bwd_dq_kernel<D, true>), dim3(cdiv(nstrips, nw), p.H, gz), dim3(64 * nw), sh, st, p);
-    else hipLaunchKernelGGL((attn_bwd_dq_kernel<D, false>), dim3(cdiv(nstrips, nw), p.H, gz), dim3(64 * nw), sh, st, p);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<D, false>), dim3(strip_blocks(p, p.Lk, nstrips, nw, p.H * gz, false), p.H, gz), dim3(64 * nw), sh, st, p);
     FIBER_CHECK_LAUNCH();
     if (p.window) {
       if (hipMemsetAsync(dbias_table, 0, (size_t)nb * p.H * sizeof(float), st) != hipSuccess) return FIBER_ELAUNCH;
@@ -641,7 +698,7 @@ int launch_bwd(AttnP& p, float* delta, float* dbias_table, float* dbias_ws, int 
   {
     const int nstrips = cdiv(p.Lk, 16), nw = pick_waves(nstrips, 1 << 20);   // key-strip pass: measured worse with small workgroups
     launch_geometry(p, p.Lq, nw, true);
-    const size_t sh = lds_bytes<D>(nb, 2, 2, p.chrows, p.chp);
+    const size_t sh = lds_bytes<D>(nb, 2, 0, p.chrows, p.chp);
     if (p.window) hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, true>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), sh, st, p);
     else hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, false>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), sh, st, p);
     FIBER_CHECK_LAUNCH();
