@@ -167,12 +167,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("FIBER_BENCH_BATCH", "256")), help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("FIBER_BENCH_BATCH", "0")),
+                    help="per-GPU batch (default: 256 for the headline task, 96 for mlm_itm_itc whose 1+3 fused passes hold "
+                         "more activations, 160 for vqa at 576^2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the forward-only and dominant-kernel timings (clean rocprof runs)")
     ap.add_argument("--task", choices=sorted(TASKS), default="mlm_itm",
                     help="default = BASELINE.json's metric; the others are extra configurations of the same path")
     args = ap.parse_args()
+    if args.batch <= 0:
+        args.batch = {"mlm_itm": 256, "mlm_itm_itc": 96, "vqa": 160}[args.task]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
