@@ -9,7 +9,11 @@
 //   * the next window's tiles and per-lane Q/dO fragments are PREFETCHED into registers (global loads in flight)
 //     while the MFMAs / softmax of the current window run, and written to LDS after the barrier (T14 split staging);
 //   * bias index = qoff(i) - keyoff(j): one LDS int4 read per 4 scores + one LDS float read per score, no divisions;
-//   * the shift mask is evaluated only for windows that touch the wrapped border (last window row / column).
+//   * the shift mask is evaluated only for windows that touch the wrapped border (last window row / column);
+//   * LDS holds ROW-MAJOR images only (96-B row stride, conflict-free for both access patterns); operands an MFMA needs
+//     transposed are read with ds_read_b64_tr_b16;
+//   * the kernels are VALU-issue bound (9 waves on 4 SIMDs, ~4.3 cycles per VALU wave-instruction), so bias, -lse/scale and
+//     -delta enter as MFMA accumulator seeds and each score costs one packed fma + one v_exp_f32.
 // Backward: pass A (wave = query strip) -> dQ and the relative-position-bias gradient, accumulated in registers over
 // all windows the workgroup visits; pass B (wave = key strip) -> dK, dV.
 #include <stdlib.h>
@@ -22,15 +26,15 @@ namespace {
 
 // Tile capacity is a template parameter MTT of every kernel / helper below: 10 tiles (N <= 160: the 12x12 windows of the 384^2
 // configurations, bias slice held in registers) or 21 tiles (N <= 336: the 18x18 windows of the 576^2 configuration, bias
-// looked up from LDS per score -- 84 more registers per lane do not exist).  MT / MAXN / TS are derived locally from it.
+// looked up from LDS per score -- 84 more registers per lane do not exist).  MT / MTP / MAXN are derived locally from it.
 // Row stride (elements) of the row-major LDS tiles: 32 + 16 pad = 96 B = 24 banks.  Both read patterns are then conflict-free
 // (MI355X_MICROARCH.md LDS table): ds_read_b128 serves lanes {0-3,12-15,20-27}... per cycle, whose 16 row starts 24*row + 4*g
 // tile the 64 banks, and ds_read_b64_tr_b16 serves 32 lanes = 8 rows x 32 B per cycle, 24*row mod 64 being the 8 multiples
 // of 8.  The former 80-B stride was 2-way conflicted on both (SQ_LDS_BANK_CONFLICT = 43 % of SQ_LDS_IDX_ACTIVE).
 constexpr int RS = 48;
 // (tiles are consumed in pairs by the second MFMA of each pass: an odd capacity is rounded up for the pair loops, the
-// per-tile register arrays and the transposed-image stride, the extra tile being all zeros)
-#define WIN_DIMS(MTT) constexpr int MT = (MTT), MTP = ((MTT) + 1) & ~1, MAXN = MTP * 16, TS = MAXN + 8; (void)MT; (void)MTP; (void)MAXN; (void)TS
+// per-tile register arrays and the image height, the extra tile being all zeros)
+#define WIN_DIMS(MTT) constexpr int MT = (MTT), MTP = ((MTT) + 1) & ~1, MAXN = MTP * 16; (void)MT; (void)MTP; (void)MAXN
 
 struct WinP {
   const bf16* qkv; bf16* o; const bf16* dout; bf16* dqkv;
@@ -48,19 +52,10 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
   for (int e = 0; e < 4; ++e) { o[e] = f2bf(a[e]); o[4 + e] = f2bf(b[e]); }
   return o;
 }
-template <int MTT>
-__device__ __forceinline__ bf16x8 tr_frag(const bf16* tr, int d, int t0, int g) {
-  WIN_DIMS(MTT);
-  const bf16x4 lo = *reinterpret_cast<const bf16x4*>(tr + d * TS + t0 * 16 + g * 4);
-  const bf16x4 hi = *reinterpret_cast<const bf16x4*>(tr + d * TS + t0 * 16 + 16 + g * 4);
-  bf16x8 o;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi[e]; }
-  return o;
-}
-// Same operand out of a ROW-MAJOR [token][32] image (row stride RS): ds_read_b64_tr_b16 hands lane l of a 16-lane group
-// column l of the 4x16 block whose (row l>>2, 4-column piece l&3) address that lane supplies, so the transposed copy of the
-// image never has to be written (8 ds_write_b16 per staged chunk less).
+// MFMA operand A (transposed fragment) out of a ROW-MAJOR [token][32] image (row stride RS): rows {t0*16+g*4..+3} U
+// {t0*16+16+g*4..+3}, column d0 + l.  ds_read_b64_tr_b16 hands lane l of a 16-lane group column l of the 4x16 block whose
+// (row l>>2, 4-column piece l&3) address that lane supplies, so a transposed copy of the image never has to be written
+// (8 ds_write_b16 per staged chunk less).
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 __device__ __forceinline__ bf16x8 trr_frag(const bf16* rm, int d0, int t0, int g, int l) {
   const bf16* a = rm + (t0 * 16 + g * 4 + (l >> 2)) * RS + d0 + (l & 3) * 4;
@@ -137,10 +132,10 @@ struct Geo {
 
 struct Smem {
   int* koff; int* kreg; float* btab; float* lse; float* dlt;
-  bf16* a0; bf16* a1; bf16* t0; bf16* t1;
+  bf16* a0; bf16* a1;
 };
 template <int MTT>
-__device__ __forceinline__ Smem carve(char* base, int nb, int n_rm, int n_tr) {
+__device__ __forceinline__ Smem carve(char* base, int nb, int n_rm) {
   WIN_DIMS(MTT);
   Smem S;
   S.koff = reinterpret_cast<int*>(base);
@@ -151,19 +146,17 @@ __device__ __forceinline__ Smem carve(char* base, int nb, int n_rm, int n_tr) {
   bf16* img = reinterpret_cast<bf16*>(base + (size_t)(4 * MAXN + ((nb + 3) & ~3)) * 4);
   S.a0 = img; img += (n_rm > 0) * MAXN * RS;
   S.a1 = img; img += (n_rm > 1) * MAXN * RS;
-  S.t0 = img; img += (n_tr > 0) * 32 * TS;
-  S.t1 = img;
   return S;
 }
 template <int MTT>
-size_t smem_bytes(int nb, int n_rm, int n_tr) {
+size_t smem_bytes(int nb, int n_rm) {
   WIN_DIMS(MTT);
-  return (size_t)(4 * MAXN + ((nb + 3) & ~3)) * 4 + (size_t)n_rm * MAXN * RS * 2 + (size_t)n_tr * 32 * TS * 2;
+  return (size_t)(4 * MAXN + ((nb + 3) & ~3)) * 4 + (size_t)n_rm * MAXN * RS * 2;
 }
 
 // common per-block setup: bias column of this head, key offsets, zeroed LDS tiles (padding rows stay zero forever)
 template <int MTT>
-__device__ __forceinline__ void setup(const WinP& p, const Smem& S, int h, int nb, int n_rm, int n_tr, float bias_mul, float lse_valid) {
+__device__ __forceinline__ void setup(const WinP& p, const Smem& S, int h, int nb, int n_rm, float bias_mul, float lse_valid) {
   WIN_DIMS(MTT);
   // bias column of this head, pre-multiplied into the domain the kernel adds it in (bias/scale or bias*log2e)
   for (int t = threadIdx.x; t < nb; t += blockDim.x) S.btab[t] = p.bias_table[(size_t)t * p.heads + h] * bias_mul;
@@ -177,7 +170,7 @@ __device__ __forceinline__ void setup(const WinP& p, const Smem& S, int h, int n
     S.lse[j] = j < p.N ? lse_valid : -INFINITY;
     S.dlt[j] = 0.f;
   }
-  const int words = (n_rm * MAXN * RS + n_tr * 32 * TS) / 2;
+  const int words = n_rm * MAXN * RS / 2;
   uint32_t* z = reinterpret_cast<uint32_t*>(S.a0);
   for (int t = threadIdx.x; t < words; t += blockDim.x) z[t] = 0u;
 }
@@ -190,7 +183,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
   WIN_DIMS(MTT);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nb = (2 * p.ws - 1) * (2 * p.ws - 1);
-  Smem S = carve<MTT>(smem, nb, 2, 0);
+  Smem S = carve<MTT>(smem, nb, 2);
   bf16* Ks = S.a0; bf16* Vs = S.a1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gq = lane >> 4, lq = lane & 15;
@@ -199,7 +192,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
   // compile-time for the 12x12 window (guards fold, the 10th tile's code disappears) and for the 21-tile variant (18x18
   // windows fill it; padded tiles of smaller windows carry bias = -inf and zero rows, so running them is only wasted work)
   const int ntile = NTC ? NTC : MT > 10 ? MT : (p.N + 15) >> 4;
-  setup<MTT>(p, S, h, nb, 2, 0, 5.656854249492381f, 0.f);
+  setup<MTT>(p, S, h, nb, 2, 5.656854249492381f, 0.f);
 
   // this thread's staging chunks: chunk id = tid + c*blockDim -> (row = id>>2 of the window, 16-byte piece id&3)
   int spr[MAXC], spc[MAXC];
@@ -290,9 +283,8 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
       qimg = geo.img(p);
       prefetch();
     }
-    // The body is instantiated twice (BORDER true/false) and selected by a wave-uniform branch per window: only windows
-    // on the wrapped border pay for the region-mask compares/selects (swin_transformer.py:327-350); padded key tiles carry
-    // bias = -inf so exp2 gives exact zeros without per-element selects.
+    // Only windows on the wrapped border pay for the region mask (one wave-uniform branch, swin_transformer.py:327-350);
+    // padded key tiles carry bias = -inf so exp2 gives exact zeros without per-element selects.
     f32x4 s[MTP];
     float mx = -INFINITY, sum;
     f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -392,7 +384,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
   WIN_DIMS(MTT);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nb = (2 * p.ws - 1) * (2 * p.ws - 1);
-  Smem S = carve<MTT>(smem, nb, 2, 0);
+  Smem S = carve<MTT>(smem, nb, 2);
   bf16* Ks = S.a0; bf16* Vs = S.a1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gq = lane >> 4, lq = lane & 15;
@@ -401,7 +393,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
   // compile-time for the 12x12 window (guards fold, the 10th tile's code disappears) and for the 21-tile variant (18x18
   // windows fill it; padded tiles of smaller windows carry bias = -inf and zero rows, so running them is only wasted work)
   const int ntile = NTC ? NTC : MT > 10 ? MT : (p.N + 15) >> 4;
-  setup<MTT>(p, S, h, nb, 2, 0, 5.656854249492381f, 0.f);
+  setup<MTT>(p, S, h, nb, 2, 5.656854249492381f, 0.f);
   int spr[MAXC], spc[MAXC];
   bool sval[MAXC];
 #pragma unroll
@@ -590,7 +582,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dkv_kernel(WinP
   WIN_DIMS(MTT);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nb = (2 * p.ws - 1) * (2 * p.ws - 1);
-  Smem S = carve<MTT>(smem, nb, 2, 0);
+  Smem S = carve<MTT>(smem, nb, 2);
   bf16* Qs = S.a0; bf16* dOs = S.a1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gq = lane >> 4, lq = lane & 15;
@@ -599,7 +591,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dkv_kernel(WinP
   // compile-time for the 12x12 window (guards fold, the 10th tile's code disappears) and for the 21-tile variant (18x18
   // windows fill it; padded tiles of smaller windows carry bias = -inf and zero rows, so running them is only wasted work)
   const int ntile = NTC ? NTC : MT > 10 ? MT : (p.N + 15) >> 4;
-  setup<MTT>(p, S, h, nb, 2, 0, 1.4426950408889634f, -INFINITY);
+  setup<MTT>(p, S, h, nb, 2, 1.4426950408889634f, -INFINITY);
   int spr[MAXC], spc[MAXC];
   bool sval[MAXC];
 #pragma unroll
@@ -862,9 +854,9 @@ int fiber_win_fwd_launch(const void* qkv, const float* bias_table, void* o, floa
   const int nb = (2 * ws - 1) * (2 * ws - 1);
   int nw, sg;
   strip_geometry(p.N, nw, sg);
-  if (big_window(p.N)) hipLaunchKernelGGL((win_fwd_kernel<3, 0, 21, false>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2, 0), st, p);
-  else if (p.N == 144 && (ntc_mask() & 1)) hipLaunchKernelGGL((win_fwd_kernel<1, 9>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2, 0), st, p);
-  else hipLaunchKernelGGL((win_fwd_kernel<1, 0>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2, 0), st, p);
+  if (big_window(p.N)) hipLaunchKernelGGL((win_fwd_kernel<3, 0, 21, false>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2), st, p);
+  else if (p.N == 144 && (ntc_mask() & 1)) hipLaunchKernelGGL((win_fwd_kernel<1, 9>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2), st, p);
+  else hipLaunchKernelGGL((win_fwd_kernel<1, 0>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2), st, p);
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }
@@ -890,16 +882,16 @@ int fiber_win_bwd_launch(const void* qkv, const float* bias_table, const void* o
   FIBER_CHECK_LAUNCH();
   const int gz = cdiv(p.G, p.gpb);
   const size_t slab = (size_t)nw * 10 * 64 * sizeof(float) * 4;   // dQ pass: per-lane bias slices [wave][tile][lane] x f32x4
-  if (big_window(p.N)) hipLaunchKernelGGL((win_bwd_dq_kernel<3, 0, 21, false>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2, 0), st, p);
-  else if (p.N == 144 && (ntc_mask() & 2)) hipLaunchKernelGGL((win_bwd_dq_kernel<1, 9>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2, 0) + slab, st, p);
-  else hipLaunchKernelGGL((win_bwd_dq_kernel<1, 0>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2, 0) + slab, st, p);
+  if (big_window(p.N)) hipLaunchKernelGGL((win_bwd_dq_kernel<3, 0, 21, false>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2), st, p);
+  else if (p.N == 144 && (ntc_mask() & 2)) hipLaunchKernelGGL((win_bwd_dq_kernel<1, 9>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2) + slab, st, p);
+  else hipLaunchKernelGGL((win_bwd_dq_kernel<1, 0>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2) + slab, st, p);
   FIBER_CHECK_LAUNCH();
   if (hipMemsetAsync(dbias_table, 0, (size_t)nb * heads * sizeof(float), st) != hipSuccess) return FIBER_ELAUNCH;
   hipLaunchKernelGGL(win_dbias_scatter_kernel, dim3(p.N, heads), dim3(256), 0, st, dbias_ws, dbias_table, gz, heads, ws);
   FIBER_CHECK_LAUNCH();
-  if (big_window(p.N)) hipLaunchKernelGGL((win_bwd_dkv_kernel<3, 0, 21, false>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2, 0), st, p);
-  else if (p.N == 144 && (ntc_mask() & 4)) hipLaunchKernelGGL((win_bwd_dkv_kernel<1, 9>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2, 0), st, p);
-  else hipLaunchKernelGGL((win_bwd_dkv_kernel<1, 0>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2, 0), st, p);
+  if (big_window(p.N)) hipLaunchKernelGGL((win_bwd_dkv_kernel<3, 0, 21, false>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2), st, p);
+  else if (p.N == 144 && (ntc_mask() & 4)) hipLaunchKernelGGL((win_bwd_dkv_kernel<1, 9>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2), st, p);
+  else hipLaunchKernelGGL((win_bwd_dkv_kernel<1, 0>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2), st, p);
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }
