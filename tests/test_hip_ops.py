@@ -215,6 +215,8 @@ def _mha_ref(q, k, v, kmask, B, heads, scale):
 @pytest.mark.parametrize("B,heads,Lq,Lk,D,masked", [
     (2, 12, 40, 40, 64, True), (2, 16, 576, 40, 32, True), (2, 12, 40, 576, 64, False), (3, 2, 12, 12, 64, True),
     (2, 32, 144, 40, 32, True), (2, 12, 40, 144, 64, False), (1, 2, 9, 6, 32, True), (2, 4, 50, 324, 64, False),
+    # many (head, sample) pairs: the single-chunk key side is staged once per workgroup, which then walks several query strips
+    (48, 16, 576, 40, 32, True), (64, 12, 200, 40, 64, True),
 ])
 def test_mha(ops, B, heads, Lq, Lk, D, masked):
     C = heads * D
