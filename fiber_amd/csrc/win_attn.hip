@@ -442,8 +442,8 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
 
   const int g0 = blockIdx.x * p.gpb, g1 = min(p.G, g0 + p.gpb);
   Geo geo;
-  bf16x8 kr[MAXC], vr[MAXC], qn = zero8(), don = zero8();
-  float lsen = 0.f, dltn = 0.f;
+  bf16x8 kr[MAXC], vr[MAXC], qn = zero8(), don = zero8(), on = zero8();
+  float lsen = 0.f;
   unsigned qpix = 0;
   size_t qimg = 0;
   auto prefetch = [&]() {
@@ -459,8 +459,8 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
     }
     qn = *reinterpret_cast<const bf16x8*>(at(base, qpix * ld + qo + gq * 8));
     don = *reinterpret_cast<const bf16x8*>(at(p.dout + qimg * C, qpix * C + h * 32 + gq * 8));
+    on = *reinterpret_cast<const bf16x8*>(at(static_cast<const bf16*>(p.o) + qimg * C, qpix * C + h * 32 + gq * 8));
     lsen = *at(p.lse + qimg * p.heads, qpix * p.heads + h);
-    dltn = *at(p.delta + qimg * p.heads, qpix * p.heads + h);
   };
   if (g0 < g1) {
     geo.set(p, g0);
@@ -485,10 +485,19 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
     const bf16x8 qf = qn, dof = don;
     // Accumulator seeds: q.k + bias/scale and dP - delta come straight out of the MFMAs, log2 p = that * scale*log2e - lse*log2e
     // is one fma; the lanes of padded queries get lse = +inf so that their p (and with it ds, dbias) is exactly 0.
-    const float nlse = qval ? lsen * -1.4426950408889634f : -INFINITY, dc = -dltn;
-    const f32x4 dseed = {dc, dc, dc, dc};
+    // delta[query] = sum_d dO*O (the softmax-backward row term) is computed here from the lane's 8-channel pieces of dO and O
+    // (4 v_dot2_f32_bf16 + a 4-lane sum) and written out for the dK/dV pass: no separate pass over O and dO.
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    float dpart = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2)
+      dpart = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, bf16x2{don[e], don[e + 1]}), __builtin_bit_cast(bf16x2_t, bf16x2{on[e], on[e + 1]}), dpart, false);
+    const float dlt = g4sum(dpart);
     const unsigned opix = qpix;
     const size_t oimg = qimg;
+    if (gq == 0 && qval) *at(const_cast<float*>(p.delta) + oimg * p.heads, opix * p.heads + h) = dlt;
+    const float nlse = qval ? lsen * -1.4426950408889634f : -INFINITY, dc = -dlt;
+    const f32x4 dseed = {dc, dc, dc, dc};
     __syncthreads();
     if (g + 1 < g1) {
       geo.next(p);
@@ -757,20 +766,6 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dkv_kernel(WinP
   }
 }
 
-// delta[row, h] = sum_d dO[row, h*32+d] * O[row, h*32+d]
-__global__ __launch_bounds__(256) void win_delta_kernel(const bf16* __restrict__ o, const bf16* __restrict__ dout,
-                                                        float* __restrict__ delta, size_t nvec, int H) {
-  for (size_t idx = blockIdx.x * (size_t)256 + threadIdx.x; idx < nvec; idx += (size_t)gridDim.x * 256) {
-    const bf16x8 a = reinterpret_cast<const bf16x8*>(o)[idx], b = reinterpret_cast<const bf16x8*>(dout)[idx];
-    float s = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s += bf2f(a[e]) * bf2f(b[e]);
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    if ((idx & 3) == 0) delta[idx >> 2] = s;           // [row, h] with 4 vectors per head
-  }
-}
-
 // dtable[rel_index(i,j), h] += sum_z part[z, h, i, j]
 __global__ __launch_bounds__(256) void win_dbias_scatter_kernel(const float* __restrict__ part, float* __restrict__ dtable,
                                                                 int nz, int H, int ws) {
@@ -876,10 +871,7 @@ int fiber_win_bwd_launch(const void* qkv, const float* bias_table, const void* o
   const int nb = (2 * ws - 1) * (2 * ws - 1);
   int nw, sg;
   strip_geometry(p.N, nw, sg);
-  const size_t nvec = (size_t)B * Hres * Wres * C / 8;
-  size_t g = (nvec + 255) / 256;
-  hipLaunchKernelGGL(win_delta_kernel, dim3((int)(g > 4096 ? 4096 : g)), dim3(256), 0, st, (const bf16*)o, (const bf16*)dout, delta_ws, nvec, heads);
-  FIBER_CHECK_LAUNCH();
+  // (delta[query, head] = sum_d dO*O is produced by the dQ pass itself and read back by the dK/dV pass)
   const int gz = cdiv(p.G, p.gpb);
   const size_t slab = (size_t)nw * 10 * 64 * sizeof(float) * 4;   // dQ pass: per-lane bias slices [wave][tile][lane] x f32x4
   if (big_window(p.N)) hipLaunchKernelGGL((win_bwd_dq_kernel<3, 0, 21, false>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2), st, p);
