@@ -38,7 +38,8 @@ constexpr int RS = 48;
 
 struct WinP {
   const bf16* qkv; bf16* o; const bf16* dout; bf16* dqkv;
-  float* lse; const float* delta; const float* bias_table; float* dbias_part;
+  float* lse; float* delta;   // delta: written by the dQ pass, read by the dK/dV pass
+  const float* bias_table; float* dbias_part;
   int B, Hres, Wres, C, heads, ws, shift, nWw, nWh, nW, G, N, gpb;
   int hmajor;   // qkv channel layout: 0 = [3][heads][32] (reference, swin_transformer.py:202), 1 = [heads][3][32] (q|k|v of a head adjacent)
 };
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
     const float dlt = g4sum(dpart);
     const unsigned opix = qpix;
     const size_t oimg = qimg;
-    if (gq == 0 && qval) *at(const_cast<float*>(p.delta) + oimg * p.heads, opix * p.heads + h) = dlt;
+    if (gq == 0 && qval) *at(p.delta + oimg * p.heads, opix * p.heads + h) = dlt;
     const float nlse = qval ? lsen * -1.4426950408889634f : -INFINITY, dc = -dlt;
     const f32x4 dseed = {dc, dc, dc, dc};
     __syncthreads();
