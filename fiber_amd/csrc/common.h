@@ -38,12 +38,12 @@ __device__ __forceinline__ float wave_max(float v) {
 //   erf(z) = 1 - (1 + a1 z + ... + a6 z^6)^-16  (z >= 0, |err| <= 3e-7),
 // with z = |x| / sqrt 2 folded into the coefficients and the 0.5 folded in as a 2^(1/16) scale of the polynomial, so that
 //   q = 1 / P(|x|)^16 = 0.5 erfc(|x| / sqrt 2),   Phi(x) = x >= 0 ? 1 - q : q.
-// Six FMAs, four squarings, ONE quarter-rate instruction (v_rcp_f32) and no v_exp: ~11 VALU issue slots per element with
+// Six FMAs, four squarings, ONE half-rate instruction (v_rcp_f32) and no v_exp, no compare / select: ~10 VALU issue slots per element with
 // the FMA/multiply chain on v_pk_*_f32 pairs, against ~25 for the 7.1.26 form (rcp + exp) that was VALU-bound in the fc1
 // epilogue (+420 us on a 620-GFLOP GEMM).  Measured |gelu - reference| <= 8e-7 over [-12, 12] (bf16 resolves 4e-3 relative).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 gelu_cdf2(f32x2 x) {
-  const f32x2 ax = {fabsf(x.x), fabsf(x.y)};
+// q = 0.5 erfc(ax / sqrt 2) for ax >= 0
+__device__ __forceinline__ f32x2 half_erfc2(f32x2 ax) {
   f32x2 p = ax * 5.621299351332709e-06f + 5.105520540382713e-05f;
   p = p * ax + 3.9686136005911976e-05f;
   p = p * ax + 0.0034227389842271805f;
@@ -51,10 +51,18 @@ __device__ __forceinline__ f32x2 gelu_cdf2(f32x2 x) {
   p = p * ax + 0.052075158804655075f;
   p = p * ax + 1.0442737340927124f;
   p = p * p; p = p * p; p = p * p; p = p * p;            // overflow -> inf -> q = 0 (|x| > ~25)
-  const f32x2 q = {__builtin_amdgcn_rcpf(p.x), __builtin_amdgcn_rcpf(p.y)};
-  return f32x2{x.x >= 0.f ? 1.f - q.x : q.x, x.y >= 0.f ? 1.f - q.y : q.y};
+  return f32x2{__builtin_amdgcn_rcpf(p.x), __builtin_amdgcn_rcpf(p.y)};
 }
-__device__ __forceinline__ f32x2 gelu2(f32x2 x) { return x * gelu_cdf2(x); }
+// Phi(x) = 0.5 + copysign(0.5 - q, x): two packed adds and a v_bfi per element instead of subtract + compare + select
+__device__ __forceinline__ f32x2 gelu_cdf2(f32x2 x) {
+  const f32x2 d = 0.5f - half_erfc2(f32x2{fabsf(x.x), fabsf(x.y)});
+  return f32x2{__builtin_copysignf(d.x, x.x), __builtin_copysignf(d.y, x.y)} + 0.5f;
+}
+// gelu(x) = x Phi(x) = max(x, 0) - |x| q = 0.5 (x + |x|) - |x| q: no select at all (packed add, multiply, fma)
+__device__ __forceinline__ f32x2 gelu2(f32x2 x) {
+  const f32x2 ax = {fabsf(x.x), fabsf(x.y)};
+  return __builtin_elementwise_fma(x + ax, f32x2{0.5f, 0.5f}, -(ax * half_erfc2(ax)));
+}
 // d/dx gelu(x) = Phi(x) + x phi(x)
 __device__ __forceinline__ f32x2 gelu_grad2(f32x2 x) {
   const f32x2 t = x * x * -0.72134752044448170368f;      // -0.5 x^2 log2(e)

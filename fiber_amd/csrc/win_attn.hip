@@ -121,8 +121,8 @@ struct Geo {
   // 32-bit per-lane value, so every global access is `saddr + 32-bit voffset` and no lane carries 64-bit addresses.
   __device__ __forceinline__ unsigned pix(const WinP& p, int pr, int pc) const {
     int r = wr * p.ws + pr + p.shift, c = wc * p.ws + pc + p.shift;
-    r = (int)min((unsigned)r, (unsigned)(r - p.Hres));   // r >= Hres ? r - Hres : r without a v_cndmask (17 cycles per
-    c = (int)min((unsigned)c, (unsigned)(c - p.Wres));   // wave-instruction on gfx950, tools/valu_probe.hip)
+    r = (int)min((unsigned)r, (unsigned)(r - p.Hres));   // r >= Hres ? r - Hres : r as one v_min_u32 (no compare + select)
+    c = (int)min((unsigned)c, (unsigned)(c - p.Wres));
     return (unsigned)(r * p.Wres + c);
   }
   __device__ __forceinline__ size_t img(const WinP& p) const { return (size_t)b * p.Hres * p.Wres; }
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) vf[t2][dt] = trr_frag(Vs, dt * 16, 2 * t2, gq, lq);
       __builtin_amdgcn_sched_barrier(0);
-      // VALU diet (a plain VALU op is ~4.3 cycles per wave on a SIMD, v_exp_f32 8.4, v_cndmask_b32 17): the softmax works on
+      // VALU diet (a plain VALU op is ~4.3 cycles per wave-instruction on a SIMD, v_exp_f32 / v_rcp_f32 8.4): the softmax works on
       // t = q.k + bias/scale straight out of the MFMA; p = exp2(t * scale*log2e - max) is ONE packed fma + exp2 per score.
       if (border) {                                       // one wave-uniform branch per window (swin_transformer.py:327-350)
 #pragma unroll

@@ -20,6 +20,11 @@ __global__ void k(float* out, long long* cyc, int iters) {
     if (OP == 6) { asm volatile(REP8("v_pk_add_f32 %0, %0, %1\n v_pk_add_f32 %1, %1, %2\n v_pk_add_f32 %2, %2, %3\n v_pk_add_f32 %3, %3, %0\n") : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3)); }
     if (OP == 7) { asm volatile(REP8("v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %0, vcc\n") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)); }
     if (OP == 8) { asm volatile(REP8("v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %1, vcc, %3, %2, %1\n") : "+v"(p0), "+v"(p1), "+v"(a0), "+v"(a1) : : "vcc"); }
+    if (OP == 10) { asm volatile(REP8("v_cmp_gt_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc\n v_cmp_gt_f32 vcc, %2, %3\n v_cndmask_b32 %2, %2, %3, vcc\n") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "vcc"); }
+    if (OP == 11) { asm volatile(REP8("v_bfi_b32 %0, %1, %0, %2\n v_bfi_b32 %1, %2, %1, %3\n v_bfi_b32 %2, %3, %2, %0\n v_bfi_b32 %3, %0, %3, %1\n") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)); }
+    if (OP == 12) { asm volatile(REP8("v_cndmask_b32_e64 %0, %0, %1, s[20:21]\n v_cndmask_b32_e64 %1, %1, %2, s[20:21]\n v_cndmask_b32_e64 %2, %2, %3, s[20:21]\n v_cndmask_b32_e64 %3, %3, %0, s[20:21]\n") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "s20", "s21"); }
+    if (OP == 13) { asm volatile(REP8("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)); }
+    if (OP == 14) { asm volatile(REP8("v_med3_f32 %0, %0, %1, %2\n v_med3_f32 %1, %1, %2, %3\n v_med3_f32 %2, %2, %3, %0\n v_med3_f32 %3, %3, %0, %1\n") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)); }
     if (OP == 9) { asm volatile(REP8("v_mul_lo_u32 %0, %0, %1\n v_mul_lo_u32 %1, %1, %2\n v_mul_lo_u32 %2, %2, %3\n v_mul_lo_u32 %3, %3, %0\n") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)); }
   }
   long long t1 = __builtin_readcyclecounter();
@@ -44,6 +49,7 @@ void run(const char* name, int per_iter) {
 }
 int main() {
   run<0>("v_fma_f32", 32); run<1>("v_exp_f32", 32); run<2>("v_pk_fma_f32", 32); run<3>("v_max3_f32", 32); run<4>("v_cvt_pk_bf16_f32", 32);
-  run<5>("v_add_f32", 32); run<6>("v_pk_add_f32", 32); run<7>("v_cndmask_b32", 32); run<8>("v_mad_u64_u32", 16); run<9>("v_mul_lo_u32", 32);
+  run<5>("v_add_f32", 32); run<6>("v_pk_add_f32", 32); run<7>("v_cndmask (stale vcc)", 32);   /* reads a VCC nothing ever wrote: 20 cycles, an artefact -- see v_cmp+v_cndmask */ run<8>("v_mad_u64_u32", 16); run<9>("v_mul_lo_u32", 32);
+  run<10>("v_cmp+v_cndmask", 32); run<11>("v_bfi_b32", 32); run<12>("v_cndmask_e64 sgpr", 32); run<13>("v_rcp_f32", 32); run<14>("v_med3_f32", 32);
   return 0;
 }
