@@ -12,8 +12,9 @@
 //                the sample's 40 text tokens, so repeat_interleave over windows disappears) and text->image cross
 //                attention (roberta.py:272-276: no mask).
 //
-// Structure (flash-style, no score tensor in HBM): a wave owns a strip of 16 queries; K and V^T of up to 160 keys are
-// staged in LDS per workgroup and shared by its waves; S^T = K.Q^T is computed with swapped MFMA operands so a lane
+// Structure (flash-style, no score tensor in HBM): a wave owns a strip of 16 queries; K and V of up to 160 keys are
+// staged in LDS per workgroup as row-major images and shared by its waves (the transposed MFMA operands -- V^T for P.V,
+// K^T, Q^T, dO^T in the backward -- are read with ds_read_b64_tr_b16); S^T = K.Q^T is computed with swapped MFMA operands so a lane
 // holds 4 consecutive keys of ONE query => row max / row sum are in-lane + two __shfl_xor (no LDS round trip), and the
 // fp32 probabilities convert in-register into the B operand of O^T = V^T.P^T (the key order inside a 32-key MFMA
 // k-slot is permuted identically on the V^T side, which is free).  Longer key ranges are walked in chunks with an
@@ -29,7 +30,6 @@ namespace {
 
 constexpr int NKT = 10;          // key (or query) tiles of 16 per LDS chunk  -> 160 rows
 constexpr int CH = NKT * 16;     // rows per chunk
-constexpr int CHP = CH + 8;      // padded row length of transposed LDS images (elements)
 
 struct AttnP {
   const bf16* q; const bf16* k; const bf16* v; bf16* o;       // forward tensors (row-major, head h at column h*D)
@@ -45,9 +45,8 @@ struct AttnP {
   const float* bias_table;   // [(2ws-1)^2, H] fp32
   float* dbias_part;         // [gridDim.z, H, N, N] fp32 partial bias gradients (pass A, WINDOW)
   int groups_per_block;      // pass A: windows visited by one workgroup
-  // LDS chunk geometry of this launch (host-chosen, launch_geometry()): tiles per chunk cap, rows of the row-major images,
-  // row length of the transposed images
-  int tpc_cap, chrows, chp;
+  // LDS chunk geometry of this launch (host-chosen, launch_geometry()): tiles per chunk cap, rows of the row-major images
+  int tpc_cap, chrows;
   // attention-probability dropout
   float p_drop; uint64_t seed;
 };
@@ -118,10 +117,10 @@ __device__ __forceinline__ bf16x8 trr_frag(const bf16* rm, int d0, int t0, int g
 // Shared LDS layout (dynamic): [rowmap int CH][reg int CH][addmask float CH][aux float CH][woff int CH][btab float nb] then bf16 images
 struct Lds {
   int* rowmap; int* reg; float* addmask; float* aux; int* woff; float* btab;
-  bf16* rm0; bf16* rm1; bf16* tr0; bf16* tr1;
+  bf16* rm0; bf16* rm1;
 };
 template <int D>
-__device__ __forceinline__ Lds carve(char* base, int nbias, int n_rm, int n_tr, int chrows, int chp) {
+__device__ __forceinline__ Lds carve(char* base, int nbias, int n_rm, int chrows) {
   Lds L;
   L.rowmap = reinterpret_cast<int*>(base);
   L.reg = L.rowmap + CH;
@@ -133,13 +132,11 @@ __device__ __forceinline__ Lds carve(char* base, int nbias, int n_rm, int n_tr, 
   bf16* img = reinterpret_cast<bf16*>(base + off);
   L.rm0 = img; img += (n_rm > 0) * chrows * (D + 16);
   L.rm1 = img; img += (n_rm > 1) * chrows * (D + 16);
-  L.tr0 = img; img += (n_tr > 0) * D * chp;
-  L.tr1 = img;
   return L;
 }
 template <int D>
-size_t lds_bytes(int nbias, int n_rm, int n_tr, int chrows, int chp) {
-  return (size_t)(5 * CH + ((nbias + 3) & ~3)) * 4 + (size_t)n_rm * chrows * (D + 16) * 2 + (size_t)n_tr * D * chp * 2;
+size_t lds_bytes(int nbias, int n_rm, int chrows) {
+  return (size_t)(5 * CH + ((nbias + 3) & ~3)) * 4 + (size_t)n_rm * chrows * (D + 16) * 2;
 }
 
 // WINDOW mode: relative_position_index(i, j) = off(i) - off(j) + wconst with off(x) = row(x) * (2 ws - 1) + col(x)
@@ -175,7 +172,7 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = D / 32, DT = D / 16;
   const int nb = WINDOW ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
-  Lds L = carve<D>(smem, nb, 2, 0, p.chrows, p.chp);
+  Lds L = carve<D>(smem, nb, 2, p.chrows);
   bf16* Ks = L.rm0; bf16* Vs = L.rm1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int gq = lane >> 4, lq = lane & 15;
@@ -332,7 +329,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = D / 32, DT = D / 16;
   const int nb = WINDOW ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
-  Lds L = carve<D>(smem, nb, 2, 0, p.chrows, p.chp);
+  Lds L = carve<D>(smem, nb, 2, p.chrows);
   bf16* Ks = L.rm0; bf16* Vs = L.rm1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int gq = lane >> 4, lq = lane & 15;
@@ -489,7 +486,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = D / 32, DT = D / 16;
   const int nb = WINDOW ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
-  Lds L = carve<D>(smem, nb, 2, 0, p.chrows, p.chp);
+  Lds L = carve<D>(smem, nb, 2, p.chrows);
   bf16* Qs = L.rm0; bf16* dOs = L.rm1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int gq = lane >> 4, lq = lane & 15;
@@ -635,7 +632,6 @@ void launch_geometry(AttnP& p, int staged_len, int nw, bool backward) {
   p.tpc_cap = (nw <= 4 && !p.window && ntiles > (backward ? 5 : 8)) ? (backward ? 5 : 8) : NKT;
   const int nchunk = cdiv(ntiles, p.tpc_cap), tpc = cdiv(ntiles, nchunk);
   p.chrows = (tpc * 16 + 31) & ~31;
-  p.chp = p.chrows + 8;
 }
 
 // grid.x of the query-strip kernels.  When the staged side fits one chunk the kernels stage it once per workgroup and loop over
@@ -653,7 +649,7 @@ int launch_fwd(AttnP& p, hipStream_t st) {
   const int nstrips = cdiv(p.Lq, 16), nw = pick_waves(nstrips, p.Lk);
   const int nb = p.window ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
   launch_geometry(p, p.Lk, nw, false);
-  const size_t sh = lds_bytes<D>(nb, 2, 0, p.chrows, p.chp);
+  const size_t sh = lds_bytes<D>(nb, 2, p.chrows);
   const int gx = strip_blocks(p, p.Lk, nstrips, nw, p.H * p.G, true);
   if (p.window) hipLaunchKernelGGL((attn_fwd_kernel<D, true>), dim3(gx, p.H, p.G), dim3(64 * nw), sh, st, p);
   else hipLaunchKernelGGL((attn_fwd_kernel<D, false>), dim3(gx, p.H, p.G), dim3(64 * nw), sh, st, p);
@@ -685,7 +681,7 @@ int launch_bwd(AttnP& p, float* delta, float* dbias_table, float* dbias_ws, int 
       p.dbias_part = dbias_ws;
     }
     launch_geometry(p, p.Lk, nw, true);
-    const size_t sh = lds_bytes<D>(nb, 2, 0, p.chrows, p.chp);
+    const size_t sh = lds_bytes<D>(nb, 2, p.chrows);
     if (p.window) hipLaunchKernelGGL((attn_bwd_dq_kernel<D, true>), dim3(cdiv(nstrips, nw), p.H, gz), dim3(64 * nw), sh, st, p);
     else hipLaunchKernelGGL((attn_bwd_dq_kernel<D, false>), dim3(strip_blocks(p, p.Lk, nstrips, nw, p.H * gz, false), p.H, gz), dim3(64 * nw), sh, st, p);
     FIBER_CHECK_LAUNCH();
@@ -698,7 +694,7 @@ int launch_bwd(AttnP& p, float* delta, float* dbias_table, float* dbias_ws, int 
   {
     const int nstrips = cdiv(p.Lk, 16), nw = pick_waves(nstrips, 1 << 20);   // key-strip pass: measured worse with small workgroups
     launch_geometry(p, p.Lq, nw, true);
-    const size_t sh = lds_bytes<D>(nb, 2, 0, p.chrows, p.chp);
+    const size_t sh = lds_bytes<D>(nb, 2, p.chrows);
     if (p.window) hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, true>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), sh, st, p);
     else hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, false>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), sh, st, p);
     FIBER_CHECK_LAUNCH();
@@ -732,8 +728,9 @@ int fiber_win_fwd_launch(const void* qkv, const float* bias_table, void* o, floa
                          int heads, int ws, int shift, int hmajor, hipStream_t st);
 int fiber_win_bwd_slices(int n_windows, int heads);
 int fiber_win_bwd_launch(const void* qkv, const float* bias_table, const void* o, const void* dout, const float* lse,
-                         void* dqkv, float* dbias_table, float* delta_ws, float* dbias_ws, int B, int Hres, int Wres, int C,
-                         int heads, int ws, int shift, int hmajor, hipStream_t st);
+                         void* dqkv, float* dbias_table, float* delta_ws, float* dbias_ws, float* dqkv_colsum, float* colsum_ws,
+                         int B, int Hres, int Wres, int C, int heads, int ws, int shift, int hmajor, hipStream_t st);
+int fiber_win_colsum_rows(int n_windows, int heads, int N);
 
 // --------------------------------------------------------------------------------------------------- C ABI
 // Window attention in image-token order.  qkv: [B*Hres*Wres, 3C] bf16 with channel layout [3][heads][32]
@@ -758,18 +755,24 @@ extern "C" int fiber_window_attn_fwd_bf16(const void* qkv, const float* bias_tab
 
 // Number of partial-gradient slices pass A uses for B*nW windows; workspace = slices * heads * N * N floats.
 extern "C" int fiber_window_attn_bwd_slices(int n_windows, int heads) { return fiber_win_bwd_slices(n_windows, heads); }
+// Rows of the column-sum workspace (0: this window size has no fused column sums, pass NULL for both pointers).
+extern "C" int fiber_window_attn_colsum_rows(int n_windows, int heads, int ws) {
+  return ws * ws <= 336 ? fiber_win_colsum_rows(n_windows, heads, ws * ws) : 0;
+}
 
 // Backward of the above.  dqkv: [B*Hres*Wres, 3C] (fully written); dbias_table fp32 [(2ws-1)^2, heads] (overwritten);
 // delta_ws: fp32 [B*Hres*Wres*heads]; dbias_ws: fp32 [slices*heads*N*N].
+// Optional: dqkv_colsum fp32 [3C] = column sums of dqkv (the bias gradient of the qkv linear, swin_transformer.py:197),
+// produced inside the two passes instead of by another pass over dqkv; colsum_ws fp32 [colsum_rows * 3C].  Both or neither.
 extern "C" int fiber_window_attn_bwd_bf16(const void* qkv, const float* bias_table, const void* o, const void* dout,
                                           const float* lse, void* dqkv, float* dbias_table, float* delta_ws,
-                                          float* dbias_ws, int B, int Hres, int Wres, int C, int heads, int ws, int shift,
-                                          int head_major, hipStream_t stream) {
+                                          float* dbias_ws, float* dqkv_colsum, float* colsum_ws, int B, int Hres, int Wres,
+                                          int C, int heads, int ws, int shift, int head_major, hipStream_t stream) {
   if (C != heads * 32 || Hres % ws || Wres % ws || shift < 0 || shift >= ws) return FIBER_EINVAL;
   if (ws * ws <= 336)
-    return fiber_win_bwd_launch(qkv, bias_table, o, dout, lse, dqkv, dbias_table, delta_ws, dbias_ws, B, Hres, Wres, C, heads,
-                                ws, shift, head_major, stream);
-  if (head_major) return FIBER_EINVAL;
+    return fiber_win_bwd_launch(qkv, bias_table, o, dout, lse, dqkv, dbias_table, delta_ws, dbias_ws, dqkv_colsum, colsum_ws, B,
+                                Hres, Wres, C, heads, ws, shift, head_major, stream);
+  if (head_major || dqkv_colsum || colsum_ws) return FIBER_EINVAL;   // (fiber_window_attn_colsum_rows() returns 0 for this path)
   ensure_attrs();
   AttnP p{};
   const bf16* base = (const bf16*)qkv;

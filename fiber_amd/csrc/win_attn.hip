@@ -40,6 +40,7 @@ struct WinP {
   const bf16* qkv; bf16* o; const bf16* dout; bf16* dqkv;
   float* lse; float* delta;   // delta: written by the dQ pass, read by the dK/dV pass
   const float* bias_table; float* dbias_part;
+  float* colsum_part;   // optional [gridDim.x * gridDim.z, 3C] fp32: per-workgroup column sums of dqkv (bias gradient of the qkv linear)
   int B, Hres, Wres, C, heads, ws, shift, nWw, nWh, nW, G, N, gpb;
   int hmajor;   // qkv channel layout: 0 = [3][heads][32] (reference, swin_transformer.py:202), 1 = [heads][3][32] (q|k|v of a head adjacent)
 };
@@ -153,6 +154,32 @@ template <int MTT>
 size_t smem_bytes(int nb, int n_rm) {
   WIN_DIMS(MTT);
   return (size_t)(4 * MAXN + ((nb + 3) & ~3)) * 4 + (size_t)n_rm * MAXN * RS * 2;
+}
+
+// Column sums of a backward pass's outputs (the bias gradient of the qkv linear), produced where the values already are instead
+// of by a second pass over dqkv: each lane adds its 4-channel pieces into private LDS slots once per window (ds_read_b128 +
+// add + ds_write_b128 on the thread's own slots: the register file is full; LDS float atomics measured 2.3x slower for the
+// whole backward), and at the end of the kernel 32 threads per 32-channel group sum the slots over waves and the 16 query /
+// key lanes and write one fp32 row per workgroup; a fold kernel adds the rows.  Thread t = wave*64 + g*16 + l owns channels
+// dt*16 + g*4 + 0..3 of query / key l; slot(piece k = grp*2 + dt, thread t) = slots[k * NTH + t] (f32x4), NTH = the kernel's
+// launch bound: lane-contiguous (conflict-free) and one address register + immediate offsets.
+template <int NV, int NTH>
+__device__ __forceinline__ void colsum_zero(f32x4* slots) {
+#pragma unroll
+  for (int k = 0; k < NV; ++k) slots[k * NTH + threadIdx.x] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+template <int NV, int NTH>
+__device__ __forceinline__ void colsum_flush(const f32x4* slots, float* dst_row, const int* chan0 /*[NV/2]*/) {
+  __syncthreads();
+  const int t = threadIdx.x, nwaves = blockDim.x >> 6;
+  if (t < 32 * (NV / 2)) {
+    const int grp = t >> 5, c = t & 31, dt = c >> 4, g = (c >> 2) & 3, r = c & 3;
+    const f32x4* col = slots + (grp * 2 + dt) * NTH + g * 16;
+    float s = 0.f;
+    for (int w = 0; w < nwaves; ++w)
+      for (int l = 0; l < 16; ++l) s += col[w * 64 + l][r];
+    dst_row[chan0[grp] + c] = s;
+  }
 }
 
 // common per-block setup: bias column of this head, key offsets, zeroed LDS tiles (padding rows stay zero forever)
@@ -383,6 +410,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
 template <int MAXC, int NTC = 0, int MTT = 10, bool BREG = true>
 __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP p) {
   WIN_DIMS(MTT);
+  constexpr int NTH = MAXC == 1 ? 640 : 448;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nb = (2 * p.ws - 1) * (2 * p.ws - 1);
   Smem S = carve<MTT>(smem, nb, 2);
@@ -415,6 +443,9 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
   // ds_read_b128 per tile) -- this kernel also carries the dbias accumulators, and 36 more registers for the slice left
   // nothing for keeping LDS operands in flight.
   f32x4* slab = reinterpret_cast<f32x4*>(S.a1 + MAXN * RS) + wave * MT * 64 + lane;
+  // column-sum slots of this kernel's dQ values (after the bias slab when there is one)
+  f32x4* cs_all = reinterpret_cast<f32x4*>(S.a1 + MAXN * RS) + (BREG ? (blockDim.x >> 6) * MT * 64 : 0);
+  if (p.colsum_part) colsum_zero<2, NTH>(cs_all);
   f32x4 dbacc[MTP];
   auto bias_tile = [&](int kt) -> f32x4 {                 // bias / scale (the seed of the q.k accumulator), -inf on padded keys
     if constexpr (BREG) {
@@ -498,7 +529,6 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
     const size_t oimg = qimg;
     if (gq == 0 && qval) *at(p.delta + oimg * p.heads, opix * p.heads + h) = dlt;
     const float nlse = qval ? lsen * -1.4426950408889634f : -INFINITY, dc = -dlt;
-    const f32x4 dseed = {dc, dc, dc, dc};
     __syncthreads();
     if (g + 1 < g1) {
       geo.next(p);
@@ -526,7 +556,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
           };
           auto mfmas = [&](int u) {
             sa[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[u], qf, sa[u], 0, 0, 0);
-            sdp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[u], dof, dseed, 0, 0, 0);
+            sdp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[u], dof, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
           };
           auto valu = [&](int u) {
             const int kt = 2 * t2 + u;
@@ -534,7 +564,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
             if (kt < ntile) {
               f32x4 sv = fma4(sa[u], scale * 1.4426950408889634f, nlse);   // log2 p; -inf on padded keys
               if constexpr (BORDER) sv = region_mask(sv, kg[u], qregf, -144.26950408889634f);
-              const f32x4 d = exp2x4(sv) * sdp[u];
+              const f32x4 d = exp2x4(sv) * (sdp[u] + dc);   // (-delta as a seed of the dP MFMA would pin four more registers)
               ds[u] = d;
               dbacc[kt] += d;
             }
@@ -570,6 +600,10 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
         *reinterpret_cast<bf16x4*>(at(p.dqkv + oimg * ld, opix * ld + qo + dt * 16 + gq * 4)) = o;
       }
     }
+    if (p.colsum_part) {                                 // (padded query lanes hold zeros)
+      f32x4* mine = cs_all + threadIdx.x;
+      mine[0] += dqacc[0] * scale; mine[NTH] += dqacc[1] * scale;
+    }
   }
   if (qval) {                                          // every (z, h, i, j<N) entry is written, zeros included
     float* dst = p.dbias_part + (((size_t)blockIdx.x * p.heads + h) * p.N + i) * p.N;
@@ -582,6 +616,10 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
           if (j < p.N) dst[j] = dbacc[kt][r];
         }
   }
+  if (p.colsum_part) {
+    const int chan0[1] = {qo};
+    colsum_flush<2, NTH>(cs_all, p.colsum_part + (size_t)(blockIdx.x * gridDim.z + blockIdx.z) * 3 * C, chan0);
+  }
 }
 
 // ================================================================ backward pass B: dK, dV ======================
@@ -590,10 +628,13 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
 template <int MAXC, int NTC = 0, int MTT = 10, bool BREG = true>
 __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dkv_kernel(WinP p) {
   WIN_DIMS(MTT);
+  constexpr int NTH = MAXC == 1 ? 640 : 448;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nb = (2 * p.ws - 1) * (2 * p.ws - 1);
   Smem S = carve<MTT>(smem, nb, 2);
   bf16* Qs = S.a0; bf16* dOs = S.a1;
+  f32x4* cs_all = reinterpret_cast<f32x4*>(S.a1 + MAXN * RS);   // column-sum slots of dK / dV (see colsum_flush)
+  if (p.colsum_part) colsum_zero<4, NTH>(cs_all);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gq = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y, C = p.C, ld = 3 * C;
@@ -764,6 +805,14 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dkv_kernel(WinP
         *reinterpret_cast<bf16x4*>(at(p.dqkv + oimg * ld, opix * ld + vo + dt * 16 + gq * 4)) = ov;
       }
     }
+    if (p.colsum_part) {                                 // (padded key lanes hold zeros)
+      f32x4* mine = cs_all + threadIdx.x;
+      mine[0] += dkacc[0] * scale; mine[NTH] += dkacc[1] * scale; mine[2 * NTH] += dvacc[0]; mine[3 * NTH] += dvacc[1];
+    }
+  }
+  if (p.colsum_part) {
+    const int chan0[2] = {ko, vo};
+    colsum_flush<4, NTH>(cs_all, p.colsum_part + (size_t)(blockIdx.x * gridDim.z + blockIdx.z) * 3 * C, chan0);
   }
 }
 
@@ -862,29 +911,41 @@ int fiber_win_bwd_slices(int n_windows, int heads) {
   return cdiv(n_windows, cdiv(n_windows, nz));
 }
 
+int fiber_win_colsum_rows(int n_windows, int heads, int N) {
+  int nw, sg;
+  strip_geometry(N, nw, sg);
+  return fiber_win_bwd_slices(n_windows, heads) * sg;
+}
+
+extern "C" int fiber_fold_rows_f32(const float* part, float* out, int rows, int N, hipStream_t stream);
+
 int fiber_win_bwd_launch(const void* qkv, const float* bias_table, const void* o, const void* dout, const float* lse,
-                         void* dqkv, float* dbias_table, float* delta_ws, float* dbias_ws, int B, int Hres, int Wres, int C,
-                         int heads, int ws, int shift, int hmajor, hipStream_t st) {
+                         void* dqkv, float* dbias_table, float* delta_ws, float* dbias_ws, float* dqkv_colsum, float* colsum_ws,
+                         int B, int Hres, int Wres, int C, int heads, int ws, int shift, int hmajor, hipStream_t st) {
   ensure_attrs();
   WinP p = make(qkv, B, Hres, Wres, C, heads, ws, shift, hmajor);
   p.o = (bf16*)o; p.lse = (float*)lse; p.bias_table = bias_table; p.dout = (const bf16*)dout; p.dqkv = (bf16*)dqkv;
-  p.delta = delta_ws; p.dbias_part = dbias_ws;
+  p.delta = delta_ws; p.dbias_part = dbias_ws; p.colsum_part = colsum_ws;
   const int nb = (2 * ws - 1) * (2 * ws - 1);
   int nw, sg;
   strip_geometry(p.N, nw, sg);
   // (delta[query, head] = sum_d dO*O is produced by the dQ pass itself and read back by the dK/dV pass)
   const int gz = cdiv(p.G, p.gpb);
   const size_t slab = (size_t)nw * 10 * 64 * sizeof(float) * 4;   // dQ pass: per-lane bias slices [wave][tile][lane] x f32x4
-  if (big_window(p.N)) hipLaunchKernelGGL((win_bwd_dq_kernel<3, 0, 21, false>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2), st, p);
-  else if (p.N == 144 && (ntc_mask() & 2)) hipLaunchKernelGGL((win_bwd_dq_kernel<1, 9>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2) + slab, st, p);
-  else hipLaunchKernelGGL((win_bwd_dq_kernel<1, 0>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2) + slab, st, p);
+  const size_t nth = big_window(p.N) ? 448 : 640;        // launch bounds = slot stride of the column-sum slots
+  const size_t csq = colsum_ws ? nth * 2 * 16 : 0, cskv = colsum_ws ? nth * 4 * 16 : 0;
+  if ((colsum_ws == nullptr) != (dqkv_colsum == nullptr)) return FIBER_EINVAL;
+  if (big_window(p.N)) hipLaunchKernelGGL((win_bwd_dq_kernel<3, 0, 21, false>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2) + csq, st, p);
+  else if (p.N == 144 && (ntc_mask() & 2)) hipLaunchKernelGGL((win_bwd_dq_kernel<1, 9>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2) + slab + csq, st, p);
+  else hipLaunchKernelGGL((win_bwd_dq_kernel<1, 0>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2) + slab + csq, st, p);
   FIBER_CHECK_LAUNCH();
   if (hipMemsetAsync(dbias_table, 0, (size_t)nb * heads * sizeof(float), st) != hipSuccess) return FIBER_ELAUNCH;
   hipLaunchKernelGGL(win_dbias_scatter_kernel, dim3(p.N, heads), dim3(256), 0, st, dbias_ws, dbias_table, gz, heads, ws);
   FIBER_CHECK_LAUNCH();
-  if (big_window(p.N)) hipLaunchKernelGGL((win_bwd_dkv_kernel<3, 0, 21, false>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2), st, p);
-  else if (p.N == 144 && (ntc_mask() & 4)) hipLaunchKernelGGL((win_bwd_dkv_kernel<1, 9>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2), st, p);
-  else hipLaunchKernelGGL((win_bwd_dkv_kernel<1, 0>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2), st, p);
+  if (big_window(p.N)) hipLaunchKernelGGL((win_bwd_dkv_kernel<3, 0, 21, false>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2) + cskv, st, p);
+  else if (p.N == 144 && (ntc_mask() & 4)) hipLaunchKernelGGL((win_bwd_dkv_kernel<1, 9>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2) + cskv, st, p);
+  else hipLaunchKernelGGL((win_bwd_dkv_kernel<1, 0>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2) + cskv, st, p);
   FIBER_CHECK_LAUNCH();
+  if (colsum_ws) return fiber_fold_rows_f32(colsum_ws, dqkv_colsum, gz * sg, 3 * C, st);
   return FIBER_OK;
 }

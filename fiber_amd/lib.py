@@ -21,7 +21,7 @@ SIGNATURES = {
     "fiber_patch_merge_ln_fwd_bf16": [P, P, P, P, P, P, I, I, I, I, F],
     "fiber_patch_merge_ln_bwd_bf16": [P, P, P, P, P, P, P, P, P, I, I, I, I],
     "fiber_window_attn_fwd_bf16": [P, P, P, P, I, I, I, I, I, I, I, I],
-    "fiber_window_attn_bwd_bf16": [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I],
+    "fiber_window_attn_bwd_bf16": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I],
     "fiber_mha_fwd_bf16": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, F, U64],
     "fiber_mha_bwd_bf16": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, F, F, U64],
     "fiber_roberta_embed_fwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, U64],
@@ -41,7 +41,7 @@ SIGNATURES = {
     "fiber_adamw_multi_f32": [P, P, P, I, F, F, F, F, F, I],
 }
 # host-side helpers without a stream argument
-PLAIN = {"fiber_layernorm_bwd_grid": [I], "fiber_window_attn_bwd_slices": [I, I], "fiber_colsum_slabs": [I, I], "fiber_gemm_row_tile": [I, I, I],
+PLAIN = {"fiber_layernorm_bwd_grid": [I], "fiber_window_attn_bwd_slices": [I, I], "fiber_window_attn_colsum_rows": [I, I, I], "fiber_colsum_slabs": [I, I], "fiber_gemm_row_tile": [I, I, I],
          "fiber_adamw_chunk": []}
 
 _lib = None

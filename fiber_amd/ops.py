@@ -270,6 +270,26 @@ def wgrad(dh, x2):
     return out.sum(0)
 
 
+# Column sums that a backward kernel produced together with its output (window attention: the qkv bias gradient).  The
+# producer leaves (data_ptr, shape, sums) here; the NEXT linear backward takes the slot -- and uses it only if it is about
+# the very tensor it received as dY.  Every linear backward clears the slot, so it can never be matched against a later
+# tensor that happens to reuse the address; a missed hand-over only costs the separate column-sum pass.
+_COLSUM_HINT = None
+
+
+def _offer_colsum(t2d, sums):
+    global _COLSUM_HINT
+    _COLSUM_HINT = (t2d.data_ptr(), tuple(t2d.shape), sums)
+
+
+def _take_colsum(t2d):
+    global _COLSUM_HINT
+    h, _COLSUM_HINT = _COLSUM_HINT, None
+    if h is not None and h[0] == t2d.data_ptr() and h[1] == tuple(t2d.shape):
+        return h[2]
+    return None
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, act, rowscale):
@@ -290,6 +310,7 @@ class _Linear(torch.autograd.Function):
         dy2 = _c(dy).view(-1, weight.shape[0])
         dres = dy if ctx.has_res else None
         db = None
+        hint = _take_colsum(dy2)
         if rowscale is not None:                      # branch gradient = per-sample scale * dy
             if ctx.has_bias and ctx.needs_input_grad[2] and not ctx.act and dy2.shape[1] % 8 == 0:
                 dy2, db = rowscale_colsum(dy2, rowscale)       # ... and the bias gradient from the same pass
@@ -306,7 +327,8 @@ class _Linear(torch.autograd.Function):
         dx = lib_matmul(dh, wb).view(ctx.shp) if ctx.needs_input_grad[0] else None
         dw = wgrad(dh, x2) if ctx.needs_input_grad[1] else None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = db if db is not None else colsum(dh)
+            if db is None:
+                db = hint if (hint is not None and dh is dy2) else colsum(dh)
         else:
             db = None
         return dx, dw, db, dres, None, None
@@ -502,8 +524,14 @@ class _WindowAttn(torch.autograd.Function):
         delta = torch.empty((rows, heads), dtype=torch.float32, device=do.device)
         nz = lib.plain("fiber_window_attn_bwd_slices", rows // N, heads)
         part = torch.empty(nz * heads * N * N, dtype=torch.float32, device=do.device)
+        # column sums of dqkv (= bias gradient of the qkv linear) come out of the same two passes
+        cs_rows = lib.plain("fiber_window_attn_colsum_rows", rows // N, heads, ws)
+        csum = torch.empty(3 * C, dtype=torch.float32, device=do.device) if cs_rows else None
+        cs_ws = torch.empty(cs_rows * 3 * C, dtype=torch.float32, device=do.device) if cs_rows else None
         lib.call("fiber_window_attn_bwd_bf16", lib.ptr(qkv), lib.ptr(bias_table), lib.ptr(o), lib.ptr(do), lib.ptr(lse), lib.ptr(dqkv),
-                 lib.ptr(dtab), lib.ptr(delta), lib.ptr(part), B, H, W, C, heads, ws, shift, head_major)
+                 lib.ptr(dtab), lib.ptr(delta), lib.ptr(part), lib.ptr(csum), lib.ptr(cs_ws), B, H, W, C, heads, ws, shift, head_major)
+        if csum is not None:
+            _offer_colsum(dqkv.view(-1, 3 * C), csum)
         return dqkv, dtab, None, None, None, None, None, None, None
 
 
@@ -558,11 +586,12 @@ class _LinearQKVHeadMajor(torch.autograd.Function):
     def backward(ctx, dy):
         x2, weight = ctx.saved_tensors
         dy2 = _c(dy).view(-1, weight.shape[0])
+        hint = _take_colsum(dy2)
         perm, inv = _qkv_perm(weight.shape[1], ctx.heads, dy.device)
         wp = _wcache[("HM", id(weight))][1][0]
         dx = lib_matmul(dy2, wp).view(ctx.shp)
         dw = wgrad(dy2, x2)[inv]
-        db = colsum(dy2)[inv]
+        db = (hint if hint is not None else colsum(dy2))[inv]
         return dx, dw, db, None
 
 

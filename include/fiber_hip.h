@@ -52,9 +52,13 @@ int fiber_patch_merge_ln_bwd_bf16(const void* dy, const void* x, const float* ga
 int fiber_window_attn_fwd_bf16(const void* qkv, const float* bias_table, void* o, float* lse, int B, int Hres, int Wres, int C,
                                int heads, int ws, int shift, int head_major, fiber_stream_t stream);
 int fiber_window_attn_bwd_slices(int n_windows, int heads);
+int fiber_window_attn_colsum_rows(int n_windows, int heads, int ws);   /* rows of colsum_ws; 0 = not available for this ws */
+/* dqkv_colsum (optional, fp32[3C]) = column sums of dqkv = bias gradient of the qkv nn.Linear (swin_transformer.py:197),
+ * produced by the two passes themselves; colsum_ws fp32[colsum_rows*3C].  Pass both or neither (NULL). */
 int fiber_window_attn_bwd_bf16(const void* qkv, const float* bias_table, const void* o, const void* dout, const float* lse,
-                               void* dqkv, float* dbias_table, float* delta_ws, float* dbias_ws, int B, int Hres, int Wres,
-                               int C, int heads, int ws, int shift, int head_major, fiber_stream_t stream);
+                               void* dqkv, float* dbias_table, float* delta_ws, float* dbias_ws, float* dqkv_colsum,
+                               float* colsum_ws, int B, int Hres, int Wres, int C, int heads, int ws, int shift, int head_major,
+                               fiber_stream_t stream);
 
 /* Generic MHA core softmax(q.k^T*scale + kmask).v with optional attention-prob dropout: RoBERTa self-attention
  * (roberta.py:256-326), image->text cross-attention (swin_transformer.py:226-256) and text->image cross-attention

@@ -178,6 +178,42 @@ def test_window_attention(ops, B, H, W, heads, ws, shift):
     oref.backward(do.float())
     assert_close("dqkv", qkv.grad, qr.grad, 1e-2)
     assert_close("dbias_table", table.grad, tr.grad, 1e-2)
+    # the backward passes also hand the column sums of dqkv (the qkv bias gradient) to the next linear backward
+    from fiber_amd import ops as ops_mod
+    hint, ops_mod._COLSUM_HINT = ops_mod._COLSUM_HINT, None
+    assert hint is not None and hint[1] == (B * H * W, 3 * C)
+    assert_close("colsum(dqkv)", hint[2], qr.grad.reshape(-1, 3 * C).sum(0), 1e-2)
+
+
+def test_window_attention_qkv_bias_grad_handover(ops):
+    """linear -> window attention: the qkv bias gradient comes from the attention backward's fused column sums (no colsum
+    launch), also with the head-major layout, and equals the column sums of the dqkv it describes; an unrelated linear
+    backward in between clears the hand-over slot instead of consuming it."""
+    from fiber_amd import lib as lib_mod, ops as ops_mod
+    B, H, W, heads, ws, shift = 2, 24, 24, 4, 12, 6
+    C = heads * 32
+    x = bf(rnd(B, H * W, C)).requires_grad_(True)
+    w = rnd(3 * C, C, std=C ** -0.5).to(DEV).requires_grad_(True)
+    b = rnd(3 * C, seed=1, std=0.1).to(DEV).requires_grad_(True)
+    table = rnd((2 * ws - 1) ** 2, heads, std=0.5).to(DEV).requires_grad_(True)
+    do = bf(rnd(B, H * W, C, seed=5))
+    real_call, launched = lib_mod.call, []
+    lib_mod.call = lambda name, *a: (launched.append(name), real_call(name, *a))[1]
+    try:
+        for hm in (False, True):
+            b.grad = None
+            launched.clear()
+            qkv = ops.linear_qkv_head_major(x, w, b, heads) if hm else ops.linear(x, w, b)
+            qkv.retain_grad()
+            ops.window_attention(qkv, table, B, H, W, heads, ws, shift, head_major=hm).backward(do)
+            assert "fiber_colsum_bf16" not in launched
+            ref = qkv.grad.float().reshape(-1, 3 * C).sum(0)
+            if hm:
+                ref = ref[ops_mod._qkv_perm(C, heads, ref.device)[1]]
+            assert_close("db", b.grad, ref, 1e-2)
+    finally:
+        lib_mod.call = real_call
+    assert ops_mod._COLSUM_HINT is None
 
 
 @pytest.mark.parametrize("B,H,W,heads,ws,shift", [(2, 8, 8, 2, 4, 2), (1, 24, 24, 4, 12, 6), (2, 14, 14, 3, 7, 3)])
