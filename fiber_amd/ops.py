@@ -277,9 +277,16 @@ def wgrad(dh, x2):
 _COLSUM_HINT = None
 
 
+def _clear_colsum():
+    global _COLSUM_HINT
+    _COLSUM_HINT = None
+
+
 def _offer_colsum(t2d, sums):
+    """Called from inside a backward(): the offer never outlives the autograd pass it was made in."""
     global _COLSUM_HINT
     _COLSUM_HINT = (t2d.data_ptr(), tuple(t2d.shape), sums)
+    torch.autograd.Variable._execution_engine.queue_callback(_clear_colsum)
 
 
 def _take_colsum(t2d):

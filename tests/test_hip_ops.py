@@ -178,11 +178,20 @@ def test_window_attention(ops, B, H, W, heads, ws, shift):
     oref.backward(do.float())
     assert_close("dqkv", qkv.grad, qr.grad, 1e-2)
     assert_close("dbias_table", table.grad, tr.grad, 1e-2)
-    # the backward passes also hand the column sums of dqkv (the qkv bias gradient) to the next linear backward
+    # the backward passes also offer the column sums of dqkv (the qkv bias gradient) to the next linear backward; an offer
+    # nobody took does not outlive its autograd pass
     from fiber_amd import ops as ops_mod
-    hint, ops_mod._COLSUM_HINT = ops_mod._COLSUM_HINT, None
-    assert hint is not None and hint[1] == (B * H * W, 3 * C)
-    assert_close("colsum(dqkv)", hint[2], qr.grad.reshape(-1, 3 * C).sum(0), 1e-2)
+    assert ops_mod._COLSUM_HINT is None
+    seen = []
+    real_offer = ops_mod._offer_colsum
+    ops_mod._offer_colsum = lambda t, sums: (seen.append((tuple(t.shape), sums)), real_offer(t, sums))[1]
+    try:
+        qkv.grad = None
+        ops.window_attention(qkv, table, B, H, W, heads, ws, shift).backward(do)
+    finally:
+        ops_mod._offer_colsum = real_offer
+    assert ops_mod._COLSUM_HINT is None and len(seen) == 1 and seen[0][0] == (B * H * W, 3 * C)
+    assert_close("colsum(dqkv)", seen[0][1], qr.grad.reshape(-1, 3 * C).sum(0), 1e-2)
 
 
 def test_window_attention_qkv_bias_grad_handover(ops):
