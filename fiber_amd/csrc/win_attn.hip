@@ -845,8 +845,7 @@ void ensure_attrs() {
   attrs_set = true;
 }
 
-// waves per workgroup / strip groups: small workgroups (<= 4 waves) so that several co-reside on a CU and one group's
-// barrier / staging phases overlap the others' MFMA phases (one 9-wave workgroup per CU left the CU idle at barriers)
+// waves per workgroup / strip groups of the three passes
 void strip_geometry(int N, int& nw, int& sg) {
   // N <= 160: one workgroup per (window run, head) with one wave per 16-query strip: each thread stages exactly one 16-byte
   // chunk (MAXC = 1).  A split into <=4-wave strip groups (MAXC = 3, several workgroups per CU) measured no faster.
@@ -855,9 +854,10 @@ void strip_geometry(int N, int& nw, int& sg) {
   else { nw = 7; sg = cdiv(cdiv(N, 16), 7); }
 }
 
-// which kernels use the compile-time tile count for 12x12 windows (bit 0 forward, 1 dQ pass, 2 dK/dV pass).  Measured at
-// 512 images, stage 0 (tools/op_bench.py 512 attn): forward 1828 -> 1542 us; backward 7441 us with neither pass, 8837 with the
-// dQ pass on it (that kernel already sits at the 168-VGPR cap and spills more), 7301 with the dK/dV pass -> forward + dK/dV.
+// which kernels use the compile-time tile count for 12x12 windows (bit 0 forward, 1 dQ pass, 2 dK/dV pass; FIBER_WIN_NTC).
+// Forward 1828 -> 1542 us at 512 images, stage 0, when it was introduced.  The dQ pass could not afford it while its bias slice
+// lived in registers (168-VGPR cap, spills inside the window loop: backward 7441 -> 8837 us); with the slice in an LDS slab all
+// three passes use it.
 int ntc_mask() {
   static const int m = getenv("FIBER_WIN_NTC") ? atoi(getenv("FIBER_WIN_NTC")) : 7;
   return m;
