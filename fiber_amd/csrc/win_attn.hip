@@ -864,10 +864,13 @@ int ntc_mask() {
 }
 
 int blocks_for(int G, int heads) {
-  // One 9-wave workgroup fits per CU, so launch exactly one round (256 workgroups = 256/heads window runs per head):
+  // One 9-wave workgroup fits per CU.  One round of 256 workgroups (256/heads window runs per head) when there are few heads:
   // rocprof ablation showed ~45 % of the kernel was per-workgroup setup (bias column, key offsets, LDS clear, bias-slice
-  // gather) + per-window geometry when 768 short-lived workgroups ran in 3 rounds.
-  static const int per = getenv("FIBER_WIN_BLOCKS") ? atoi(getenv("FIBER_WIN_BLOCKS")) : 256;
+  // gather) + per-window geometry when 768 short-lived workgroups ran in 3 rounds.  From 8 heads on (stages 1-3: fewer windows
+  // per run, so the end of the single round is ragged) two rounds of half-length runs measured 3-8 % faster
+  // (tools/op_bench.py 512 attn: stage 2 forward 399 -> 368 us, backward 1790 -> 1716 us; stage 0 backward 5880 -> 5966 us).
+  static const int forced = getenv("FIBER_WIN_BLOCKS") ? atoi(getenv("FIBER_WIN_BLOCKS")) : 0;
+  const int per = forced > 0 ? forced : (heads >= 8 ? 512 : 256);
   int nz = per / heads;
   nz = nz < 1 ? 1 : nz;
   return nz > G ? G : nz;
