@@ -100,13 +100,22 @@ __global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(const bf16* __rest
   const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (col < N) {
-    for (int r = r0 + rl; r < r1; r += 8) {
-      const size_t off = (size_t)r * N + col;
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(dg + off), b = *reinterpret_cast<const bf16x8*>(h + off);
+    auto one = [&](int r, const bf16x8& a, const bf16x8& b) {
       const bf16x8 o = gelu_grad_mul8(a, b);
 #pragma unroll
       for (int e = 0; e < 8; ++e) s[e] += bf2f(o[e]);
-      *reinterpret_cast<bf16x8*>(dh + off) = o;
+      *reinterpret_cast<bf16x8*>(dh + (size_t)r * N + col) = o;
+    };
+    int r = r0 + rl;
+    for (; r + 8 < r1; r += 16) {                        // two row groups (4 loads) in flight per thread
+      const size_t o0 = (size_t)r * N + col, o1 = (size_t)(r + 8) * N + col;
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(dg + o0), b0 = *reinterpret_cast<const bf16x8*>(h + o0);
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(dg + o1), b1 = *reinterpret_cast<const bf16x8*>(h + o1);
+      one(r, a0, b0); one(r + 8, a1, b1);
+    }
+    for (; r < r1; r += 8) {
+      const size_t off = (size_t)r * N + col;
+      one(r, *reinterpret_cast<const bf16x8*>(dg + off), *reinterpret_cast<const bf16x8*>(h + off));
     }
   }
 #pragma unroll
@@ -131,15 +140,22 @@ __global__ __launch_bounds__(256) void rowscale_colsum_kernel(const bf16* __rest
   const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (col < N) {
-    for (int r = r0 + rl; r < r1; r += 8) {
-      const size_t off = (size_t)r * N + col;
+    auto one = [&](int r, const bf16x8& a) {
       const float sc = scale[r / rows_per_sample];
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(x + off);
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) { o[e] = f2bf(sc * bf2f(a[e])); s[e] += bf2f(o[e]); }
-      *reinterpret_cast<bf16x8*>(y + off) = o;
+      *reinterpret_cast<bf16x8*>(y + (size_t)r * N + col) = o;
+    };
+    int r = r0 + rl;
+    for (; r + 24 < r1; r += 32) {                       // 4 independent 16-byte loads in flight per thread
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(x + (size_t)r * N + col);
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(x + (size_t)(r + 8) * N + col);
+      const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(x + (size_t)(r + 16) * N + col);
+      const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(x + (size_t)(r + 24) * N + col);
+      one(r, a0); one(r + 8, a1); one(r + 16, a2); one(r + 24, a3);
     }
+    for (; r < r1; r += 8) one(r, *reinterpret_cast<const bf16x8*>(x + (size_t)r * N + col));
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) red[rl][cv * 8 + e] = s[e];
