@@ -242,6 +242,9 @@ def lib_linear(x, w, b=None):
     return _LibLinear.apply(x, w, b)
 
 
+_WGRAD_TARGET = int(os.environ.get("FIBER_WGRAD_TARGET", "768"))   # chunk GEMMs x 128x128 tiles the split aims for (tools/wgrad_bench.py: 256 / 512 / 768..1024 / 2048 -> 57.7 / 49.4 / 48.6 / 50.3 ms per step)
+
+
 def wgrad(dh, x2):
     """dW[N,K] = dh[M,N]^T . x2[M,K] in fp32.  The library TN GEMM does not split the (huge) M reduction, so for
     small N*K it runs on a handful of CUs (49 TFLOP/s at M=295k, N=384, K=128); expressing the reduction as a batch of
@@ -250,7 +253,7 @@ def wgrad(dh, x2):
     K = x2.shape[1]
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     S = 1
-    while S < 64 and tiles * S < 512 and M % (2 * S) == 0 and M // (2 * S) >= 1024:
+    while S < 64 and tiles * S < _WGRAD_TARGET and M % (2 * S) == 0 and M // (2 * S) >= 1024:
         S *= 2
     if S == 1:
         return lib_matmul(dh.t(), x2).float()
