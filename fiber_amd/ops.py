@@ -54,7 +54,7 @@ def bf16_weight_t(w):
     hit = _wcache.get(key)
     if hit is not None and hit[0] == _stamp(w) and hit[2] is w:
         return hit[1]
-    wt = w.detach().t().to(BF16).contiguous()
+    wt = bf16_weight(w).t().contiguous()                 # one transposing copy of the (optimizer-refreshed) bf16 working copy
     _wcache[key] = (_stamp(w), wt, w)
     return wt
 
@@ -300,6 +300,19 @@ def _take_colsum(t2d):
     return None
 
 
+_DGRAD_NT_ROWS = int(os.environ.get("FIBER_DGRAD_NT_ROWS", "65536"))   # rows from which the library dgrad runs in NT form
+
+
+def _dgrad(dh, weight):
+    """dX = dY . W on the library.  For the image-token GEMMs the NT form (F.linear with the transposed bf16 copy of W) is
+    4-19 % faster than the NN form on every shape of the step (tools/dgrad_bench.py: 53.3 -> 48.5 ms over the Swin blocks);
+    the transposed copy costs one small kernel per weight and step, which the short text-side GEMMs would not earn back."""
+    if dh.shape[0] >= _DGRAD_NT_ROWS:
+        with lib_gemm():
+            return torch.nn.functional.linear(dh, bf16_weight_t(weight))
+    return lib_matmul(dh, bf16_weight(weight))
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, act, rowscale):
@@ -333,8 +346,7 @@ class _Linear(torch.autograd.Function):
             dh, db = gelu_bwd_colsum(dy2, pre)
         else:
             dh = dy2
-        wb = bf16_weight(weight)
-        dx = lib_matmul(dh, wb).view(ctx.shp) if ctx.needs_input_grad[0] else None
+        dx = _dgrad(dh, weight).view(ctx.shp) if ctx.needs_input_grad[0] else None
         dw = wgrad(dh, x2) if ctx.needs_input_grad[1] else None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             if db is None:
@@ -585,8 +597,9 @@ class _LinearQKVHeadMajor(torch.autograd.Function):
         key = ("HM", id(weight))
         hit = _wcache.get(key)
         if hit is None or hit[0] != (_stamp(weight), _stamp(bias)) or hit[2] is not weight:
-            _wcache[key] = ((_stamp(weight), _stamp(bias)), (weight.detach()[perm].to(BF16).contiguous(), bias.detach()[perm].contiguous()), weight)
-        wp, bp = _wcache[key][1]
+            wp = weight.detach()[perm].to(BF16).contiguous()
+            _wcache[key] = ((_stamp(weight), _stamp(bias)), (wp, bias.detach()[perm].contiguous(), wp.t().contiguous()), weight)
+        wp, bp, _ = _wcache[key][1]
         y, _ = gemm_nt(x2, wp, bp)
         ctx.save_for_backward(x2, weight)
         ctx.shp, ctx.heads = shp, heads
@@ -598,8 +611,12 @@ class _LinearQKVHeadMajor(torch.autograd.Function):
         dy2 = _c(dy).view(-1, weight.shape[0])
         hint = _take_colsum(dy2)
         perm, inv = _qkv_perm(weight.shape[1], ctx.heads, dy.device)
-        wp = _wcache[("HM", id(weight))][1][0]
-        dx = lib_matmul(dy2, wp).view(ctx.shp)
+        wp, _, wpt = _wcache[("HM", id(weight))][1]
+        if dy2.shape[0] >= _DGRAD_NT_ROWS:                 # NT form of the library dgrad (see _dgrad)
+            with lib_gemm():
+                dx = torch.nn.functional.linear(dy2, wpt).view(ctx.shp)
+        else:
+            dx = lib_matmul(dy2, wp).view(ctx.shp)
         dw = wgrad(dy2, x2)[inv]
         db = (hint if hint is not None else colsum(dy2))[inv]
         return dx, dw, db, None
