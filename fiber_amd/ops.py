@@ -16,9 +16,10 @@ import os
 
 BF16 = torch.bfloat16
 _wcache = {}
-# (dY.W2^T)*gelu'(H) + fc1 bias gradient as ONE hand-written GEMM instead of library GEMM + gelu_bwd_colsum.  Measured at
-# M = 295k (tools/op_bench.py 512 mlpbwd): 1361 vs 1439 us at C=512, 911 vs 921 at C=1024, 2481 vs 2406 at C=256, 5529 vs 4178
-# at C=128 -> on from C = 512 up ("auto"); FIBER_FUSED_MLP_BWD=0 / 1 forces it off / on everywhere.
+# (dY.W2^T)*gelu'(H) + fc1 bias gradient as ONE hand-written GEMM instead of library GEMM + gelu_bwd_colsum.  Measured at 512
+# images (tools/op_bench.py 512 mlpbwd, persistent 256x256 kernel + select-free gelu', library dgrad in NT form): 3866 vs 4294 us
+# at C=128, 2084 vs 2369 at C=256, 1284 vs 1394 at C=512, 899 vs 859 at C=1024 -> on below C = 1024 ("auto"; an earlier build of
+# the GEMM lost at C <= 256); FIBER_FUSED_MLP_BWD=0 / 1 forces it off / on everywhere.
 _FUSED_MLP_BWD = os.environ.get("FIBER_FUSED_MLP_BWD", "auto")
 
 
@@ -404,14 +405,14 @@ class _MLP(torch.autograd.Function):
                          dy2.numel() // rowscale.numel())
                 dy2 = ds
         C, C4 = dy2.shape[1], h.shape[1]
-        if C % 64 == 0 and C4 % 8 == 0 and (_FUSED_MLP_BWD == "1" or (_FUSED_MLP_BWD == "auto" and C >= 512)):
+        if C % 64 == 0 and C4 % 8 == 0 and (_FUSED_MLP_BWD == "1" or (_FUSED_MLP_BWD == "auto" and C < 1024)):
             dh, db1 = gemm_nt(dy2, bf16_weight_t(w2), None, None, 2, False, aux=h, want_colsum=True)
-        else:                                         # shapes the DMA kernel does not cover (e.g. Swin-T C=96)
-            dh, db1 = gelu_bwd_colsum(lib_matmul(dy2, bf16_weight(w2)), h)
+        else:                                         # C = 1024, or shapes the DMA kernel does not cover (e.g. Swin-T C=96)
+            dh, db1 = gelu_bwd_colsum(_dgrad(dy2, w2), h)
         dw2 = wgrad(dy2, g)
         if db2 is None:
             db2 = colsum(dy2)
-        dx = lib_matmul(dh, bf16_weight(w1)).view(ctx.shp)
+        dx = _dgrad(dh, w1).view(ctx.shp)
         dw1 = wgrad(dh, x2)
         return dx, dw1, db1, dw2, db2, dres, None
 

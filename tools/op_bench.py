@@ -60,10 +60,10 @@ def main():
             wt, wb = ops.bf16_weight_t(w2), ops.bf16_weight(w2)
             t_f = timeit(lambda: ops.gemm_nt(dy, wt, None, None, 2, False, aux=h, want_colsum=True))
             t_p = timeit(lambda: ops.gemm_nt(dy, wt, None, None, 0, False))
-            def unf():
-                return ops.gelu_bwd_colsum(torch.matmul(dy, wb), h)
+            def unf():                                # the product path: library dgrad in NT form (ops._dgrad) + gelu' + column sums
+                return ops.gelu_bwd_colsum(torch.nn.functional.linear(dy, wt), h)
             t_u = timeit(unf)
-            t_l = timeit(lambda: torch.matmul(dy, wb))
+            t_l = timeit(lambda: torch.nn.functional.linear(dy, wt))
             print(f"{name} M={M} C={C}: fused {t_f:8.1f}us | hip plain {t_p:8.1f} | unfused total {t_u:8.1f} (lib gemm {t_l:8.1f})")
     if which in ("all", "attn"):
         print(f"== window attention (B={B})  fwd | bwd  [us, TFLOP/s on 4*L*N*C algorithmic flops fwd, x2.5 bwd]")
