@@ -247,6 +247,20 @@ def test_window_attention_head_major_layout(ops, B, H, W, heads, ws, shift):
         assert_close(name, a, r, 6e-3)
 
 
+def test_wgrad_split_and_nt_dgrad(ops):
+    """Library side of a linear backward: dW = dY^T X split over M chunks + fp32 fold, and dX = dY W in NT form (transposed bf16
+    weight copy) from 65536 rows on, against fp32 products of the same bf16 operands."""
+    for M, N, K in ((131072, 384, 128), (65536, 512, 2048), (4096, 768, 768)):
+        dy = bf(rnd(M, N, seed=1))
+        x = bf(rnd(M, K, seed=2))
+        w = rnd(N, K, seed=3, std=K ** -0.5).to(DEV)
+        dw = ops.wgrad(dy, x)
+        assert dw.dtype == torch.float32
+        assert_close("dW", dw, dy.float().t() @ x.float(), 2e-3)
+        dx = ops._dgrad(dy, w)
+        assert_close("dX", dx, dy.float() @ w.to(torch.bfloat16).float(), 6e-3)
+
+
 def _mha_ref(q, k, v, kmask, B, heads, scale):
     D = q.shape[1] // heads
     qh = q.view(B, -1, heads, D).transpose(1, 2)
