@@ -106,4 +106,21 @@ __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t 
   return hash_u32(seed, idx) >= thresh;
 }
 
+// One LDS-DMA instruction (64 lanes x 16 B -> 1 KB at `lds_wave_base`, lane-linear) issued from inline asm.  The builtin
+// form tells the compiler that LDS is being written behind the vmcnt counter, and its waitcnt pass then guards LDS reads
+// with vmcnt(0) wherever it loses count (after branches, around other VMEM traffic): in the persistent kernel that put a
+// full drain -- including the previous round's output stores -- in front of every staging ds_read.  All ordering of these
+// transfers is done by hand (counted s_waitcnt + s_barrier), so the compiler does not need to know.  M0 is written and
+// consumed inside the block; nothing else in these kernels uses it.
+// Address = wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset: no 64-bit VGPR address arithmetic.
+__device__ __forceinline__ void lds_dma16(const void* base, unsigned lane_byte_off, void* lds_wave_base) {
+  const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)(char*)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m), "v"(lane_byte_off), "s"(base) : "memory");
+}
+// The same with a 64-bit per-lane source address (used where lanes of one instruction read from unrelated buffers).
+__device__ __forceinline__ void lds_dma16_v(const void* lane_src, void* lds_wave_base) {
+  const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)(char*)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m), "v"(lane_src) : "memory");
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

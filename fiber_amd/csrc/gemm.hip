@@ -666,18 +666,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_wide_kernel(GemmArgs a) 
 }
 
 
-// One LDS-DMA instruction (64 lanes x 16 B -> 1 KB at `lds_wave_base`, lane-linear) issued from inline asm.  The builtin
-// form tells the compiler that LDS is being written behind the vmcnt counter, and its waitcnt pass then guards LDS reads
-// with vmcnt(0) wherever it loses count (after branches, around other VMEM traffic): in the persistent kernel that put a
-// full drain -- including the previous round's output stores -- in front of every staging ds_read.  All ordering of these
-// transfers is done by hand (counted s_waitcnt + s_barrier), so the compiler does not need to know.  M0 is written and
-// consumed inside the block; nothing else in these kernels uses it.
-// Address = wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset: no 64-bit VGPR address arithmetic.
-__device__ __forceinline__ void lds_dma16(const void* base, unsigned lane_byte_off, void* lds_wave_base) {
-  const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)(char*)lds_wave_base);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m), "v"(lane_byte_off), "s"(base) : "memory");
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // v3 persistent: the wide kernel walking a run of output tiles per workgroup (one workgroup per CU).  At K = 512 the
 // non-persistent kernel spends ~9 of 23 us per tile outside the K loop, most of it waiting for its 128 KB of output to drain

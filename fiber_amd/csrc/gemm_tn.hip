@@ -1,0 +1,337 @@
+// Weight-gradient GEMM of every nn.Linear on the FIBER fused-backbone path (gfx950 / CDNA4):
+//
+//   dW[N,K] = dY[M,N]^T . X[M,K]        dY, X row-major bf16 (the layouts the forward pass left them in), fp32 result
+//   db[N]   = column sums of dY         (optional: the bias gradient rides in the same pass)
+//
+// This is the implicit autograd of swin_transformer.py:197,221,233,238,257 (qkv / proj / i2t linears), timm Mlp fc1 / fc2
+// (:325), PatchMerging.reduction (:431), PatchEmbed.proj, roberta.py:231-241,337,398,415 and fiber_module.py:349-350, which
+// the reference leaves to ATen (addmm backward = a TN GEMM + a column-sum kernel per linear).
+//
+// "TN": the contraction runs over M, the SLOW dimension of both operands, and M is huge (B*L = 10^4..10^6 rows) while the
+// result is small (<= 4096 x 1024).  So
+//  * the M reduction is split INSIDE the launch: workgroup = (output tile, M range); every split writes its fp32 tile into
+//    its own slab and one small fold kernel sums the slabs (no atomics, deterministic, no [S,N,K] batched-GEMM temporary
+//    in front of a library reduction);
+//  * K tiles are 64 rows of dY and X, brought HBM -> LDS by global_load_lds_dwordx4 exactly as they lie in memory
+//    (row-major, 512-byte rows: fully coalesced), and BOTH MFMA operands are read transposed out of those row-major images
+//    with ds_read_b64_tr_b16 (two reads = the 8 consecutive-m values a lane needs for its column) -- no transposed copy of
+//    dY or X is ever made, in HBM or in LDS;
+//  * bank conflicts: a 16-lane group of a transposed read touches 4 rows x 32 B; with 512-byte (or 256-byte) rows the four
+//    rows would sit on the same banks, so 32-byte chunk c of row r is stored at chunk c ^ ((r & 3) << 1) -- applied on the
+//    per-lane SOURCE address of the DMA (which writes lane-linear) and on the read address.  The eight 32-byte pieces of a
+//    half-wave then tile the 256-byte bank row exactly;
+//  * 256x256 output tile, 8 waves as 2 x 4 (128 x 64 per wave = 4 x 2 MFMA 32x32x16 tiles), two 64-KB stages, and the same
+//    two-wave-group schedule as the forward GEMM (gemm.hip): the groups run the K loop half a sub-tile apart so that on every
+//    SIMD one wave feeds the matrix pipe while its partner reads fragments.  A 128x128 / 4-wave instance covers the narrow
+//    weights (stage-0 / stage-1 linears, patch embedding, test configurations);
+//  * the bias gradient: waves of the first K-column tile add their dY fragments up with v_dot2_f32_bf16 against (1, 1) --
+//    two VALU issues per MFMA gap -- so no separate pass ever streams dY for its column sums.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+struct TnArgs {
+  const bf16* A;      // dY [M, lda]  (columns = output rows n)
+  const bf16* B;      // X  [M, ldb]  (columns = output columns k)
+  float* out;         // slabs [S][N*K] (S > 1) or dW itself (S == 1)
+  float* cs;          // slabs [S][N] or db itself; nullable
+  int M, N, K, lda, ldb;
+  int S, tiles_n, tiles_k, kt_per_split, nk_total;
+};
+
+__device__ __attribute__((aligned(16))) unsigned g_tn_zeros[128];   // 512 zero bytes: the source of dY rows past M
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* p, int hi_off) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + hi_off));
+  s16x8 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi[e]; }
+  return __builtin_bit_cast(bf16x8, o);
+}
+
+// TS: output tile edge (256: 8 waves, 128: 4 waves).  BKM: rows of dY / X per K tile.  NS: LDS stages.
+// STAG (TS = 256, BKM = 64, NS = 2): two wave groups half a sub-tile apart, one workgroup per CU.
+// ring (TS = 128, BKM = 32, NS = 4): the narrow weights are pure streaming problems (2 x 256 B per row of M against 128 x 128
+// MACs), so what matters is bytes in flight: three K tiles per workgroup stay requested across the (raw) barrier behind a
+// COUNTED vmcnt, 64 KB of LDS per workgroup so that two workgroups share a CU and cover each other's fragment reads.
+template <int TS, int BKM, int NS, bool STAG>
+__global__ __launch_bounds__(TS * 2) void gemm_tn_kernel(TnArgs a) {
+  constexpr int NTH = TS * 2;
+  constexpr int NW = NTH / 64;                  // 8 | 4 waves
+  constexpr int WA = 2, WB = NW / 2;            // wave grid: 2 along n, 4 | 2 along k
+  constexpr int WTA = TS / WA, WTB = TS / WB;   // per-wave tile 128 x 64 | 64 x 64
+  constexpr int TA = WTA / 32, TB = WTB / 32;
+  constexpr int RB = TS * 2;                    // bytes per LDS row (one operand)
+  constexpr int CPRW = RB / 16;                 // 16-byte chunks per row
+  constexpr int RPI = 64 / CPRW;                // rows per DMA instruction (1 KB)
+  constexpr int NDI = BKM / RPI / NW;           // DMA instructions per wave, operand and K tile
+  constexpr int OPB = BKM * RB;                 // bytes per operand per stage
+  constexpr int STAGEB = 2 * OPB;
+  constexpr int NSUB = BKM / 32;                // 32-row sub-tiles (two MFMA k-steps each) per K tile
+  static_assert(NDI * RPI * NW == BKM && (!STAG || (NW == 8 && BKM == 64 && NS == 2)) && (BKM == 32 || BKM == 64), "geometry");
+  __shared__ __attribute__((aligned(16))) char smem[NS * STAGEB];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: scalar branches, SGPR LDS bases
+  const int wa = wave / WB, wb = wave % WB;
+  const int tiles = a.tiles_n * a.tiles_k, nblk = tiles * a.S;
+  int bid = blockIdx.x;
+  {  // XCD-aware bijective remap: the tiles of one M range (they share dY / X row panels) run on one XCD's L2
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int s = bid / tiles, tile = bid - s * tiles;
+  const int tn = tile / a.tiles_k, tk = tile - tn * a.tiles_k;
+  const int n0 = tn * TS, k0 = tk * TS;
+  const int kt0 = s * a.kt_per_split;
+  const int nk = min(a.kt_per_split, a.nk_total - kt0);
+  const int m0 = kt0 * BKM;
+
+  // ---- DMA addressing: instruction p of this wave covers tile rows (p*NW + wave)*RPI .. +RPI-1, lane -> (row, 16-B chunk).
+  // Source = wave-uniform row-panel base (SGPR pair, advanced per K tile) + per-lane 32-bit byte offset; issued from inline
+  // asm (common.h lds_dma16) so that the compiler's waitcnt pass does not guard every ds_read with vmcnt(0).
+  const int drow = lane / CPRW, dchunk = lane % CPRW;
+  unsigned aoff[NDI], boff[NDI];
+#pragma unroll
+  for (int p = 0; p < NDI; ++p) {
+    const int r = (p * NW + wave) * RPI + drow;
+    const int gc = dchunk ^ ((r & 3) << 2);                       // source chunk of this LDS slot (32-B chunk ^ (r&3)<<1)
+    aoff[p] = (unsigned)(r * a.lda + min(n0 + gc * 8, a.N - 8)) * 2u;
+    boff[p] = (unsigned)(r * a.ldb + min(k0 + gc * 8, a.K - 8)) * 2u;
+  }
+  auto dma = [&](int kt) {
+    char* st = smem + (kt % NS) * STAGEB;
+    const int mt = m0 + kt * BKM;                                 // first row of this K tile (scalar)
+    const bf16* abase = a.A + (size_t)mt * a.lda;
+    const bf16* bbase = a.B + (size_t)mt * a.ldb;
+    if (mt + BKM <= a.M) {
+#pragma unroll
+      for (int p = 0; p < NDI; ++p) {
+        lds_dma16(abase, aoff[p], st + (p * NW + wave) * RPI * RB);
+        lds_dma16(bbase, boff[p], st + OPB + (p * NW + wave) * RPI * RB);
+      }
+    } else {                                                      // the very last K tile of the problem: rows past M
+#pragma unroll
+      for (int p = 0; p < NDI; ++p) {
+        const int r = (p * NW + wave) * RPI + drow;
+        const bool in = mt + r < a.M;
+        const char* ap = in ? reinterpret_cast<const char*>(abase) + aoff[p]
+                            : reinterpret_cast<const char*>(g_tn_zeros) + dchunk * 16;          // dY row of zeros ...
+        const char* bp = reinterpret_cast<const char*>(bbase) + (in ? boff[p] : boff[p] - (unsigned)(r * a.ldb) * 2u);  // ... times row mt (finite)
+        lds_dma16_v(ap, st + (p * NW + wave) * RPI * RB);
+        lds_dma16_v(bp, st + OPB + (p * NW + wave) * RPI * RB);
+      }
+    }
+  };
+
+  // ---- fragment addressing (transposed reads of the row-major images)
+  const int fi = lane & 15, cg = (lane >> 4) & 1, kh = lane >> 5;
+  const int rowl = kh * 8 + (fi >> 2), sx = (fi >> 2) << 1;
+  int offa[TA], offb[TB];
+#pragma unroll
+  for (int t = 0; t < TA; ++t) offa[t] = rowl * RB + (((wa * (WTA / 16) + 2 * t + cg) ^ sx) << 5) + (fi & 3) * 8;
+#pragma unroll
+  for (int u = 0; u < TB; ++u) offb[u] = OPB + rowl * RB + (((wb * (WTB / 16) + 2 * u + cg) ^ sx) << 5) + (fi & 3) * 8;
+
+  f32x16 acc[TA][TB];
+#pragma unroll
+  for (int t = 0; t < TA; ++t)
+#pragma unroll
+    for (int u = 0; u < TB; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+  float csa[TA];
+#pragma unroll
+  for (int t = 0; t < TA; ++t) csa[t] = 0.f;
+  const bool do_cs = a.cs != nullptr && tk == 0 && wb == 0;       // wave-uniform
+
+  bf16x8 fa[2][TA], fb[2][TB];
+  auto load_phase = [&](int kt, int sub) {
+    const char* st = smem + (kt % NS) * STAGEB + sub * 32 * RB;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int t = 0; t < TA; ++t) fa[ks][t] = tr_frag(st + offa[t] + ks * 16 * RB, 4 * RB);
+#pragma unroll
+      for (int u = 0; u < TB; ++u) fb[ks][u] = tr_frag(st + offb[u] + ks * 16 * RB, 4 * RB);
+    }
+  };
+  const bf16x2_t ones = {(__bf16)1.0f, (__bf16)1.0f};
+  auto math_phase = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int t = 0; t < TA; ++t) {
+#pragma unroll
+        for (int u = 0; u < TB; ++u)
+          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][t], fb[ks][u], acc[t][u], 0, 0, 0);
+        if (do_cs) {
+#pragma unroll
+          for (int e = 0; e < 8; e += 2)
+            csa[t] = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{fa[ks][t][e], fa[ks][t][e + 1]}, ones, csa[t], false);
+        }
+      }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  if constexpr (STAG) {
+    auto phase_barrier = [&](bool landed) {
+      if (landed) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    dma(0);
+    phase_barrier(true);
+    if (wa == 1) phase_barrier(false);                   // group 1 runs one phase behind (see gemm.hip, wide kernel)
+    for (int kt = 0; kt < nk; ++kt) {
+      load_phase(kt, 0);
+      if (kt + 1 < nk) dma(kt + 1);
+      phase_barrier(false);
+      math_phase();
+      phase_barrier(false);
+      load_phase(kt, 1);
+      phase_barrier(wa == 1);
+      math_phase();
+      phase_barrier(wa == 0);
+    }
+    if (wa == 0) phase_barrier(false);
+  } else {
+    static_assert(STAG || (NS == 4 && NDI == 2), "counted vmcnt below: 3 tiles x 4 DMA instructions per wave in flight");
+    for (int pre = 0; pre < NS - 1 && pre < nk; ++pre) dma(pre);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int newer = min(nk - 1 - kt, NS - 2);          // K tiles requested after tile kt (2 NDI instructions per wave each)
+      if (newer >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      else if (newer == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();                       // tile kt resident for every wave; tile kt-1 fully consumed
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + NS - 1 < nk) dma(kt + NS - 1);             // into the stage tile kt-1 just vacated
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub) {
+        load_phase(kt, sub);
+        math_phase();
+      }
+    }
+  }
+
+  // ---- epilogue: fp32 tile -> this split's slab.  Per accumulator register a half-wave writes 128 contiguous bytes.
+  float* outp = a.out + (size_t)s * a.N * a.K;
+  const int kcol_l = lane & 31;
+#pragma unroll
+  for (int t = 0; t < TA; ++t)
+#pragma unroll
+    for (int u = 0; u < TB; ++u) {
+      const int kk = k0 + wb * WTB + u * 32 + kcol_l;
+      const int nb = n0 + wa * WTA + t * 32 + 4 * kh;
+      if (kk < a.K) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = nb + (r & 3) + 8 * (r >> 2);
+          if (n < a.N) outp[(size_t)n * a.K + kk] = acc[t][u][r];
+        }
+      }
+    }
+  if (do_cs) {
+    float* csp = a.cs + (size_t)s * a.N;
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {
+      const float v = csa[t] + __shfl_xor(csa[t], 32);
+      const int n = n0 + wa * WTA + t * 32 + (lane & 31);
+      if (lane < 32 && n < a.N) csp[n] = v;
+    }
+  }
+}
+
+// out[i] = sum_s slab[s][i] over the N*K tile elements (float4) and, optionally, the N column sums
+__global__ __launch_bounds__(256) void tn_fold_kernel(const float* ws, const float* ws_cs, float* out, float* cs, int S, long nk4, int N) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < nk4) {
+    const float4* p = reinterpret_cast<const float4*>(ws) + i;
+    float4 t = p[0];
+    for (int s = 1; s < S; ++s) {
+      const float4 v = p[(long)s * nk4];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = t;
+  } else if (cs != nullptr && i - nk4 < N) {
+    const int n = (int)(i - nk4);
+    float t = 0.f;
+    for (int s = 0; s < S; ++s) t += ws_cs[(long)s * N + n];
+    cs[n] = t;
+  }
+}
+
+struct TnPlan { int ts, bkm, tiles_n, tiles_k, S, kt_per_split, nk_total; };
+
+TnPlan tn_plan(int M, int N, int K) {
+  static const int force_ts = getenv("FIBER_TN_TILE") ? atoi(getenv("FIBER_TN_TILE")) : 0;
+  static const int rounds = getenv("FIBER_TN_ROUNDS") ? atoi(getenv("FIBER_TN_ROUNDS")) : 1;
+  TnPlan p;
+  p.ts = (N >= 192 && K >= 192) ? 256 : 128;
+  if (force_ts == 128 || force_ts == 256) p.ts = force_ts;
+  p.bkm = p.ts == 256 ? 64 : 32;
+  p.tiles_n = cdiv(N, p.ts);
+  p.tiles_k = cdiv(K, p.ts);
+  p.nk_total = cdiv(M, p.bkm);
+  const int tiles = p.tiles_n * p.tiles_k;
+  // Every workgroup of a launch does the same amount of work, so the grid should be just UNDER a whole number of rounds of
+  // resident workgroups (1 per CU for the 256 tile, 2 for the 128 tile): 516 workgroups on 256 CUs would take three rounds.
+  const int resident = 256 * (p.ts == 256 ? 1 : 2) * (rounds > 0 ? rounds : 1);
+  int S = resident / tiles;
+  const int min_kt = p.ts == 256 ? 8 : 16;                 // a split shorter than this is all prologue + epilogue
+  if (S > p.nk_total / min_kt) S = p.nk_total / min_kt;
+  if (S < 1) S = 1;
+  p.kt_per_split = cdiv(p.nk_total, S);
+  p.S = cdiv(p.nk_total, p.kt_per_split);                  // every split owns >= 1 K tile
+  return p;
+}
+
+}  // namespace
+
+// C ABI ---------------------------------------------------------------------------------------------------------
+// Number of M splits the kernel will use for this problem; workspace = S > 1 ? S * (N*K + N) floats : 0.
+extern "C" int fiber_gemm_tn_splits(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  return tn_plan(M, N, K).S;
+}
+
+// dW[N,K] (fp32, contiguous) = dY[M,lddy]^T . X[M,ldx];  dbias (nullable, fp32[N]) = column sums of dY.
+// N % 8 == 0, K % 8 == 0, lddy % 8 == 0, ldx % 8 == 0, 16-byte aligned bases.
+extern "C" int fiber_gemm_tn_bf16(const void* dY, const void* X, float* dW, float* dbias, float* workspace, int M, int N, int K,
+                                  int lddy, int ldx, hipStream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return FIBER_OK;
+  if ((N & 7) || (K & 7) || (lddy & 7) || (ldx & 7)) return FIBER_EINVAL;
+  const TnPlan p = tn_plan(M, N, K);
+  if (p.S > 1 && !workspace) return FIBER_EINVAL;
+  TnArgs a;
+  a.A = (const bf16*)dY; a.B = (const bf16*)X;
+  a.out = p.S > 1 ? workspace : dW;
+  a.cs = dbias ? (p.S > 1 ? workspace + (size_t)p.S * N * K : dbias) : nullptr;
+  a.M = M; a.N = N; a.K = K; a.lda = lddy; a.ldb = ldx;
+  a.S = p.S; a.tiles_n = p.tiles_n; a.tiles_k = p.tiles_k; a.kt_per_split = p.kt_per_split; a.nk_total = p.nk_total;
+  const unsigned grid = (unsigned)(p.tiles_n * p.tiles_k * p.S);
+  if (p.ts == 256) hipLaunchKernelGGL((gemm_tn_kernel<256, 64, 2, true>), dim3(grid), dim3(512), 0, stream, a);
+  else hipLaunchKernelGGL((gemm_tn_kernel<128, 32, 4, false>), dim3(grid), dim3(256), 0, stream, a);
+  FIBER_CHECK_LAUNCH();
+  if (p.S > 1) {
+    const long nk4 = (long)N * K / 4;
+    const long total = nk4 + (dbias ? N : 0);
+    hipLaunchKernelGGL(tn_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, workspace,
+                       workspace + (size_t)p.S * N * K, dW, dbias, p.S, nk4, N);
+    FIBER_CHECK_LAUNCH();
+  }
+  return FIBER_OK;
+}

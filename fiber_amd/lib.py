@@ -16,6 +16,7 @@ P, I, F, L, U64 = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_uint64
 # name -> argtypes (stream appended automatically)
 SIGNATURES = {
     "fiber_gemm_nt_bf16": [P, P, P, P, P, P, P, I, P, I, P, I, I, I, I, I, I, I, I],
+    "fiber_gemm_tn_bf16": [P, P, P, P, P, I, I, I, I, I],
     "fiber_layernorm_fwd_bf16": [P, P, P, P, P, P, I, I, F],
     "fiber_layernorm_bwd_bf16": [P, P, P, P, P, P, P, P, P, P, I, I],
     "fiber_patch_merge_ln_fwd_bf16": [P, P, P, P, P, P, I, I, I, I, F],
@@ -41,7 +42,7 @@ SIGNATURES = {
     "fiber_adamw_multi_f32": [P, P, P, I, F, F, F, F, F, I],
 }
 # host-side helpers without a stream argument
-PLAIN = {"fiber_layernorm_bwd_grid": [I], "fiber_window_attn_bwd_slices": [I, I], "fiber_window_attn_colsum_rows": [I, I, I], "fiber_colsum_slabs": [I, I], "fiber_gemm_row_tile": [I, I, I],
+PLAIN = {"fiber_layernorm_bwd_grid": [I], "fiber_window_attn_bwd_slices": [I, I], "fiber_window_attn_colsum_rows": [I, I, I], "fiber_colsum_slabs": [I, I], "fiber_gemm_row_tile": [I, I, I], "fiber_gemm_tn_splits": [I, I, I],
          "fiber_adamw_chunk": []}
 
 _lib = None

@@ -340,12 +340,35 @@ class FIBERTransformerSS(LightningModule):
 
     def training_step(self, batch, batch_idx):
         fiber_utils.set_task(self)
+        ops.set_rng_step(int(self.global_step))           # dropout / DropPath keys advance with the optimizer step (resume-safe)
         output = self(batch)
         return sum([v for k, v in output.items() if "loss" in k])
+
+    def training_epoch_end(self, outs):
+        fiber_utils.epoch_wrapup(self)
 
     def validation_step(self, batch, batch_idx):
         fiber_utils.set_task(self)
         return self(batch)
+
+    def validation_epoch_end(self, outs):
+        fiber_utils.epoch_wrapup(self)
+
+    def test_step(self, batch, batch_idx):
+        """fiber_module.py:490-507: forward, then the per-task test record (VQA answers; captioning is out of scope)."""
+        fiber_utils.set_task(self)
+        output = self(batch)
+        ret = dict()
+        if self.hparams.config["loss_names"].get("vqa", 0) > 0:
+            ret.update(objectives.vqa_test_step(self, batch, output))
+        return ret
+
+    def test_epoch_end(self, outs):
+        """fiber_module.py:509-520: write the VQA submission file (rank shards merged by rank 0), then the epoch wrap-up."""
+        model_name = self.hparams.config["load_path"].split("/")[-1][:-5]
+        if self.hparams.config["loss_names"].get("vqa", 0) > 0:
+            objectives.vqa_test_wrapup(outs, model_name)
+        fiber_utils.epoch_wrapup(self)
 
     def configure_optimizers(self):
         return fiber_utils.set_schedule(self)

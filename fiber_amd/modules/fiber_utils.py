@@ -1,5 +1,5 @@
-"""set_metrics / set_task / set_schedule for the metric path (reference coarse_grained/fiber/modules/fiber_utils.py:14-41,
-151-287; coarse_grained/fiber/gadgets/my_metrics.py).  AdamW and the polynomial-decay-with-warmup schedule restate
+"""set_metrics / epoch_wrapup / set_task / set_schedule for the metric path (reference
+coarse_grained/fiber/modules/fiber_utils.py:14-41, 44-140, 151-287; coarse_grained/fiber/gadgets/my_metrics.py).  AdamW and the polynomial-decay-with-warmup schedule restate
 transformers==4.6.0 (`AdamW(correct_bias=True)`: decoupled weight decay, eps 1e-8, betas (0.9, 0.98);
 `get_polynomial_decay_schedule_with_warmup`)."""
 import math
@@ -8,39 +8,65 @@ import os
 import torch
 
 
+def _world_sum(t):
+    """dist_reduce_fx="sum" of the reference's Metric states (my_metrics.py:8-9,34-35,52-53): metric state is summed over
+    the data-parallel ranks when an epoch value is computed."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        t = t.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
 class _Running:
-    """Stand-in for pytorch_lightning.metrics.Metric (my_metrics.py): running value, callable, compute()/reset()."""
+    """Stand-in for pytorch_lightning.metrics.Metric as the reference uses it (my_metrics.py): calling the metric updates
+    the epoch state AND returns the value of this batch (Lightning 1.3 `Metric.forward`); compute() = state over the epoch
+    (summed over ranks), reset() clears it.  State lives on the device of the inputs as two fp32 scalars that are only
+    added to -- nothing here synchronises the host on the hot path."""
 
     def __init__(self):
         self.reset()
 
     def reset(self):
-        self.num, self.den = 0.0, 0.0
+        self.num, self.den, self.last = None, None, None
+
+    def _update(self, num, den):
+        num, den = num.detach().float(), den.detach().float()
+        if self.num is None:
+            self.num, self.den = num.clone(), den.clone()
+        else:
+            self.num += num
+            self.den += den
 
     def compute(self):
-        return torch.tensor(self.num / max(self.den, 1e-12))
+        if self.num is None:
+            return torch.tensor(float("nan"))
+        state = _world_sum(torch.stack([self.num, self.den]))
+        return state[0] / state[1]
 
 
 class Scalar(_Running):
-    def __call__(self, scalar):
-        self.last = scalar.detach() if isinstance(scalar, torch.Tensor) else torch.tensor(float(scalar))
-        return self.last                      # accumulated lazily: no host sync on the hot path
+    """my_metrics.py:31-46: mean of the logged scalars."""
 
-    def compute(self):
-        return self.last
+    def __call__(self, scalar):
+        v = scalar.detach().float() if isinstance(scalar, torch.Tensor) else torch.tensor(float(scalar))
+        self._update(v, torch.ones((), device=v.device))
+        self.last = v
+        return v
 
 
 class Accuracy(_Running):
+    """my_metrics.py:5-28: arg-max accuracy over the targets that are not -100."""
+
     def __call__(self, logits, target):
         with torch.no_grad():
             preds = logits.detach().argmax(dim=-1)
             tgt = target.detach().to(preds.device)
             valid = tgt != -100
             correct = ((preds == tgt) & valid).sum().float()
-            self.last = correct / valid.sum().clamp(min=1).float()
-        return self.last
-
-    def compute(self):
+            total = valid.sum().float()
+            self._update(correct, total)
+            self.last = correct / total.clamp(min=1)
         return self.last
 
 
@@ -50,10 +76,10 @@ class VQAScore(_Running):
     def __call__(self, logits, target):
         with torch.no_grad():
             pick = logits.detach().float().argmax(dim=1, keepdim=True)
-            self.last = target.detach().float().gather(1, pick).mean()
-        return self.last
-
-    def compute(self):
+            score = target.detach().float().gather(1, pick).sum()
+            n = torch.tensor(float(logits.shape[0]), device=score.device)
+            self._update(score, n)
+            self.last = score / n
         return self.last
 
 
@@ -66,8 +92,46 @@ def set_metrics(pl_module):
                 setattr(pl_module, f"{split}_vqa_score", VQAScore())
                 setattr(pl_module, f"{split}_{k}_loss", Scalar())
                 continue
+            if k == "itc":                     # fiber_utils.py:36-40
+                setattr(pl_module, f"{split}_{k}_i2t_accuracy", Accuracy())
+                setattr(pl_module, f"{split}_{k}_t2i_accuracy", Accuracy())
+                setattr(pl_module, f"{split}_{k}_loss", Scalar())
+                setattr(pl_module, f"{split}_{k}_logit_scale", Scalar())
+                continue
             setattr(pl_module, f"{split}_{k}_accuracy", Accuracy())
             setattr(pl_module, f"{split}_{k}_loss", Scalar())
+
+
+# epoch-level metric(s) of a task: (attribute suffix, logged tag); the LAST one is what enters `the_metric`
+_EPOCH_VALUES = {"vqa": (("score", "score"),), "itc": (("i2t_accuracy", "i2t_accuracy"), ("t2i_accuracy", "t2i_accuracy"))}
+
+
+def epoch_wrapup(pl_module):
+    """End-of-epoch bookkeeping (reference fiber_utils.py:44-140): per active task log `<task>/<phase>/<metric>_epoch` and
+    `<task>/<phase>/loss_epoch`, reset the running metrics, and log their sum as `<phase>/the_metric` -- the quantity
+    run.py:29-35's ModelCheckpoint monitors.  Retrieval recall (compute_itc_recall / compute_itm_recall) is outside the
+    fused-backbone path built here."""
+    cfg = pl_module.hparams.config
+    phase = "train" if pl_module.training else "val"
+    if cfg.get("get_recall_metric") and not pl_module.training:
+        raise NotImplementedError("retrieval-recall evaluation (objectives.py:266-499) is outside the hot path built here")
+    the_metric = 0
+    for task, weight in cfg["loss_names"].items():
+        if weight <= 0:
+            continue
+        value = 0
+        for attr, tag in _EPOCH_VALUES.get(task, (("accuracy", "accuracy"),)):
+            metric = getattr(pl_module, f"{phase}_{task}_{attr}", None)
+            if metric is None:
+                continue
+            value = metric.compute()
+            pl_module.log(f"{task}/{phase}/{tag}_epoch", value)
+            metric.reset()
+        running_loss = getattr(pl_module, f"{phase}_{task}_loss")
+        pl_module.log(f"{task}/{phase}/loss_epoch", running_loss.compute())
+        running_loss.reset()
+        the_metric = the_metric + value
+    pl_module.log(f"{phase}/the_metric", the_metric)
 
 
 def set_task(pl_module):

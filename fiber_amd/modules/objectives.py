@@ -212,6 +212,41 @@ def compute_vqa(pl_module, batch):
     return ret
 
 
+def vqa_test_step(pl_module, batch, output):
+    """objectives.py:513-524: arg-max answer strings for a test batch (answer vocabulary from the datamodule)."""
+    dicts = pl_module.trainer.datamodule.dm_dicts
+    id2answer = (dicts["vqa_trainval"] if "vqa_trainval" in dicts else dicts["vqa"]).id2answer
+    picks = output["vqa_logits"].argmax(dim=-1).tolist()
+    return {"qids": batch["qid"], "preds": [id2answer[i] for i in picks]}
+
+
+def vqa_test_wrapup(outs, model_name, out_dir="result"):
+    """objectives.py:531-557: every rank writes its shard, rank 0 merges the shards into result/vqa_submit_<model>.json."""
+    import glob
+    import json
+    import os
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank() if multi else 0
+    records = [{"question_id": q, "answer": a} for out in outs for q, a in zip(out["qids"], out["preds"])]
+    shard = f"vqa_submit_{rank}.json"
+    with open(shard, "w") as fp:
+        json.dump(records, fp, indent=4)
+    if multi:
+        dist.barrier()
+    if rank == 0:
+        merged = []
+        for path in sorted(glob.glob("vqa_submit_*.json")):
+            with open(path) as fp:
+                merged += json.load(fp)
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, f"vqa_submit_{model_name}.json"), "w") as fp:
+            json.dump(merged, fp, indent=4)
+    if multi:
+        dist.barrier()
+    os.remove(shard)
+
+
 def init_weights(module):
     if isinstance(module, (nn.Linear, nn.Embedding)):
         module.weight.data.normal_(mean=0.0, std=0.02)

@@ -2,11 +2,13 @@
 
 Activations are bf16, parameters stay fp32 masters (state-dict compatible with the reference); each op casts the
 weights it needs to bf16 once per parameter version.  Forward GEMMs with fused epilogues, LayerNorm, all attention
-cores, embeddings and the element-wise glue are hand-written HIP kernels.  The plain backward GEMMs (dX = dY.W,
-dW = dY^T.X -- no epilogue to fuse) go through torch.matmul, i.e. hipBLASLt/rocBLAS on the same device and stream.
+cores, embeddings and the element-wise glue are hand-written HIP kernels, and so are both backward GEMMs of every linear:
+dX = dY.W on the NT kernel (transposed bf16 working copy of W), dW = dY^T.X (+ the bias gradient) on the TN kernel
+(csrc/gemm_tn.hip).  Only the caller-side heads (vocabulary decoder, 2-way ITM, VQA classifier) use the library GEMM.
 Nothing here runs on the CPU: tensors must live on a HIP device.
 """
 import math
+import weakref
 
 import torch
 
@@ -15,7 +17,21 @@ from . import lib
 import os
 
 BF16 = torch.bfloat16
+# Derived copies of parameters (bf16 / transposed / permuted working copies), keyed by (kind, id(parameter)).  The parameter
+# itself is held WEAKLY: when a module is deleted its entries go with it (a finalizer purges them), so the cache neither keeps
+# dead models' weights alive nor hands a stale copy to a new tensor that happens to reuse the id.
 _wcache = {}
+
+
+def _cache_get(key, w):
+    hit = _wcache.get(key)
+    if hit is not None and hit[2]() is w:
+        return hit
+    return None
+
+
+def _cache_put(key, stamp, value, w):
+    _wcache[key] = (stamp, value, weakref.ref(w, lambda _r, k=key: _wcache.pop(k, None)))
 # (dY.W2^T)*gelu'(H) + fc1 bias gradient as ONE hand-written GEMM instead of library GEMM + gelu_bwd_colsum.  Measured at 512
 # images (tools/op_bench.py 512 mlpbwd, persistent 256x256 kernel + select-free gelu', library dgrad in NT form): 3866 vs 4294 us
 # at C=128, 2084 vs 2369 at C=256, 1284 vs 1394 at C=512, 899 vs 859 at C=1024 -> on below C = 1024 ("auto"; an earlier build of
@@ -40,11 +56,11 @@ def _stamp(w):
 def bf16_weight(w):
     """bf16 copy of an fp32 parameter, refreshed when the parameter changes (version counter or optimizer step)."""
     key = id(w)
-    hit = _wcache.get(key)
-    if hit is not None and hit[0] == _stamp(w) and hit[2] is w:
+    hit = _cache_get(key, w)
+    if hit is not None and hit[0] == _stamp(w):
         return hit[1]
     wb = w.detach().to(BF16).contiguous()
-    _wcache[key] = (_stamp(w), wb, w)
+    _cache_put(key, _stamp(w), wb, w)
     return wb
 
 
@@ -52,18 +68,18 @@ def bf16_weight_t(w):
     """bf16 TRANSPOSED copy of an fp32 [N, K] parameter -> [K, N] (the B operand of the dgrad GEMM dX = dY . W in the
     kernel's NT form), refreshed when the parameter's version counter changes."""
     key = ("T", id(w))
-    hit = _wcache.get(key)
-    if hit is not None and hit[0] == _stamp(w) and hit[2] is w:
+    hit = _cache_get(key, w)
+    if hit is not None and hit[0] == _stamp(w):
         return hit[1]
     wt = bf16_weight(w).t().contiguous()                 # one transposing copy of the (optimizer-refreshed) bf16 working copy
-    _wcache[key] = (_stamp(w), wt, w)
+    _cache_put(key, _stamp(w), wt, w)
     return wt
 
 
 def bf16_copy_if_cached(w):
     """The cached bf16 working copy of `w` (whatever its state), or None -- for the fused optimizer, which rewrites it."""
-    hit = _wcache.get(id(w))
-    return hit[1] if (hit is not None and hit[2] is w) else None
+    hit = _cache_get(id(w), w)
+    return hit[1] if hit is not None else None
 
 
 def restamp_bf16_copies(params, bump=True):
@@ -72,9 +88,9 @@ def restamp_bf16_copies(params, bump=True):
     if bump:
         _gen[0] += 1
     for w in params:
-        hit = _wcache.get(id(w))
-        if hit is not None and hit[2] is w:
-            _wcache[id(w)] = (_stamp(w), hit[1], w)
+        hit = _cache_get(id(w), w)
+        if hit is not None:
+            _wcache[id(w)] = (_stamp(w), hit[1], hit[2])
 
 
 def cast_bf16(w):
@@ -243,35 +259,19 @@ def lib_linear(x, w, b=None):
     return _LibLinear.apply(x, w, b)
 
 
-_WGRAD_TARGET = int(os.environ.get("FIBER_WGRAD_TARGET", "768"))   # chunk GEMMs x 128x128 tiles the split aims for (tools/wgrad_bench.py: 256 / 512 / 768..1024 / 2048 -> 57.7 / 49.4 / 48.6 / 50.3 ms per step)
-
-
-def wgrad(dh, x2):
-    """dW[N,K] = dh[M,N]^T . x2[M,K] in fp32.  The library TN GEMM does not split the (huge) M reduction, so for
-    small N*K it runs on a handful of CUs (49 TFLOP/s at M=295k, N=384, K=128); expressing the reduction as a batch of
-    S independent chunk GEMMs + one fp32 sum restores parallelism."""
+def wgrad(dh, x2, want_bias=False):
+    """dW[N,K] = dh[M,N]^T . x2[M,K] in fp32 on the hand-written TN kernel (csrc/gemm_tn.hip): both operands are read as
+    they lie (row-major, M slow) and transposed on the LDS -> register path; the M reduction is split inside the launch
+    (fp32 slabs + one fold).  want_bias: also return the column sums of dh (the bias gradient) from the same pass."""
     M, N = dh.shape
     K = x2.shape[1]
-    tiles = ((N + 127) // 128) * ((K + 127) // 128)
-    S = 1
-    while S < 64 and tiles * S < _WGRAD_TARGET and M % (2 * S) == 0 and M // (2 * S) >= 1024:
-        S *= 2
-    if S == 1:
-        return lib_matmul(dh.t(), x2).float()
-    a = dh.view(S, M // S, N).transpose(1, 2)
-    b = x2.view(S, M // S, K)
-    if _bmm_fp32[0] is None:
-        try:
-            torch.bmm(a[:1], b[:1], out_dtype=torch.float32)
-            _bmm_fp32[0] = True
-        except Exception:  # noqa: BLE001
-            _bmm_fp32[0] = False
-    with lib_gemm():
-        if _bmm_fp32[0]:
-            out = torch.bmm(a, b, out_dtype=torch.float32)
-        else:
-            out = torch.bmm(a, b).float()
-    return out.sum(0)
+    assert dh.dtype == BF16 and x2.dtype == BF16 and dh.stride(1) == 1 and x2.stride(1) == 1 and x2.shape[0] == M
+    dw = torch.empty((N, K), dtype=torch.float32, device=dh.device)
+    db = torch.empty(N, dtype=torch.float32, device=dh.device) if want_bias else None
+    S = lib.plain("fiber_gemm_tn_splits", M, N, K)
+    ws = torch.empty(S * (N * K + N), dtype=torch.float32, device=dh.device) if S > 1 else None
+    lib.call("fiber_gemm_tn_bf16", lib.ptr(dh), lib.ptr(x2), lib.ptr(dw), lib.ptr(db), lib.ptr(ws), M, N, K, dh.stride(0), x2.stride(0))
+    return (dw, db) if want_bias else dw
 
 
 # Column sums that a backward kernel produced together with its output (window attention: the qkv bias gradient).  The
@@ -301,17 +301,11 @@ def _take_colsum(t2d):
     return None
 
 
-_DGRAD_NT_ROWS = int(os.environ.get("FIBER_DGRAD_NT_ROWS", "65536"))   # rows from which the library dgrad runs in NT form
-
-
 def _dgrad(dh, weight):
-    """dX = dY . W on the library.  For the image-token GEMMs the NT form (F.linear with the transposed bf16 copy of W) is
-    4-19 % faster than the NN form on every shape of the step (tools/dgrad_bench.py: 53.3 -> 48.5 ms over the Swin blocks);
-    the transposed copy costs one small kernel per weight and step, which the short text-side GEMMs would not earn back."""
-    if dh.shape[0] >= _DGRAD_NT_ROWS:
-        with lib_gemm():
-            return torch.nn.functional.linear(dh, bf16_weight_t(weight))
-    return lib_matmul(dh, bf16_weight(weight))
+    """dX = dY . W on the hand-written NT kernel: the B operand is the transposed bf16 working copy of W ([K, N], one small
+    transposing kernel per weight and optimizer step), so the contraction is contiguous on both sides."""
+    y, _ = gemm_nt(dh, bf16_weight_t(weight))
+    return y
 
 
 class _Linear(torch.autograd.Function):
@@ -348,20 +342,27 @@ class _Linear(torch.autograd.Function):
         else:
             dh = dy2
         dx = _dgrad(dh, weight).view(ctx.shp) if ctx.needs_input_grad[0] else None
-        dw = wgrad(dh, x2) if ctx.needs_input_grad[1] else None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            if db is None:
-                db = hint if (hint is not None and dh is dy2) else colsum(dh)
-        else:
+        need_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if need_db and db is None and hint is not None and dh is dy2:
+            db = hint                                  # produced by the kernel that wrote dy (window attention backward)
+        want = need_db and db is None                  # otherwise the bias gradient rides in the weight-gradient pass
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = wgrad(dh, x2, want_bias=want)
+            if want:
+                dw, db = dw
+        elif want:
+            db = colsum(dh)
+        if not need_db:
             db = None
         return dx, dw, db, dres, None, None
 
 
 def linear(x, weight, bias=None, residual=None, act=None, rowscale=None):
-    """nn.Linear with fused bias / exact GELU / residual.  Falls back to a library GEMM only for shapes the tile
-    kernel does not cover (N % 4 != 0, e.g. the 2-way ITM head, or K % 8 != 0)."""
+    """nn.Linear with fused bias / exact GELU / residual, forward and both backward GEMMs on the hand-written kernels.
+    A library GEMM is used only for shapes the tile kernels do not cover (N % 8 != 0, e.g. the 2-way ITM head, or K % 8 != 0)."""
     N, K = weight.shape
-    if (N % 4) or (K % 8):
+    if (N % 8) or (K % 8):
         y = torch.nn.functional.linear(x, weight.to(BF16), bias.to(BF16) if bias is not None else None)
         if act:
             y = torch.nn.functional.gelu(y)
@@ -406,14 +407,19 @@ class _MLP(torch.autograd.Function):
                 dy2 = ds
         C, C4 = dy2.shape[1], h.shape[1]
         if C % 64 == 0 and C4 % 8 == 0 and (_FUSED_MLP_BWD == "1" or (_FUSED_MLP_BWD == "auto" and C < 1024)):
-            dh, db1 = gemm_nt(dy2, bf16_weight_t(w2), None, None, 2, False, aux=h, want_colsum=True)
+            dh, _ = gemm_nt(dy2, bf16_weight_t(w2), None, None, 2, False, aux=h)
+            db1 = None
         else:                                         # C = 1024, or shapes the DMA kernel does not cover (e.g. Swin-T C=96)
             dh, db1 = gelu_bwd_colsum(_dgrad(dy2, w2), h)
-        dw2 = wgrad(dy2, g)
         if db2 is None:
-            db2 = colsum(dy2)
+            dw2, db2 = wgrad(dy2, g, want_bias=True)
+        else:
+            dw2 = wgrad(dy2, g)
         dx = _dgrad(dh, w1).view(ctx.shp)
-        dw1 = wgrad(dh, x2)
+        if db1 is None:
+            dw1, db1 = wgrad(dh, x2, want_bias=True)   # fc1 bias gradient = column sums of dH, from the same pass
+        else:
+            dw1 = wgrad(dh, x2)
         return dx, dw1, db1, dw2, db2, dres, None
 
 
@@ -596,10 +602,10 @@ class _LinearQKVHeadMajor(torch.autograd.Function):
         C = weight.shape[1]
         perm, inv = _qkv_perm(C, heads, x.device)
         key = ("HM", id(weight))
-        hit = _wcache.get(key)
-        if hit is None or hit[0] != (_stamp(weight), _stamp(bias)) or hit[2] is not weight:
+        hit = _cache_get(key, weight)
+        if hit is None or hit[0] != (_stamp(weight), _stamp(bias)):
             wp = weight.detach()[perm].to(BF16).contiguous()
-            _wcache[key] = ((_stamp(weight), _stamp(bias)), (wp, bias.detach()[perm].contiguous(), wp.t().contiguous()), weight)
+            _cache_put(key, (_stamp(weight), _stamp(bias)), (wp, bias.detach()[perm].contiguous(), wp.t().contiguous()), weight)
         wp, bp, _ = _wcache[key][1]
         y, _ = gemm_nt(x2, wp, bp)
         ctx.save_for_backward(x2, weight)
@@ -613,13 +619,12 @@ class _LinearQKVHeadMajor(torch.autograd.Function):
         hint = _take_colsum(dy2)
         perm, inv = _qkv_perm(weight.shape[1], ctx.heads, dy.device)
         wp, _, wpt = _wcache[("HM", id(weight))][1]
-        if dy2.shape[0] >= _DGRAD_NT_ROWS:                 # NT form of the library dgrad (see _dgrad)
-            with lib_gemm():
-                dx = torch.nn.functional.linear(dy2, wpt).view(ctx.shp)
+        dx = gemm_nt(dy2, wpt)[0].view(ctx.shp)
+        if hint is not None:
+            dw, db = wgrad(dy2, x2)[inv], hint[inv]
         else:
-            dx = lib_matmul(dy2, wp).view(ctx.shp)
-        dw = wgrad(dy2, x2)[inv]
-        db = (hint if hint is not None else colsum(dy2))[inv]
+            dw, db = wgrad(dy2, x2, want_bias=True)
+            dw, db = dw[inv], db[inv]
         return dx, dw, db, None
 
 
@@ -729,17 +734,29 @@ class _Dropout(torch.autograd.Function):
         return dx, None, None
 
 
-_seed_state = {"seed": 0x5EED, "ctr": 0}
+_seed_state = {"seed": 0x5EED, "ctr": 0, "step": None}
 
 
 def manual_seed(seed):
-    _seed_state["seed"], _seed_state["ctr"] = int(seed) & 0xFFFFFFFF, 0
+    """Seed of the dropout / DropPath streams (lightning.seed_everything and the Trainer call this with config["seed"] + rank)."""
+    _seed_state["seed"], _seed_state["ctr"], _seed_state["step"] = int(seed) & 0xFFFFFFFF, 0, None
+
+
+def set_rng_step(step):
+    """Called once per training step with the optimizer-step index: the per-call-site counter restarts inside a window of
+    2^20 keys owned by that step, so a run resumed at step s draws the masks of step s, not those of step 0."""
+    if _seed_state["step"] != step:
+        _seed_state["step"] = step
+        _seed_state["ctr"] = (int(step) & 0xFFF) << 20
 
 
 def next_seed():
     """A fresh 64-bit dropout key per call site (counter-based: forward and backward share it through ctx)."""
     _seed_state["ctr"] += 1
-    return (_seed_state["seed"] << 32) | (_seed_state["ctr"] & 0xFFFFFFFF)
+    hi = _seed_state["seed"]
+    if _seed_state["step"] is not None:
+        hi = (hi ^ ((int(_seed_state["step"]) >> 12) * 0x9E3779B1)) & 0xFFFFFFFF
+    return (hi << 32) | (_seed_state["ctr"] & 0xFFFFFFFF)
 
 
 def dropout(x, p, training):
@@ -836,11 +853,11 @@ class _PatchEmbedProj(torch.autograd.Function):
         cols = torch.empty((rows, 64), dtype=BF16, device=img.device)
         lib.call("fiber_im2col_patch4", lib.ptr(img), lib.ptr(cols), B, H, W)
         key = ("pe", id(weight))
-        hit = _wcache.get(key)
-        if hit is None or hit[0] != _stamp(weight) or hit[2] is not weight:
+        hit = _cache_get(key, weight)
+        if hit is None or hit[0] != _stamp(weight):
             wp = torch.zeros((Cout, 64), dtype=BF16, device=img.device)
             wp[:, :48] = weight.detach().reshape(Cout, 48).to(BF16)
-            _wcache[key] = (_stamp(weight), wp, weight)
+            _cache_put(key, _stamp(weight), wp, weight)
         wp = _wcache[key][1]
         y, _ = gemm_nt(cols, wp, bias)
         ctx.save_for_backward(cols)
@@ -851,8 +868,8 @@ class _PatchEmbedProj(torch.autograd.Function):
     def backward(ctx, dy):
         (cols,) = ctx.saved_tensors
         dy2 = _c(dy).view(-1, dy.shape[-1])
-        dw = wgrad(dy2, cols)[:, :48].reshape(ctx.wshape)
-        return None, dw, colsum(dy2)
+        dw, db = wgrad(dy2, cols, want_bias=True)
+        return None, dw[:, :48].reshape(ctx.wshape), db
 
 
 def patch_embed_proj(img, weight, bias):

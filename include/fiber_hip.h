@@ -30,6 +30,15 @@ int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bias, const vo
                        int K, int ldx, int ldw, int ldy, int ldr, int act, fiber_stream_t stream);
 int fiber_gemm_row_tile(int M, int N, int K);
 
+/* Weight (+bias) gradient of nn.Linear: dW[N,K] (fp32, contiguous) = dY[M,lddy]^T . X[M,ldx]; dbias (nullable, fp32[N]) =
+ * column sums of dY.  replaces the ATen addmm-backward (TN GEMM + sum(0)) behind every Linear the reference back-propagates
+ * through: swin_transformer.py:197,221,233,238,257, timm Mlp (:325), PatchMerging.reduction (:431), PatchEmbed.proj,
+ * roberta.py:231-241,337,398,415, fiber_module.py:349-350.  The M reduction is split inside the launch: workspace must hold
+ * S*(N*K + N) floats when S = fiber_gemm_tn_splits(M,N,K) > 1 (NULL otherwise).  N%8==0, K%8==0, lddy%8==0, ldx%8==0. */
+int fiber_gemm_tn_splits(int M, int N, int K);
+int fiber_gemm_tn_bf16(const void* dY, const void* X, float* dW, float* dbias, float* workspace, int M, int N, int K, int lddy,
+                       int ldx, fiber_stream_t stream);
+
 /* nn.LayerNorm over the last dim (C%8==0, C<=4096); saves mean/rstd.  replaces swin_transformer.py:362,391,244; roberta.py:485,422 */
 int fiber_layernorm_fwd_bf16(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int rows,
                              int C, float eps, fiber_stream_t stream);

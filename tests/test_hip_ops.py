@@ -247,16 +247,52 @@ def test_window_attention_head_major_layout(ops, B, H, W, heads, ws, shift):
         assert_close(name, a, r, 6e-3)
 
 
-def test_wgrad_split_and_nt_dgrad(ops):
-    """Library side of a linear backward: dW = dY^T X split over M chunks + fp32 fold, and dX = dY W in NT form (transposed bf16
-    weight copy) from 65536 rows on, against fp32 products of the same bf16 operands."""
-    for M, N, K in ((131072, 384, 128), (65536, 512, 2048), (4096, 768, 768)):
+@pytest.mark.parametrize("M,N,K", [
+    (131072, 384, 128),      # stage-0 qkv: 128x128 tiles, deep split
+    (65536, 512, 2048),      # fc2: 256x256 tiles, staggered wave groups
+    (36864, 2048, 512),      # fc1
+    (4096, 768, 768),        # text layer
+    (1000, 96, 288),         # Swin-T-like, M not a multiple of 64 (zero-row tail), N/K not multiples of the tile
+    (70, 16, 24),            # tiny: one K tile with a tail, one partly filled 128x128 tile
+    (64, 8, 8), (130, 264, 520),
+    (18432, 128, 64),        # patch embedding (K = 48 padded to 64)
+])
+def test_wgrad_tn_kernel(ops, M, N, K):
+    """dW = dY^T X (+ bias gradient = column sums of dY) on csrc/gemm_tn.hip against fp32 products of the same bf16 operands.
+    Operands are asymmetric random data (a transposed or row/column-swapped result cannot pass); rel-L2 <= 2e-3 (fp32
+    accumulation; only the summation order differs)."""
+    dy = bf(rnd(M, N, seed=1) + 0.25)                 # non-zero mean: column sums are not ~0
+    x = bf(rnd(M, K, seed=2) * torch.linspace(0.5, 2.0, K))
+    dw, db = ops.wgrad(dy, x, want_bias=True)
+    assert dw.dtype == torch.float32 and dw.shape == (N, K) and db.shape == (N,)
+    ref = dy.double().t() @ x.double()
+    assert_close("dW", dw, ref, 2e-3)
+    assert_close("db", db, dy.double().sum(0), 2e-3)
+    assert_close("dW (no bias)", ops.wgrad(dy, x), ref, 2e-3)
+    # row-strided operands (column views of wider tensors, e.g. a packed projection)
+    wide = bf(rnd(M, N + K, seed=4))
+    dw2 = ops.wgrad(wide[:, :N], wide[:, N:])
+    assert_close("dW strided", dw2, wide[:, :N].double().t() @ wide[:, N:].double(), 2e-3)
+
+
+def test_wgrad_tn_identity_layout(ops):
+    """A = I-structured check with an ASYMMETRIC partner: dY = one-hot rows selects rows of X, so dW[n] must equal the sum of
+    the X rows whose hot column is n -- catches any row/column or operand swap exactly (values are small integers)."""
+    M, N, K = 512, 64, 128
+    hot = torch.arange(M) % N
+    dy = torch.zeros(M, N)
+    dy[torch.arange(M), hot] = 1.0
+    x = (torch.arange(M)[:, None] % 7 + torch.arange(K)[None, :] % 5).float()
+    dw = ops.wgrad(bf(dy), bf(x))
+    ref = dy.t() @ x
+    assert torch.equal(dw.cpu(), ref), (dw.cpu() - ref).abs().max()
+
+
+def test_own_dgrad_nt(ops):
+    """dX = dY W on the NT kernel with the transposed bf16 working copy of W."""
+    for M, N, K in ((131072, 384, 128), (65536, 512, 2048), (4096, 768, 768), (80, 3072, 768)):
         dy = bf(rnd(M, N, seed=1))
-        x = bf(rnd(M, K, seed=2))
         w = rnd(N, K, seed=3, std=K ** -0.5).to(DEV)
-        dw = ops.wgrad(dy, x)
-        assert dw.dtype == torch.float32
-        assert_close("dW", dw, dy.float().t() @ x.float(), 2e-3)
         dx = ops._dgrad(dy, w)
         assert_close("dX", dx, dy.float() @ w.to(torch.bfloat16).float(), 6e-3)
 
