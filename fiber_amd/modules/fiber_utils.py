@@ -174,15 +174,15 @@ def set_schedule(pl_module):
             groups[gi]["params"].append(p)
     own = None
     if cfg["optim_type"] == "adamw":
-        # transformers 4.6.0 AdamW(correct_bias=True) == decoupled weight decay + bias correction == torch AdamW.
-        # (torch's fused=True variant measured no faster here once the bf16 working copies are refreshed every step.)
-        # On a HIP device: one kernel per parameter group that also rewrites the bf16 working copies (fiber_amd/optim.py);
-        # host tensors (the CPU wiring tests) take torch's implementation of the same rule.
+        # transformers 4.6.0 AdamW(correct_bias=True): eps on the un-corrected sqrt(v), weight decay after the update -- NOT
+        # torch.optim.AdamW's form of the rule (fiber_amd/optim.py).  On a HIP device: one kernel per parameter group that
+        # also rewrites the bf16 working copies; host tensors (the CPU wiring tests) take the plain-torch statement of the
+        # same rule.
+        from ..optim import FiberAdamW, HFAdamW
         if any(p.is_cuda for g in groups for p in g["params"]) and not os.environ.get("FIBER_TORCH_ADAMW"):
-            from ..optim import FiberAdamW
             optimizer = own = FiberAdamW(groups, lr=lr, eps=1e-8, betas=(0.9, 0.98))
         else:
-            optimizer = torch.optim.AdamW(groups, lr=lr, eps=1e-8, betas=(0.9, 0.98))
+            optimizer = HFAdamW(groups, lr=lr, eps=1e-8, betas=(0.9, 0.98))
     elif cfg["optim_type"] == "adam":
         optimizer = torch.optim.Adam(groups, lr=lr)
     else:

@@ -1,13 +1,47 @@
 """AdamW for the fused path on the HIP kernel of csrc/optim.hip: one launch per parameter group, bf16 working copies of
-the weights refreshed in the same pass.  Same update rule as torch.optim.AdamW / transformers 4.6.0 AdamW(correct_bias=True)
-(reference fiber_utils.py:248-252); parameter groups, `lr` scheduling through LambdaLR and state_dict work as for any
-torch optimizer.
+the weights refreshed in the same pass.  The update rule is transformers 4.6.0 `AdamW(correct_bias=True)` (reference
+fiber_utils.py:248-252) in ITS form -- eps added to the un-corrected sqrt(v), weight decay applied after the Adam update --
+which differs from torch.optim.AdamW for small gradients / early steps.  `HFAdamW` is the same rule in plain torch for host
+tensors (CPU wiring tests).  Parameter groups, `lr` scheduling through LambdaLR, state_dict / load_state_dict work as for
+any torch optimizer.
 
 Host side: the pointer / size / chunk tables of a group live on the device and are rebuilt only when something moved (a
 gradient was re-allocated, a bf16 copy appeared); the per-step work is one pass over the parameters comparing addresses."""
 import torch
 
 from . import lib, ops
+
+
+class HFAdamW(torch.optim.Optimizer):
+    """transformers 4.6.0 AdamW(correct_bias=True), restated (optimization.py of that release): used where the HIP kernel
+    cannot run (host tensors)."""
+
+    def __init__(self, params, lr=1e-5, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"], st["exp_avg"], st["exp_avg_sq"] = 0, torch.zeros_like(p), torch.zeros_like(p)
+                st["step"] += 1
+                g = p.grad
+                st["exp_avg"].mul_(b1).add_(g, alpha=1.0 - b1)
+                st["exp_avg_sq"].mul_(b2).addcmul_(g, g, value=1.0 - b2)
+                step_size = group["lr"] * (1.0 - b2 ** st["step"]) ** 0.5 / (1.0 - b1 ** st["step"])
+                p.addcdiv_(st["exp_avg"], st["exp_avg_sq"].sqrt().add_(group["eps"]), value=-step_size)
+                if group["weight_decay"] > 0.0:
+                    p.add_(p, alpha=-group["lr"] * group["weight_decay"])
+        return loss
 
 
 class FiberAdamW(torch.optim.Optimizer):
@@ -17,8 +51,21 @@ class FiberAdamW(torch.optim.Optimizer):
         self._tables = {}                       # group index -> cached device tables
         self.rebuilds = 0                       # how often a table had to be rebuilt (diagnostics)
 
+    def load_state_dict(self, state_dict):
+        """Loaded moments and step counters live in NEW tensors / dicts: drop every cached device table."""
+        super().load_state_dict(state_dict)
+        self._tables = {}
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._tables = {}
+        self.__dict__.setdefault("_chunk", None)
+        self.__dict__.setdefault("rebuilds", 0)
+
     def _state_of(self, p):
         st = self.state[p]
+        if st and isinstance(st.get("step"), torch.Tensor):     # a state dict saved by torch.optim.AdamW keeps tensor steps
+            st["step"] = int(st["step"].item())
         if not st:
             if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
                 raise lib.FiberHipError("FiberAdamW needs contiguous fp32 parameters on a HIP device")
@@ -48,9 +95,12 @@ class FiberAdamW(torch.optim.Optimizer):
                     raise lib.FiberHipError("FiberAdamW needs contiguous fp32 gradients")
                 grads.append(g.data_ptr())
             copies = [cached(p) for p in plist]
-            key = (tuple(map(id, plist)), tuple(grads), tuple(0 if c is None else c.data_ptr() for c in copies))
+            # what the cached device table was built from: the parameters AND their storage AND the state dicts (a
+            # load_state_dict() swaps self.state's dicts and tensors, model.to() moves storage under an unchanged id)
+            members = (tuple(map(id, plist)), tuple(p.data_ptr() for p in plist), tuple(id(self.state[p]) for p in plist))
+            key = (members, tuple(grads), tuple(0 if c is None else c.data_ptr() for c in copies))
             tab = self._tables.get(gi)
-            if tab is None or tab["key"][0] != key[0]:            # membership changed: rebuild everything for this group
+            if tab is None or tab["key"] is None or tab["key"][0] != key[0]:   # membership / storage / state changed: rebuild
                 self.rebuilds += 1
                 states = [self._state_of(p) for p in plist]
                 sizes = [p.numel() for p in plist]

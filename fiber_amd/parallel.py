@@ -35,10 +35,24 @@ def freeze_unused(model, names):
     return n
 
 
-def wrap_ddp(model, device=None, bucket_cap_mb=64):
-    """DistributedDataParallel with bucket views (gradients are written straight into the all-reduce buckets)."""
+def wrap_ddp(model, device=None, bucket_cap_mb=64, bf16_grads=None):
+    """DistributedDataParallel with bucket views (gradients are written straight into the all-reduce buckets).
+    Bucket ORDER: with find_unused_parameters=False (the never-used parameters are frozen, freeze_unused) torch's reducer
+    rebuilds its buckets after the first iteration in the order the gradients actually became ready, i.e. reverse execution
+    order of the interleaved image / text stacks (heads and Swin stage 3 / text layers 10-11 first, patch embedding last) --
+    the definition order of `model.parameters()` only matters for step 0.
+    bf16_grads (default: on for nccl/RCCL, env FIBER_DDP_BF16=0/1 overrides): all-reduce the buckets in bf16
+    (`bf16_compress_hook`: 0.56 GB instead of 1.13 GB per step over xGMI) -- the sum is formed in bf16
+    on the wire and decompressed into the fp32 gradient views."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return model
     ids = [device.index] if (device is not None and device.type == "cuda") else None
-    return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, broadcast_buffers=False,
-                                                     gradient_as_bucket_view=True, bucket_cap_mb=bucket_cap_mb)
+    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, broadcast_buffers=False,
+                                                    gradient_as_bucket_view=True, bucket_cap_mb=bucket_cap_mb)
+    if bf16_grads is None:
+        env = os.environ.get("FIBER_DDP_BF16")
+        bf16_grads = (dist.get_backend() == "nccl") if env is None else env == "1"
+    if bf16_grads:
+        from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+        ddp.register_comm_hook(state=None, hook=default_hooks.bf16_compress_hook)
+    return ddp

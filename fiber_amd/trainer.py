@@ -1,49 +1,111 @@
-"""Minimal stand-in for the `pl.Trainer` kwargs the reference's run.py uses (coarse_grained/run.py:50-70) when
-pytorch_lightning is not installed: max_steps, accumulate_grad_batches, DDP over one process per GPU, step-interval LR
-scheduler, optional checkpoint of `state_dict` (key-compatible with the reference's `ckpt["state_dict"]`).
-With Lightning present, use `pl.Trainer(accelerator="ddp", ...)` directly -- the module is a LightningModule."""
+"""Minimal stand-in for the `pl.Trainer` kwargs the reference's run.py uses (coarse_grained/run.py:50-75) when
+pytorch_lightning is not installed: max_steps / max_epochs, accumulate_grad_batches, DDP over one process per GPU,
+step-interval LR scheduler, the Lightning hook order (training_step -> training_epoch_end, validation_step ->
+validation_epoch_end, test_step -> test_epoch_end), `last.ckpt` / best-`val/the_metric` checkpoints carrying
+`state_dict` (key-compatible with the reference's `ckpt["state_dict"]`), optimizer and scheduler state, and
+`resume_from_checkpoint`.  With Lightning present, use `pl.Trainer(accelerator="ddp", ...)` directly -- the module is a
+LightningModule."""
+import os
 import time
 
 import torch
 
 from . import parallel
+from .lightning import seed_everything
+
+
+def _to_device(batch, device):
+    return {k: (v.to(device) if isinstance(v, torch.Tensor) else [t.to(device) for t in v]
+                if isinstance(v, list) and v and isinstance(v[0], torch.Tensor) else v) for k, v in batch.items()}
 
 
 class Trainer:
-    def __init__(self, max_steps=100, accumulate_grad_batches=1, log_every_n_steps=10, default_root_dir=None, **unused):
+    def __init__(self, max_steps=None, max_epochs=None, accumulate_grad_batches=1, log_every_n_steps=10, default_root_dir=None,
+                 resume_from_checkpoint=None, val_check_interval=1.0, seed=None, datamodule=None, **unused):
+        if max_steps is None and max_epochs is None:
+            max_epochs = 1000                                   # run.py:59 passes 1000 epochs when it bounds the run by steps
         self.max_steps = max_steps
-        self.max_epochs = None
+        self.max_epochs = max_epochs
         self.accumulate_grad_batches = max(1, int(accumulate_grad_batches))
         self.log_every_n_steps = log_every_n_steps
         self.default_root_dir = default_root_dir
-        self.datamodule = None
+        self.resume_from_checkpoint = resume_from_checkpoint
+        self.datamodule = datamodule
+        self.seed = seed
         self.global_step = 0
+        self.current_epoch = 0
+        self.best_metric = None
 
-    def fit(self, model, train_dataloader, device=None):
-        """`train_dataloader`: iterable of batch dicts (schema of BaseDataset.collate, base_dataset.py:172-245)."""
+    # ---- helpers -------------------------------------------------------------------------------------------------
+    def _attach(self, model):
+        try:
+            model.trainer = self                                # the stand-in LightningModule; a real one exposes a property
+        except AttributeError:
+            object.__setattr__(model, "_fiber_trainer", self)
+
+    def _done(self):
+        return self.max_steps is not None and self.global_step >= self.max_steps
+
+    def _save(self, model, opt, sched, name):
+        if not self.default_root_dir:
+            return
+        os.makedirs(self.default_root_dir, exist_ok=True)
+        torch.save({"state_dict": model.state_dict(), "global_step": self.global_step, "epoch": self.current_epoch,
+                    "optimizer_states": [opt.state_dict()], "lr_schedulers": [sched["scheduler"].state_dict()],
+                    "best_metric": self.best_metric}, os.path.join(self.default_root_dir, name))
+
+    def _resume(self, model, opt, sched, device):
+        ck = torch.load(self.resume_from_checkpoint, map_location=device, weights_only=False)
+        model.load_state_dict(ck["state_dict"], strict=False)
+        if ck.get("optimizer_states"):
+            opt.load_state_dict(ck["optimizer_states"][0])      # FiberAdamW drops its cached device tables here
+        if ck.get("lr_schedulers"):
+            sched["scheduler"].load_state_dict(ck["lr_schedulers"][0])
+        self.global_step = int(ck.get("global_step", 0))
+        self.current_epoch = int(ck.get("epoch", 0))
+        self.best_metric = ck.get("best_metric")
+        model.global_step = self.global_step
+        from . import ops
+        ops.mark_weights_dirty()                                # cached bf16 working copies belong to the old weights
+
+    # ---- loops ---------------------------------------------------------------------------------------------------
+    def fit(self, model, train_dataloader, val_dataloader=None, device=None):
+        """`train_dataloader` / `val_dataloader`: iterables of batch dicts (schema of BaseDataset.collate,
+        base_dataset.py:172-245).  Returns the last training loss."""
         rank, local, world = parallel.init_distributed()
-        model.trainer = self
+        self._attach(model)
+        if self.seed is not None:
+            seed_everything(self.seed)
         if device is None:
             device = torch.device("cuda", local) if torch.cuda.is_available() else torch.device("cpu")
         if hasattr(model, "unused_parameter_names"):
             parallel.freeze_unused(model, model.unused_parameter_names())
         model.to(device).train()
         (opt,), (sched,) = model.configure_optimizers()
+        if self.resume_from_checkpoint:
+            self._resume(model, opt, sched, device)
         net = parallel.wrap_ddp(model, device)
         opt.zero_grad(set_to_none=True)
-        micro, t0, last = 0, time.time(), None
-        while self.global_step < self.max_steps:
-            for batch in train_dataloader:
-                batch = {k: (v.to(device) if isinstance(v, torch.Tensor) else [t.to(device) for t in v]
-                             if isinstance(v, list) and v and isinstance(v[0], torch.Tensor) else v) for k, v in batch.items()}
+        micro, t0, last, step0 = 0, time.time(), None, self.global_step
+        while not self._done() and (self.max_epochs is None or self.current_epoch < self.max_epochs):
+            seen = 0
+            for batch_idx, batch in enumerate(train_dataloader):
+                seen += 1
+                batch = _to_device(batch, device)
                 sync = (micro + 1) % self.accumulate_grad_batches == 0
                 ctx = net.no_sync() if (not sync and hasattr(net, "no_sync")) else _null()
                 with ctx:
-                    if hasattr(model, "current_tasks") and not model.current_tasks:
-                        from .modules import fiber_utils
-                        fiber_utils.set_task(model)
-                    out = net(batch)
-                    loss = sum(v for k, v in out.items() if "loss" in k) / self.accumulate_grad_batches
+                    if net is model and hasattr(model, "training_step"):
+                        loss = model.training_step(batch, batch_idx)
+                    else:                                       # DDP must see forward() itself to arm its reducer
+                        if "loss_names" in getattr(getattr(model, "hparams", None), "config", {}):
+                            from .modules import fiber_utils
+                            fiber_utils.set_task(model)
+                        from . import ops
+                        ops.set_rng_step(self.global_step)
+                        out = net(batch)
+                        loss = sum(v for k, v in out.items() if "loss" in k)
+                    loss = loss / self.accumulate_grad_batches
                     loss.backward()
                 micro += 1
                 if sync:
@@ -55,12 +117,45 @@ class Trainer:
                     last = loss.detach()
                     if rank == 0 and self.log_every_n_steps and self.global_step % self.log_every_n_steps == 0:
                         print(f"step {self.global_step}: loss {float(last) * self.accumulate_grad_batches:.4f} "
-                              f"({(time.time() - t0) / self.global_step:.3f} s/step)", flush=True)
-                    if self.global_step >= self.max_steps:
+                              f"({(time.time() - t0) / max(1, self.global_step - step0):.3f} s/step)", flush=True)
+                    if self._done():
                         break
-        if rank == 0 and self.default_root_dir:
-            torch.save({"state_dict": model.state_dict(), "global_step": self.global_step}, f"{self.default_root_dir}/last.ckpt")
+            if seen == 0:
+                raise ValueError("Trainer.fit: the training dataloader yielded no batch")
+            if hasattr(model, "training_epoch_end"):
+                model.training_epoch_end([])
+            self.current_epoch += 1
+            if val_dataloader is not None:
+                metric = self.validate(model, val_dataloader, device=device)
+                if rank == 0 and metric is not None and (self.best_metric is None or metric > self.best_metric):
+                    self.best_metric = metric                   # ModelCheckpoint(monitor="val/the_metric", mode="max", save_top_k=1)
+                    self._save(model, opt, sched, "best.ckpt")
+            if rank == 0:
+                self._save(model, opt, sched, "last.ckpt")      # save_last=True
         return last
+
+    @torch.no_grad()
+    def validate(self, model, dataloader, device=None):
+        """validation_step over the loader, then validation_epoch_end; returns `val/the_metric` if the module logged it."""
+        self._attach(model)
+        device = device or next(model.parameters()).device
+        was_training = model.training
+        model.eval()
+        outs = [model.validation_step(_to_device(b, device), i) for i, b in enumerate(dataloader)]
+        model.validation_epoch_end(outs)
+        model.train(was_training)
+        value = getattr(model, "logged", {}).get("val/the_metric")
+        return float(value) if value is not None else None
+
+    @torch.no_grad()
+    def test(self, model, dataloader, device=None):
+        """test_step over the loader, then test_epoch_end (run.py:75)."""
+        self._attach(model)
+        device = device or next(model.parameters()).device
+        model.eval()
+        outs = [model.test_step(_to_device(b, device), i) for i, b in enumerate(dataloader)]
+        model.test_epoch_end(outs)
+        return outs
 
 
 class _null:

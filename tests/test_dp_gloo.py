@@ -74,6 +74,73 @@ def test_ddp_gradients_match_single_process(tmp_path):
         torch.testing.assert_close(res["grads"][k], p.grad, rtol=1e-5, atol=1e-6)
 
 
+def _worker_collectives(rank, world, port, out):
+    """World-2 behaviour of the path's OTHER collectives: ITC's concat_all_gather + _dequeue_and_enqueue
+    (fiber_module.py:12-24,181-222), the metric-state reduction of epoch_wrapup (my_metrics.py dist_reduce_fx="sum"), DDP with
+    the bf16 gradient-compression hook and no_sync gradient accumulation."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from fiber_amd import parallel
+    from fiber_amd.config import make_config
+    from fiber_amd.modules import FIBERTransformerSS, fiber_module, fiber_utils
+    from oracle import cases
+    parallel.init_distributed("gloo")
+    res = {}
+    # 1. concat_all_gather: rank-major concatenation, no gradient
+    t = torch.full((2, 3), float(rank + 1))
+    g = fiber_module.concat_all_gather(t)
+    res["gather"] = g.clone()
+    # 2. ITC queues: every rank enqueues the GLOBAL batch (4 samples from 2 ranks), pointer / total advance by the global size
+    m = FIBERTransformerSS(make_config(**dict(cases.TINY, loss_names={"mlm": 1, "itm": 1, "itc": 1}, itc_queue_size=6)))
+    D = m.image_queue.shape[0]
+    imgs = torch.full((2, 3, cases.TINY["image_size"], cases.TINY["image_size"]), float(10 + rank))
+    ids = torch.full((2, cases.TINY["max_text_len"]), 100 + rank, dtype=torch.long)
+    for rnd in range(2):                                      # second round wraps the 6-slot queue
+        m._dequeue_and_enqueue(torch.full((2, D), float(rank + 1 + 10 * rnd)), torch.full((2, D), -float(rank + 1 + 10 * rnd)),
+                               imgs + rnd, ids + rnd, torch.ones_like(ids))
+    res["queue_ptr"], res["queue_total"] = int(m.queue_ptr), int(m.queue_total)
+    res["image_queue_row0"] = m.image_queue[0].clone()
+    res["text_ids_col0"] = m.text_input_queue[:, 0].clone()
+    # 3. metric state summed over ranks at epoch end
+    acc = fiber_utils.Accuracy()
+    acc(torch.tensor([[1.0, 0.0], [0.0, 1.0], [1.0, 0.0]]), torch.tensor([0, 1, 1]) if rank == 0 else torch.tensor([1, 0, -100]))
+    res["acc"] = float(acc.compute())                         # rank 0: 2 of 3, rank 1: 0 of 2 -> 2 / 5
+    # 4. DDP + bf16 compression hook + no_sync accumulation == single process on the concatenated micro-batches
+    toy = Toy()
+    parallel.freeze_unused(toy, ["unused.weight", "unused.bias"])
+    net = parallel.wrap_ddp(toy, bf16_grads=True)
+    full = [_data(8, 1), _data(8, 2)]
+    with net.no_sync():
+        (net({k: v[rank * 4:(rank + 1) * 4] for k, v in full[0].items()})["loss"] / 2).backward()
+    (net({k: v[rank * 4:(rank + 1) * 4] for k, v in full[1].items()})["loss"] / 2).backward()
+    res["grads"] = {k: p.grad.clone() for k, p in toy.named_parameters() if p.grad is not None}
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_gather_queue_metrics_bf16_hook_no_sync(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker_collectives, args=(2, port, out), nprocs=2, join=True)
+    res = torch.load(out)
+    assert torch.equal(res["gather"], torch.tensor([[1.0] * 3] * 2 + [[2.0] * 3] * 2))
+    # 8 samples through a 6-slot queue: pointer (0 + 4 + 4) % 6 = 2, total 8; slots 4,5,0,1 hold round 2 (11,11,12,12), 2,3 round 1 (2,2)
+    assert res["queue_ptr"] == 2 and res["queue_total"] == 8
+    assert res["image_queue_row0"].tolist() == [12.0, 12.0, 2.0, 2.0, 11.0, 11.0]
+    assert res["text_ids_col0"].tolist() == [102, 102, 101, 101, 101, 101]
+    assert abs(res["acc"] - 2 / 5) < 1e-6
+    ref = Toy()
+    for d in (_data(8, 1), _data(8, 2)):
+        (ref(d)["loss"] / 2).backward()
+    for k, p in ref.named_parameters():
+        if not k.startswith("unused"):
+            torch.testing.assert_close(res["grads"][k], p.grad, rtol=2e-2, atol=2e-3)       # bf16 on the wire
+
+
 def test_unused_parameter_list_is_consistent_with_reference_golden(golden):
     """unused_parameter_names() == the parameters that received no gradient in the REFERENCE run (golden fixture)."""
     from fiber_amd.config import make_config

@@ -438,11 +438,12 @@ def test_elementwise(ops):
     assert all(abs(v) < 1e-2 or abs(v - 2.0) < 2e-2 for v in ratio.tolist()), ratio
 
 
-def test_adamw_multi_matches_torch(ops):
-    """csrc/optim.hip vs torch.optim.AdamW (= transformers 4.6.0 AdamW(correct_bias=True), fiber_utils.py:248-252): two
+def test_adamw_multi_matches_hf_rule(ops):
+    """csrc/optim.hip vs the transformers 4.6.0 AdamW(correct_bias=True) rule (fiber_utils.py:248-252; restated in plain
+    torch as fiber_amd.optim.HFAdamW: eps on the un-corrected sqrt(v), weight decay after the update): two
     groups with different lr / weight decay, ragged and unaligned sizes, a scalar parameter, a parameter without a gradient,
     three steps with a changing lr; the cached bf16 working copy of a weight is rewritten by the same kernel."""
-    from fiber_amd.optim import FiberAdamW
+    from fiber_amd.optim import FiberAdamW, HFAdamW
     shapes = [(768, 512), (4099,), (), (3, 5, 7), (1 << 20,), (17,)]
     mine = [rnd(*s, seed=i).to(DEV).requires_grad_(True) if s else torch.tensor(0.3, device=DEV, requires_grad=True)
             for i, s in enumerate(shapes)]
@@ -450,7 +451,7 @@ def test_adamw_multi_matches_torch(ops):
     wb = ops.bf16_weight(mine[0])                                    # creates the cached working copy
     groups = lambda ps: [{"params": ps[:3], "weight_decay": 0.01, "lr": 1e-3}, {"params": ps[3:], "weight_decay": 0.0, "lr": 5e-3}]
     om = FiberAdamW(groups(mine), lr=1e-3, betas=(0.9, 0.98), eps=1e-8)
-    ot = torch.optim.AdamW(groups(ref), lr=1e-3, betas=(0.9, 0.98), eps=1e-8)
+    ot = HFAdamW(groups(ref), lr=1e-3, betas=(0.9, 0.98), eps=1e-8)
     for step in range(3):
         for i, (a, b) in enumerate(zip(mine, ref)):
             if i == 5:
@@ -471,7 +472,7 @@ def test_adamw_multi_matches_torch(ops):
 def test_adamw_multi_bucket_view_gradients(ops):
     """Gradients that are views into one flat buffer at 4-byte (not 16-byte) aligned offsets -- what DDP's
     gradient_as_bucket_view hands the optimizer after a 1-element parameter (alpha_i2t / alpha_t2i) sits in the bucket."""
-    from fiber_amd.optim import FiberAdamW
+    from fiber_amd.optim import FiberAdamW, HFAdamW
     sizes = [1, 4096 + 8, 1, 333, 2048]
     flat = rnd(sum(sizes) + 3, seed=9).to(DEV)
     mine = [rnd(n, seed=20 + i).to(DEV).requires_grad_(True) for i, n in enumerate(sizes)]
@@ -482,12 +483,45 @@ def test_adamw_multi_bucket_view_gradients(ops):
         b.grad = flat[off:off + n].clone()
         off += n
     om = FiberAdamW(mine, lr=1e-2, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01)
-    ot = torch.optim.AdamW(ref, lr=1e-2, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01)
+    ot = HFAdamW(ref, lr=1e-2, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01)
     for _ in range(2):
         om.step()
         ot.step()
     for a, b in zip(mine, ref):
         assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), (a.shape, (a - b).abs().max().item())
+
+
+def test_adamw_load_state_dict_and_moved_storage(ops):
+    """A state dict loaded AFTER a step must be what the kernel updates from then on (the cached device tables hold raw
+    pointers), and a parameter whose storage moved under an unchanged id must not be written through the old pointer."""
+    from fiber_amd.optim import FiberAdamW, HFAdamW
+    mk = lambda: [rnd(300, 40, seed=1).to(DEV).requires_grad_(True), rnd(77, seed=2).to(DEV).requires_grad_(True)]
+    a, b, r = mk(), mk(), mk()
+    oa = FiberAdamW(a, lr=1e-2, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01)
+    ob = FiberAdamW(b, lr=1e-2, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01)
+    orf = HFAdamW(r, lr=1e-2, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01)
+    grads = lambda k: [rnd(300, 40, seed=10 + k).to(DEV), rnd(77, seed=20 + k).to(DEV)]
+
+    def step(opt, ps, k):
+        for p, g in zip(ps, grads(k)):
+            p.grad = g.clone()
+        opt.step()
+    for k in range(2):
+        step(oa, a, k)
+        step(orf, r, k)
+    step(ob, b, 7)                                          # ob has stepped once with other gradients: its tables are built
+    with torch.no_grad():
+        for pb, pa in zip(b, a):
+            pb.copy_(pa)
+    ob.load_state_dict(oa.state_dict())                     # now it must continue a's trajectory
+    b[0].data = b[0].data.clone()                           # storage moves, id(b[0]) stays
+    for k in range(2, 4):
+        step(ob, b, k)
+        step(orf, r, k)
+    for pb, pr in zip(b, r):
+        assert torch.allclose(pb, pr, rtol=2e-6, atol=1e-7), (pb - pr).abs().max().item()
+    sd = ob.state_dict()["state"]
+    assert all(int(v["step"]) == 4 for v in sd.values())
 
 
 @pytest.mark.parametrize("B,L,K,N", [(3, 1000, 128, 136), (4, 576, 512, 512)])
