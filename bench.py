@@ -24,6 +24,7 @@ FLOP_FWD_PAIR = 111.07e9          # fused fwd per image-text pair incl. transfor
 FLOP_MLM_HEAD = 3.14e9
 FLOP_STEP_PER_IMAGE = 3 * (2 * FLOP_FWD_PAIR + FLOP_MLM_HEAD)   # = 675.8 GFLOP (fwd + 2x bwd, two passes)
 PEAK_BF16_TFLOPS = 2500.0         # dense MFMA bf16, MI355X_MICROARCH.md
+PEAK_HBM_GBPS = 8000.0            # HBM3E spec, MI355X_MICROARCH.md (6.3 TB/s is what a float4 copy achieves)
 # Other task configurations of the same path (extras; the default line stays on BASELINE.json's metric).  Algorithmic
 # GFLOP per image per optimizer step, from SURVEY.md section 8(d): image-only Swin 94.16, text-only RoBERTa 6.85, fused 111.07
 # per pair at 384^2 / 40 tokens; 256.51 per pair at 576^2 / 50 tokens.
@@ -132,9 +133,13 @@ def time_dominant_kernel(B, device):
     us = e0.elapsed_time(e1) * 1e3 / reps
     tf = 2.0 * M * N * K / (us * 1e-6) / 1e12
     alg_bytes = 2 * (M * K + N * K + 2 * M * N)          # X, W in; Y and the saved pre-activation out
+    # 618.5 GFLOP over 2.72 GB = 227 flop/B, BELOW the machine balance (2500 TFLOP/s / 8 TB/s = 312 flop/B): with its two
+    # output streams this kernel is HBM-bound by construction (floor 340 us at 8 TB/s vs 247 us of MFMA time), so its
+    # roofline is stated against HBM bandwidth; the MFMA fraction is given beside it.
+    gbps = alg_bytes / us / 1e3
     out = {"kernel": "gemm_nt_wide_persist_kernel<2,4,1,false,false> (stage-2 fc1: bias + GELU + pre-activation store)", "shape": [M, N, K], "us": round(us, 2),
-           "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
-           "algorithmic_bytes": alg_bytes, "algorithmic_GBps": round(alg_bytes / us / 1e3, 1), "traffic": None}
+           "bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
+           "algorithmic_bytes": alg_bytes, "mfma_TFLOPs": round(tf, 1), "mfma_frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None}
     try:   # HBM bytes per launch from the committed PMC pass (profiles/, collected with rocprofv3 --pmc on this same shape)
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")))
         if pmc["shape"] == [M, N, K]:
@@ -165,8 +170,8 @@ def time_forward(model, batch, B, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)       # warm-up 10, >= 50 timed steps, median + p10/p90
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("FIBER_BENCH_BATCH", "0")),
                     help="per-GPU batch (default: 256 for the headline task, 96 for mlm_itm_itc whose 1+3 fused passes hold "
                          "more activations, 160 for vqa at 576^2)")
@@ -226,21 +231,45 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # per-step HIP events (recorded on the compute stream, read after the timed region: no extra synchronisation inside it)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    dt = time.perf_counter() - t0
+    dt_local = dt = time.perf_counter() - t0
+    per_rank_ms = [dt_local / args.steps * 1e3]
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank_ms = [x.item() / args.steps * 1e3 for x in allt]
+        dt = max(x.item() for x in allt)                     # MAX over ranks
     ms = dt / args.steps * 1e3
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    pct = lambda q: step_ms[min(len(step_ms) - 1, int(round(q * (len(step_ms) - 1))))]
+    exposed_allreduce_ms = None
+    if world > 1 and not args.no_extras:
+        # the same step without the gradient all-reduce (DDP no_sync): the difference is the communication time that backward
+        # did NOT hide.  Outside the timed region; gradients of these steps are rank-local and are thrown away with the run.
+        n_ns = max(3, min(10, args.steps))
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(n_ns):
+            with net.no_sync():
+                step()
+        torch.cuda.synchronize()
+        ms_ns = torch.tensor([(time.perf_counter() - t1) / n_ns * 1e3], device=device, dtype=torch.float64)
+        dist.all_reduce(ms_ns, op=dist.ReduceOp.MAX)
+        exposed_allreduce_ms = round(ms - ms_ns.item(), 3)
     if rank == 0:
         print(f"[bench] {ms:.2f} ms/step, {args.batch * world * args.steps / dt:.1f} images/s, peak HBM "
               f"{torch.cuda.max_memory_allocated() / 2**30:.1f} GiB allocated / {torch.cuda.max_memory_reserved() / 2**30:.1f} GiB reserved",
@@ -261,6 +290,10 @@ def main():
             "config": {"workload": task["workload"], "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "dropout": "reference defaults (text 0.1, DropPath linspace 0..0.1)"},
             "loss": round(lossv, 4),
+            "step_ms": {"p10": round(pct(0.1), 3), "median": round(pct(0.5), 3), "p90": round(pct(0.9), 3),
+                        "per_rank_mean": [round(x, 3) for x in per_rank_ms], "allreduce_exposed": exposed_allreduce_ms,
+                        "grad_allreduce": ("bf16 buckets (bf16_compress_hook), 64 MB, reverse execution order after step 0"
+                                           if world > 1 else None)},
             "roofline": {"bound": "mfma", "achieved": round(tf_per_gpu, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tf_per_gpu / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "basis": f"{task['flop'] / 1e9:.1f} GFLOP algorithmic per image per step (BASELINE.md section 3 / SURVEY.md "
