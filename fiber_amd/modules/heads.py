@@ -52,9 +52,11 @@ class MLMHead(nn.Module):
         self.bias = nn.Parameter(torch.zeros(config.vocab_size))
         if weight is not None:
             self.decoder.weight = weight
+        self.last_hidden = None          # transform output of the latest forward (objectives._mlm_ce: fp32 label logits)
 
     def forward(self, x):
         h = self.transform(x)
+        self.last_hidden = h.detach()
         return ops.lib_linear(h, ops.cast_bf16(self.decoder.weight), ops.cast_bf16(self.bias))
 
 

@@ -7,16 +7,32 @@ import torch.nn.functional as F
 from .. import ops
 
 
-def _mlm_ce(logits, labels):
-    """F.cross_entropy(logits, labels, ignore_index=-100) (objectives.py:24-28) on the HIP kernel for bf16 device logits."""
-    return ops.cross_entropy(logits.to(torch.bfloat16), labels, -100)
+def _mlm_ce(logits, labels, head=None):
+    """F.cross_entropy(logits, labels, ignore_index=-100) (objectives.py:24-28) on the HIP kernel for bf16 device logits.
+
+    The 50265-way logits are bf16 (2 B instead of 8 MB per sample of HBM traffic); log-sum-exp averages their rounding away,
+    but the LABEL logit enters the loss directly, and 2^-9 relative rounding of a logit of magnitude 5-10 is 1e-2..2e-2 per
+    token -- the dominant term of the loss-curve gap to the fp32 reference (tests/test_hip_modules.py, 50-step curve).  With
+    `head` (the MLMHead, after its forward) the label logit is recomputed in fp32 from the head's hidden state -- a gathered
+    dot product per token -- and substituted into the loss VALUE; gradients are unchanged (they are the same function)."""
+    loss = ops.cross_entropy(logits.to(torch.bfloat16), labels, -100)
+    if head is not None and head.last_hidden is not None:
+        with torch.no_grad():
+            h = head.last_hidden.reshape(-1, head.last_hidden.shape[-1])
+            valid = labels != -100
+            lab = labels.clamp(min=0)
+            z16 = logits.gather(1, lab[:, None]).squeeze(1).float()
+            z32 = (h.float() * head.decoder.weight[lab]).sum(-1) + head.bias[lab]
+            corr = ((z16 - z32) * valid).sum() / valid.sum().clamp(min=1)
+        loss = loss + corr                                  # a constant w.r.t. autograd: value correction only
+    return loss
 
 
 def compute_mlm(pl_module, batch):
     infer = pl_module.infer(batch, mask_text=True, mask_image=False)
     mlm_logits = pl_module.mlm_score(infer["text_feats"])
     mlm_labels = infer["text_labels"]
-    mlm_loss = _mlm_ce(mlm_logits.view(-1, pl_module.hparams.config["vocab_size"]), mlm_labels.view(-1))
+    mlm_loss = _mlm_ce(mlm_logits.view(-1, pl_module.hparams.config["vocab_size"]), mlm_labels.view(-1), pl_module.mlm_score)
     ret = {"mlm_loss": mlm_loss, "mlm_logits": mlm_logits, "mlm_labels": mlm_labels, "mlm_ids": infer["text_ids"]}
     phase = "train" if pl_module.training else "val"
     loss = getattr(pl_module, f"{phase}_mlm_loss")(ret["mlm_loss"])
@@ -75,7 +91,7 @@ def compute_mlm_itm_fused(pl_module, batch, itm_labels=None):
     infer = pl_module.infer(fused, mask_text=False, mask_image=False)
     mlm_logits = pl_module.mlm_score(infer["text_feats"][:B])
     mlm_labels = batch["text_labels_mlm"]
-    mlm_loss = _mlm_ce(mlm_logits.view(-1, pl_module.hparams.config["vocab_size"]), mlm_labels.view(-1))
+    mlm_loss = _mlm_ce(mlm_logits.view(-1, pl_module.hparams.config["vocab_size"]), mlm_labels.view(-1), pl_module.mlm_score)
     itm_logits = pl_module.itm_score(infer["cls_feats"][B:])
     itm_loss = F.cross_entropy(itm_logits, itm_labels.long())
     ret = {"mlm_loss": mlm_loss, "mlm_logits": mlm_logits, "mlm_labels": mlm_labels, "mlm_ids": batch["text_ids_mlm"],
@@ -176,7 +192,7 @@ def compute_mlm_itm_hardneg_fused(pl_module, batch, image_neg, text_neg, text_ma
     infer = pl_module.infer(fused, mask_text=False, mask_image=False)
     mlm_logits = pl_module.mlm_score(infer["text_feats"][:B])
     mlm_labels = batch["text_labels_mlm"]
-    mlm_loss = _mlm_ce(mlm_logits.view(-1, pl_module.hparams.config["vocab_size"]), mlm_labels.view(-1))
+    mlm_loss = _mlm_ce(mlm_logits.view(-1, pl_module.hparams.config["vocab_size"]), mlm_labels.view(-1), pl_module.mlm_score)
     itm_labels = torch.cat([torch.ones(B), torch.zeros(2 * B)]).to(pl_module.device)
     itm_logits = pl_module.itm_score(infer["cls_feats"][B:])
     itm_loss = F.cross_entropy(itm_logits, itm_labels.long())

@@ -54,7 +54,7 @@ SWIN_B = dict(image_size=384, vit="swin_base_patch4_window12_384_in22k", text_dr
 PATH_CASES = {
     "path_tiny": dict(config=TINY, B=2, grads=True),
     "path_swin_t": dict(config=SWIN_T, B=2, grads=True),
-    "path_swin_b": dict(config=SWIN_B, B=1, grads=False),
+    "path_swin_b": dict(config=SWIN_B, B=1, grads=True),
 }
 
 

@@ -71,6 +71,72 @@ def test_swin_block(name, golden):
         _grad_close(n, p.grad, rp[n].grad)
 
 
+def _golden_grads(module, gold, tol, skip=()):
+    """every parameter gradient the reference run stored for this module: rel-L2 of the strided sample <= tol"""
+    n_checked = 0
+    for n, p in module.named_parameters():
+        if f"grad/{n}/sub" in gold and n not in skip:
+            _sub_close("grad " + n, p.grad, gold, "grad/" + n, tol)
+            n_checked += 1
+    return n_checked
+
+
+@pytest.mark.parametrize("name", list(cases.MERGE_CASES))
+def test_patch_merging_golden(name, golden):
+    """PatchMerging (swin_transformer.py:411-432) on the HIP path against the fingerprints of the REFERENCE's own run
+    (tests/golden/merge_*.npz): output, input gradient, norm / reduction gradients.  bf16 compute: rel-L2 <= 1.5e-2 / 3e-2."""
+    from fiber_amd.modules import swin_transformer as S
+    c, gold = cases.MERGE_CASES[name], golden(name)
+    ref = detgen.fill_(R.PatchMerging(c["res"], c["dim"]).eval())
+    m = S.PatchMerging(c["res"], c["dim"]).eval()
+    m.load_state_dict(ref.state_dict())
+    m.to(DEV)
+    L = c["res"][0] * c["res"][1]
+    x = bf(cases.randn(name + ".x", (c["B"], L, c["dim"]))).requires_grad_(True)
+    g = cases.randn(name + ".g", (c["B"], L // 4, 2 * c["dim"]))
+    out = m(x)
+    out.backward(bf(g))
+    _sub_close("out", out, gold, "out", 1.5e-2)
+    _sub_close("dx", x.grad, gold, "grad_in/x", 3e-2)
+    assert _golden_grads(m, gold, 3e-2) == 3
+
+
+@pytest.mark.parametrize("name", list(cases.EMBED_CASES))
+def test_patch_embed_golden(name, golden):
+    """timm PatchEmbed (conv4s4 + LN, swin_transformer.py:588-594) against tests/golden/pe_*.npz (reference run)."""
+    from fiber_amd.modules import swin_transformer as S
+    c, gold = cases.EMBED_CASES[name], golden(name)
+    ref = detgen.fill_(R.PatchEmbed(c["img"], 4, 3, c["dim"]).eval())
+    m = S.PatchEmbed(c["img"], 4, 3, c["dim"]).eval()
+    m.load_state_dict(ref.state_dict())
+    m.to(DEV)
+    img = cases.randn(name + ".img", (c["B"], 3, c["img"], c["img"])).to(DEV)
+    out = m(img)
+    out.backward(bf(cases.randn(name + ".g", tuple(out.shape))))
+    _sub_close("out", out, gold, "out", 1.5e-2)
+    assert _golden_grads(m, gold, 3e-2) == 4
+
+
+def test_roberta_embeddings_golden(golden):
+    """RobertaEmbeddings with padded rows (roberta.py:169-199, position ids :877-888) against tests/golden/roberta_emb.npz."""
+    from fiber_amd.modules import roberta as RB
+    gold = golden("roberta_emb")
+    ref = detgen.fill_(R.RobertaEmbeddings(50265, 768, 514, dropout=0.1).eval())
+    emb = RB.RobertaEmbeddings(RB.roberta_base_config()).eval()
+    emb.load_state_dict(ref.state_dict(), strict=False)
+    emb.to(DEV)
+    b = detgen.synth_batch(3, image_size=8, seed=3)
+    assert (b["text_ids"] == 1).any(), "fixture must contain padded rows"
+    out = emb(input_ids=b["text_ids"].to(DEV))
+    out.backward(bf(cases.randn("emb.g", tuple(out.shape))))
+    _sub_close("out", out, gold, "out", 1.5e-2)
+    rows = torch.unique(b["text_ids"]).to(DEV)
+    _sub_close("d word rows", emb.word_embeddings.weight.grad[rows], gold, "grad/word_rows", 3e-2)
+    _sub_close("d position", emb.position_embeddings.weight.grad, gold, "grad/position_embeddings", 3e-2)
+    _sub_close("d token type", emb.token_type_embeddings.weight.grad, gold, "grad/token_type_embeddings", 3e-2)
+    _sub_close("d LN weight", emb.LayerNorm.weight.grad, gold, "grad/LayerNorm.weight", 3e-2)
+
+
 @pytest.mark.parametrize("name", list(cases.ROBERTA_LAYER_CASES))
 def test_roberta_layer(name, golden):
     from fiber_amd.modules import roberta as RB
@@ -100,6 +166,44 @@ def test_roberta_layer(name, golden):
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
             continue
         _grad_close(n, p.grad, rp[n].grad)
+
+
+# Gradient-NORM tolerances against the reference's fp32 run, by explicit rule (round 1 tolerated "up to 2 % of all parameters"
+# anonymously).  |got - ref| <= rel * ref + floor, with
+#   rel   = 8 % for every parameter, except the named classes in GRADNORM_LOOSE;
+#   floor = 0 except for gradients that are SUMS WITH HEAVY CANCELLATION, where bf16 rounding of the terms sets an absolute
+#           error scale that the (tiny) exact sum does not reflect:
+#     "<layer>.bias"  column sum of dY over all rows: floor = 0.5 % of the norm of the SAME layer's weight gradient (both are
+#                     built from the same dY; e.g. the ITM classifier bias with two samples of opposite-sign gradient:
+#                     |db| = 0.009 |dW|).  Measured worst cases: path_tiny cross_modal_image_transform.bias (ref 4.2e-5 vs
+#                     weight 4.0e-2), layers.3.blocks.1.mlp.fc2.bias (1.4e-5 vs 8.8e-3), cross_modal_image_pooler.dense.bias
+#                     (2.8e-4 vs 4.1e-2); path_swin_t itm_score.fc.bias (7.1e-3 vs 0.78).
+#     "alpha_*"       scalar gate = <dOut, branch> over every element: floor = 0.5 % of the median |gradient| of the model's
+#                     other gates (vqa_swin_b_576: layer-6 alpha_t2i is 4.8e-5 next to peers of 1e-2..5e-2: a zero crossing).
+#   relative_position_bias_table: sums over 10^4..10^5 (window, query, key) softmax-gradient terms of mixed sign: rel 15 %.
+GRADNORM_LOOSE = (("alpha_i2t", 0.20), ("alpha_t2i", 0.20), ("relative_position_bias_table", 0.15))
+
+
+def _gradnorm_tol(name, gold=None):
+    """(rel, floor) for parameter `name`; `gold` = the fixture (reference gradient norms) for the cancellation floors."""
+    rel = 0.08
+    for pat, tol in GRADNORM_LOOSE:
+        if pat in name:
+            rel = tol
+    floor = 0.0
+    if gold is not None:
+        if name.endswith(".bias") and f"gradnorm/{name[:-4]}weight" in gold:
+            floor = 5e-3 * float(gold[f"gradnorm/{name[:-4]}weight"])
+        elif "alpha_" in name:
+            peers = [float(v) for k, v in gold.items() if k.startswith("gradnorm/") and "alpha_" in k and not k.endswith(name)]
+            if peers:
+                floor = 5e-3 * float(np.median(peers))
+    return rel, floor
+
+
+def _gradnorm_bad(name, got, gn, gold):
+    rel, floor = _gradnorm_tol(name, gold)
+    return abs(got - gn) > rel * gn + floor + 1e-6
 
 
 def _to_dev(b):
@@ -157,9 +261,9 @@ def test_fused_path(name, golden):
                     if gn < 1e-6:                      # mathematically zero gradient (key bias): absolute bound only
                         assert got < 1e-2, (n, got)
                         continue
-                    if abs(got - gn) > 0.08 * gn + 1e-6:
-                        bad.append((n, got, gn))
-            assert len(bad) <= max(2, len(params) // 50), bad[:10]
+                    if _gradnorm_bad(n, got, gn, gold):
+                        bad.append((n, round(got / gn - 1, 4), float("%.3e" % gn)))
+            assert not bad, bad                                # explicit, named tolerances only (GRADNORM_LOOSE)
             for key in gold:
                 if key.startswith("grad/") and key.endswith("/sub"):
                     n = key[len("grad/"):-len("/sub")]
@@ -204,9 +308,9 @@ def test_vqa_finetune_path(name, golden):
             if gn < 1e-6:
                 assert got < 1e-2 * max(1.0, gl), (n, got)
                 continue
-            if abs(got - gn) > 0.08 * gn + 1e-6:
-                bad.append((n, got, gn))
-    assert len(bad) <= max(2, len(params) // 50), bad[:10]
+            if _gradnorm_bad(n, got, gn, gold):
+                bad.append((n, round(got / gn - 1, 4), float("%.3e" % gn)))
+    assert not bad, bad
     for key in gold:
         if key.startswith("grad/") and key.endswith("/sub"):
             n = key[len("grad/"):-len("/sub")]
@@ -266,9 +370,9 @@ def test_itc_pretrain_steps(name, fuse, golden):
             if gn < 1e-6:
                 assert got < 1e-2, (n, got)
                 continue
-            if abs(got - gn) > 0.08 * gn + 1e-6:
-                bad.append((n, got, gn))
-    assert len(bad) <= max(2, len(params) // 50), bad[:10]
+            if _gradnorm_bad(n, got, gn, gold):
+                bad.append((n, round(got / gn - 1, 4), float("%.3e" % gn)))
+    assert not bad, bad
     for key in gold:
         if key.startswith("grad/") and key.endswith("/sub"):
             n = key[len("grad/"):-len("/sub")]
@@ -351,8 +455,9 @@ def test_fused_mlm_itm_pass_equals_two_passes():
 
 def test_loss_curve_tracks_oracle_over_optimizer_steps():
     """MLM+ITM loss curve over 8 AdamW steps (dropout / DropPath 0, fixed batch, fixed ITM permutation): HIP bf16 path vs
-    the fp32 oracle from identical weights.  North-star asks for +-1e-3 on the curves; the measured gap (max 2.3e-3 over 8 steps,
-    mostly ~1e-3) is printed and held to 4e-3 absolute here (bf16 activations/weight copies on a ~7.6 loss; the per-step DIFFERENCES agree to ~1e-3)."""
+    the fp32 oracle from identical weights.  North-star asks for +-1e-3 on the curves; the measured gap (max 1.1e-3 over 8 steps
+    with the fp32 label logit of objectives._mlm_ce, 2.3e-3 before it) is printed and held to 2.5e-3 absolute here (bf16
+    activations / weight copies on a ~7.5 loss)."""
     from fiber_amd.config import make_config
     from fiber_amd.modules import FIBERTransformerSS, fiber_utils, objectives
     cfg = dict(cases.TINY)
@@ -375,7 +480,8 @@ def test_loss_curve_tracks_oracle_over_optimizer_steps():
     for gi, g in enumerate(opt.param_groups):
         for p in g["params"]:
             groups[gi]["params"].append(rparams[name_of[id(p)]])
-    ropt = torch.optim.AdamW(groups, lr=1e-4, eps=1e-8, betas=(0.9, 0.98))
+    from fiber_amd.optim import HFAdamW                    # the same rule as the HIP optimizer kernel (transformers 4.6.0 AdamW)
+    ropt = HFAdamW(groups, lr=1e-4, eps=1e-8, betas=(0.9, 0.98))
     got, want = [], []
     for step in range(8):
         opt.zero_grad(set_to_none=True)
@@ -393,4 +499,80 @@ def test_loss_curve_tracks_oracle_over_optimizer_steps():
     print("hip   :", [round(v, 4) for v in got])
     print("oracle:", [round(v, 4) for v in want])
     assert want[-1] < want[0] - 0.01, "oracle loss should fall on a fixed batch"
-    assert gap < 4e-3 and dgap < 4e-3, (gap, dgap, got, want)
+    assert gap < 2.5e-3 and dgap < 2.5e-3, (gap, dgap, got, want)
+
+
+def test_loss_curve_swin_t_224_mlm_itm_50_steps():
+    """BASELINE.json configs[0] shape (Swin-Tiny + RoBERTa-base, 224x224, MLM+ITM; batch 2 here so that the fp32 oracle's 50
+    CPU steps stay within a few minutes), 50 optimizer steps with the
+    reference's hyper-parameter structure (6 parameter groups, lr x5 on heads / cross-modal, HF AdamW, linear warm-up + poly
+    decay), dropout / DropPath 0 and a FIXED cycle of 5 synthetic batches on both sides: HIP bf16 path vs the fp32 oracle from
+    identical weights.  The north star asks for +-1e-3 on the curves; the per-step gap is printed, summarised into
+    gpurun_out/loss_curve_swin_t.json when that directory exists, and held to the bound stated at the bottom."""
+    import json
+    import os
+    from fiber_amd import parallel
+    from fiber_amd.config import make_config
+    from fiber_amd.modules import FIBERTransformerSS, fiber_utils
+    from fiber_amd.optim import HFAdamW
+    steps, nb = 50, 5
+    torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+    cfg = dict(cases.SWIN_T)
+    torch.manual_seed(0)
+    ref = detgen.fill_(R.FiberRef(cfg).train())
+    hyper = dict(learning_rate=2e-5, lr_mult_head=5, lr_mult_cross_modal=5, warmup_steps=5, max_steps=steps, weight_decay=0.01,
+                 end_lr=0, decay_power=1)
+    model = FIBERTransformerSS(make_config(**cfg, **hyper)).train()
+    load_from_oracle(model, ref)
+    for m_ in (ref, model):
+        for n, p in m_.named_parameters():
+            if "alpha_" in n:
+                p.data.fill_(0.5)                          # reference init 0 would switch the fusion branches off (SURVEY 8d)
+    model.to(DEV)
+    fiber_utils.set_task(model)
+    parallel.freeze_unused(model, model.unused_parameter_names())
+    (opt,), (sched,) = model.configure_optimizers()
+    # (the product's LambdaLR has already scaled g["lr"] by lambda(0) = 0: the group's own rate is initial_lr)
+    groups = [{"params": [], "weight_decay": g["weight_decay"], "lr": g["initial_lr"]} for g in opt.param_groups]
+    name_of = {id(p): n for n, p in model.named_parameters()}
+    rparams = dict(ref.named_parameters())
+    for gi, g in enumerate(opt.param_groups):
+        for p in g["params"]:
+            groups[gi]["params"].append(rparams[name_of[id(p)]])
+    ropt = HFAdamW(groups, lr=hyper["learning_rate"], eps=1e-8, betas=(0.9, 0.98))
+    rsched = torch.optim.lr_scheduler.LambdaLR(ropt, lambda s_: fiber_utils.poly_decay_lambda(s_, 5, steps, hyper["learning_rate"], 0, 1))
+    batches = [detgen.synth_batch(2, 224, 40, 50265, seed=100 + i, min_len=8) for i in range(nb)]
+    dbatches = []
+    for b in batches:
+        bd = _to_dev(b)
+        bd["itm_labels_override"] = bd["itm_labels"]
+        dbatches.append(bd)
+    got, want = [], []
+    for step in range(steps):
+        b, bd = batches[step % nb], dbatches[step % nb]
+        opt.zero_grad(set_to_none=True)
+        loss = model.training_step(bd, step)
+        loss.backward()
+        opt.step()
+        sched["scheduler"].step()
+        ropt.zero_grad(set_to_none=True)
+        rl = ref.training_loss(b, b["itm_labels"])
+        rl.backward()
+        ropt.step()
+        rsched.step()
+        got.append(loss.item())
+        want.append(rl.item())
+    gaps = [abs(a - c) for a, c in zip(got, want)]
+    srt = sorted(gaps)
+    summary = {"steps": steps, "loss_first": want[0], "loss_last": want[-1], "gap_max": max(gaps), "gap_median": srt[len(srt) // 2],
+               "gap_p90": srt[int(0.9 * (len(srt) - 1))], "steps_within_1e-3": sum(g_ <= 1e-3 for g_ in gaps),
+               "hip": [round(v, 5) for v in got], "oracle": [round(v, 5) for v in want]}
+    print(json.dumps(summary))
+    if os.path.isdir("gpurun_out"):
+        json.dump(summary, open("gpurun_out/loss_curve_swin_t.json", "w"))
+    assert want[-1] < want[0] - 0.05, "oracle loss should fall over 50 steps"
+    # Measured (profiles/r02_loss_curve_swin_t.json): loss 11.21 -> 1.34; gap median 2.2e-3, p90 5.1e-3, max 8.1e-3, 11 of 50
+    # steps within the north star's 1e-3, step 0 (no training dynamics: forward numerics only) 1.9e-3.  bf16 activations with
+    # a 12-token MLM mean at batch 2 do not reach +-1e-3; before the fp32 label-logit correction (objectives._mlm_ce) the same
+    # run read median 2.9e-3 / max 1.5e-2.  Bounds below = 2x the measured values.
+    assert summary["gap_max"] < 1.6e-2 and summary["gap_median"] < 4.5e-3, summary
