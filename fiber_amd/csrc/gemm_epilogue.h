@@ -1,0 +1,185 @@
+// Shared pieces of the NT GEMM kernels (gemm.hip): argument block, LDS swizzle, fused epilogue.
+#pragma once
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 64;
+
+struct GemmArgs {
+  const bf16* X; const bf16* W; const float* bias; const bf16* R; bf16* Y; bf16* Ypre;
+  const float* rowscale;   // optional per-sample scale (timm DropPath): row m uses rowscale[m / rows_per_sample]
+  const bf16* aux;         // act == 2: pre-activation H [M, ldaux]; the output is acc * gelu'(H)  (fused GELU backward)
+  float* colpart;          // optional [tilesM, N] fp32: per-row-tile column sums of the stored output (bias gradient)
+  int M, N, K, ldx, ldw, ldy, ldr, act, rows_per_sample, ldaux;
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return (row * 8 + (chunk ^ ((row >> 1) & 7))) * 8; }  // element offset
+
+// ---------------------------------------------------------------------------------------------------------------
+// Epilogue shared by the LDS-DMA kernels: accumulators -> LDS tile (bf16, in ROUNDS row slabs) -> coalesced 16-byte rows.
+// Everything that selects code is a template parameter: with the variants as run-time flags the unrolled store passes
+// compiled to ~560 instructions each and the epilogue of a 256x256 tile cost 7 us *without* its stores (ablation in
+// tools/gemm_dbg.py) -- as much as the tile's MFMAs at K = 512.
+//   EPI 0: Y = rowscale * (acc + bias) + R          (HAS_RS / HAS_R)
+//   EPI 1: Ypre = acc + bias (optional);  Y = rowscale * gelu(bf16(acc + bias))
+//   EPI 2: Y = acc * gelu'(aux);  optional per-row-tile column sums of Y (colpart)
+//   FULL:  the tile lies entirely inside [M, N] (no row / column predicates)
+// Y is read by the next kernel and is stored normally: marking it non-temporal made the isolated GEMM faster (fc1 845 ->
+// 772 us at M = 295k, less L2 pollution) but the whole step slower (670 -> 658 images/s, the consumer then misses the
+// Infinity Cache).  The pre-activation copy is only read again in the backward pass, so it does stream past the caches.
+__device__ __forceinline__ void st_out(bf16x8* p, bf16x8 v) { *p = v; }
+__device__ __forceinline__ void st_stream(bf16x8* p, bf16x8 v) { __builtin_nontemporal_store(v, p); }
+
+//   RAWBAR: barriers are s_waitcnt lgkmcnt(0) + s_barrier instead of __syncthreads() -- for the persistent kernel, where a
+//          __syncthreads() fence would drain the next tile's LDS-DMA and this tile's own stores (vmcnt(0)).
+template <bool RAWBAR>
+__device__ __forceinline__ void epi_barrier() {
+  if constexpr (RAWBAR) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  } else {
+    __syncthreads();
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int ROUNDS, int EPI, bool HAS_R, bool HAS_RS, bool FULL, bool RAWBAR = false>
+__device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], bf16* Cs,
+                                              const float* bias_s, int tm0, int tn0) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int CLD = BN + 8;
+  constexpr int HM = BM / ROUNDS;                       // rows staged per round
+  constexpr int CPR = BN / 8;                           // 16-byte chunks per tile row
+  constexpr int RPP = NT / CPR;                         // rows per store pass
+  constexpr int NPH = HM / RPP;                         // store passes per round
+  static_assert(HM % 32 == 0 && HM % RPP == 0, "epilogue geometry");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int erow = tid / CPR, echunk = tid % CPR;
+  const int n_out = tn0 + echunk * 8;
+  const bool col_ok = FULL || n_out < a.N;
+  constexpr bool SIDE = HAS_R || EPI == 2;
+  const bf16* sidep = EPI == 2 ? a.aux : a.R;
+  const size_t sideld = EPI == 2 ? a.ldaux : a.ldr;
+  const bool has_bias = a.bias != nullptr;
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int h = 0; h < ROUNDS; ++h) {
+    const int mbase = tm0 + h * HM + erow;              // this thread's first output row in the round
+    // side rows / DropPath scales are requested BEFORE the staging pass so their latency hides behind it
+    bf16x8 side[SIDE ? NPH : 1];
+    float prs[(EPI == 1 && HAS_RS) ? NPH : 1];
+    if constexpr (SIDE) {
+      const bf16* sp = sidep + (size_t)mbase * sideld + n_out;
+#pragma unroll
+      for (int pp = 0; pp < NPH; ++pp)
+        if (FULL || (mbase + pp * RPP < a.M && col_ok)) side[pp] = *reinterpret_cast<const bf16x8*>(sp + (size_t)pp * RPP * sideld);
+    }
+    if constexpr (EPI == 1 && HAS_RS) {
+#pragma unroll
+      for (int pp = 0; pp < NPH; ++pp) prs[pp] = a.rowscale[min(mbase + pp * RPP, a.M - 1) / a.rows_per_sample];
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if (ROUNDS == 1 || (wm * WTM + i * 32) / HM == h) {          // this wave's 32-row slab i belongs to round h
+        const int ml = wm * WTM + i * 32 + (lane & 31);
+        float rsc = 1.f;
+        if constexpr (EPI == 0 && HAS_RS) rsc = a.rowscale[min(tm0 + ml, a.M - 1) / a.rows_per_sample];
+        bf16* crow = Cs + (ml - h * HM) * CLD + wn * WTN + (lane >> 5) * 4;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int nl = wn * WTN + j * 32 + q * 8 + (lane >> 5) * 4;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
+            if (EPI != 2 && has_bias) {
+              const float4 bb = *reinterpret_cast<const float4*>(bias_s + nl);
+              v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+            }
+            if constexpr (EPI == 0 && HAS_RS) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] *= rsc;
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+            *reinterpret_cast<bf16x4*>(crow + j * 32 + q * 8) = o;
+          }
+      }
+    }
+    epi_barrier<RAWBAR>();
+    {
+      bf16* yp = a.Y + (size_t)mbase * a.ldy + n_out;
+      bf16* prep = (EPI == 1 && a.Ypre) ? a.Ypre + (size_t)mbase * a.ldy + n_out : nullptr;
+      const size_t ystep = (size_t)RPP * a.ldy;
+      const bf16* cp = Cs + erow * CLD + echunk * 8;
+#pragma unroll
+      for (int pp = 0; pp < NPH; ++pp) {
+        if (FULL || (mbase + pp * RPP < a.M && col_ok)) {
+          bf16x8 v = *reinterpret_cast<const bf16x8*>(cp + pp * RPP * CLD);
+          if constexpr (EPI == 1) {
+            if (prep) st_stream(reinterpret_cast<bf16x8*>(prep + pp * ystep), v);
+            v = gelu8(v, HAS_RS ? prs[pp] : 1.f);
+          } else if constexpr (EPI == 2) {
+            v = gelu_grad_mul8(v, side[pp]);
+          }
+          if constexpr (HAS_R) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(side[pp][e]));
+          }
+          st_out(reinterpret_cast<bf16x8*>(yp + pp * ystep), v);
+          if constexpr (EPI == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) csum[e] += bf2f(v[e]);
+          }
+        }
+      }
+    }
+    if (h + 1 < ROUNDS || EPI == 2 || RAWBAR) epi_barrier<RAWBAR>();     // staged slab fully read before it is overwritten / re-used
+  }
+  if constexpr (EPI == 2) {
+    if (a.colpart) {                                    // column sums of the stored tile: bias gradient of the fused backward
+      float* red = reinterpret_cast<float*>(Cs);
+      constexpr int LPC = 64 / (CPR < 64 ? CPR : 64);   // lanes of one wave that share a column chunk
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = csum[e];
+        if constexpr (LPC >= 2 && CPR <= 32) t += __shfl_xor(t, 32);
+        if constexpr (LPC >= 4 && CPR <= 16) t += __shfl_xor(t, 16);
+        if constexpr (LPC >= 8 && CPR <= 8) t += __shfl_xor(t, 8);
+        csum[e] = t;
+      }
+      static_assert(CPR == 8 || CPR == 16 || CPR == 32, "column-sum shuffle tree");
+      if (lane < CPR) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wave * BN + lane * 8 + e] = csum[e];
+      }
+      epi_barrier<RAWBAR>();
+      for (int c = tid; c < BN; c += NT) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM * WN; ++w) t += red[w * BN + c];
+        if (tn0 + c < a.N) a.colpart[(size_t)(tm0 / BM) * a.N + tn0 + c] = t;
+      }
+      if constexpr (RAWBAR) epi_barrier<RAWBAR>();
+    }
+  }
+}
+
+// bias slice of the tile -> LDS once per workgroup (read by the staging pass many barriers later)
+template <int BN>
+__device__ __forceinline__ void stage_bias(const GemmArgs& a, float* bias_s, int tn0) {
+  if (a.bias && threadIdx.x < BN / 4) {
+    const int n = min(tn0 + (int)threadIdx.x * 4, a.N - 4);
+    *reinterpret_cast<float4*>(bias_s + threadIdx.x * 4) = *reinterpret_cast<const float4*>(a.bias + n);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+}  // namespace
