@@ -40,10 +40,12 @@ SIGNATURES = {
     "fiber_ce_fwd_bf16": [P, P, P, P, I, I, L],
     "fiber_ce_bwd_bf16": [P, P, P, P, P, I, I, L],
     "fiber_adamw_multi_f32": [P, P, P, I, F, F, F, F, F, I],
+    "fiber_resize_bicubic_norm_u8": [P, I, P, P, P, I, I, P, P],
+    "fiber_mlm_mask_i64": [P, P, P, L, U64, C.c_uint, I, I, I, I],
 }
 # host-side helpers without a stream argument
 PLAIN = {"fiber_layernorm_bwd_grid": [I], "fiber_window_attn_bwd_slices": [I, I], "fiber_window_attn_colsum_rows": [I, I, I], "fiber_colsum_slabs": [I, I], "fiber_gemm_row_tile": [I, I, I], "fiber_gemm_tn_splits": [I, I, I],
-         "fiber_adamw_chunk": []}
+         "fiber_adamw_chunk": [], "fiber_resample_ksize": [I, I]}
 
 _lib = None
 

@@ -124,6 +124,22 @@ int fiber_ce_bwd_bf16(const void* logits, const long long* labels, const float* 
 int fiber_adamw_chunk(void);
 int fiber_adamw_multi_f32(const long long* table, const long long* numel, const int* chunks, int nchunks, float lr,
                           float weight_decay, float beta1, float beta2, float eps, int step, fiber_stream_t stream);
+/* On-device input pipeline.
+ * fiber_resize_bicubic_norm_u8 replaces transforms/transform.py:10-17 `albef_transform`: torchvision Resize((S,S), BICUBIC) on a
+ * PIL RGB image (= Pillow ImagingResample: anti-aliased separable bicubic, 22-bit fixed-point coefficients, 8-bit rounding after
+ * each pass) + ToTensor + Normalize, bit-identical to PIL.  descs: device array of n records {int64 src; int32 H, W, src_stride,
+ * ksize_h, ksize_v, tmp_off, coef_h_off, coef_v_off} (40 bytes; src = uint8 [H][W][3], ksize_* = fiber_resample_ksize(in, S),
+ * offsets into the int32 workspace `coef` (S*(2+ksize) ints per axis and image) and the byte workspace `tmp` (H*S*3 bytes per
+ * image)); out: fp32 [n,3,S,S]; max_h = tallest source; mean / std: HOST pointers to 3 floats.
+ * fiber_mlm_mask_i64 replaces datamodule_base.py:52 DataCollatorForLanguageModeling.mask_tokens (transformers 4.6.0): tokens with
+ * id outside [special_lo, special_hi] are selected with probability p_select / 2^32; selected tokens become labels (others -100)
+ * and are replaced by mask_id (80 %), a random id < vocab (10 %) or kept (10 %); draws = counter-based hash of (seed, index). */
+int fiber_resample_ksize(int in_size, int out_size);
+int fiber_resize_bicubic_norm_u8(const void* descs, int n, int* coef, void* tmp, float* out, int S, int max_h, const float* mean,
+                                 const float* std, fiber_stream_t stream);
+int fiber_mlm_mask_i64(const long long* ids, long long* ids_mlm, long long* labels, long n, unsigned long long seed,
+                       unsigned p_select, int mask_id, int vocab, int special_lo, int special_hi, fiber_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
