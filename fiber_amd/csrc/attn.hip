@@ -48,7 +48,7 @@ struct AttnP {
   // LDS chunk geometry of this launch (host-chosen, launch_geometry()): tiles per chunk cap, rows of the row-major images
   int tpc_cap, chrows;
   // attention-probability dropout
-  float p_drop; uint64_t seed;
+  float p_drop; uint64_t seed; const uint64_t* seed_base;   // key = seed + *seed_base (seed_base nullable: hipGraph replay)
 };
 
 __device__ __forceinline__ int region_of(int x, int n, int ws, int shift) { return x < n - ws ? 0 : (x < n - shift ? 1 : 2); }
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnP p) {
         psum += e;
         if (p.p_drop > 0.f) {
           const uint64_t idx = (((uint64_t)g * p.H + h) * p.Lq + (qvalid ? i : 0)) * p.Lk + kbase + kt * 16 + gq * 4 + r;
-          e = drop_keep(p.seed, idx, thresh) ? e * inv_keep : 0.f;
+          e = drop_keep(p.seed + (p.seed_base ? *p.seed_base : 0ull), idx, thresh) ? e * inv_keep : 0.f;
         }
         s[kt][r] = e;
       }
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
                 float dpe = dp[r];
                 if (p.p_drop > 0.f) {
                   const uint64_t idx = (((uint64_t)g * p.H + h) * p.Lq + (qvalid ? i : 0)) * p.Lk + kbase + jl;
-                  dpe = drop_keep(p.seed, idx, thresh) ? dpe * inv_keep : 0.f;
+                  dpe = drop_keep(p.seed + (p.seed_base ? *p.seed_base : 0ull), idx, thresh) ? dpe * inv_keep : 0.f;
                 }
                 const float d = qvalid ? pr * (dpe - dlt) : 0.f;
                 ds[u][r] = d;
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnP p) {
               float dpe = dp[r], prd = pr;
               if (p.p_drop > 0.f) {
                 const uint64_t idx = (((uint64_t)g * p.H + h) * p.Lq + ig) * p.Lk + (kvalid ? j : 0);
-                const bool keep = drop_keep(p.seed, idx, thresh);
+                const bool keep = drop_keep(p.seed + (p.seed_base ? *p.seed_base : 0ull), idx, thresh);
                 dpe = keep ? dpe * inv_keep : 0.f;
                 prd = keep ? pr * inv_keep : 0.f;
               }
@@ -791,13 +791,13 @@ extern "C" int fiber_window_attn_bwd_bf16(const void* qkv, const float* bias_tab
 // dropout (0 disables).  D in {32, 64}.  lse fp32 [B*Lq, heads].
 extern "C" int fiber_mha_fwd_bf16(const void* q, const void* k, const void* v, const float* kmask, void* o, float* lse,
                                   int B, int heads, int Lq, int Lk, int D, int ldq, int ldk, int ldv, int ldo,
-                                  float scale, float p_drop, uint64_t seed, hipStream_t stream) {
+                                  float scale, float p_drop, uint64_t seed, const uint64_t* seed_base, hipStream_t stream) {
   if ((D != 32 && D != 64) || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) || Lq <= 0 || Lk <= 0) return FIBER_EINVAL;
   ensure_attrs();
   AttnP p{};
   p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.o = (bf16*)o; p.lse = lse;
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
-  p.H = heads; p.Lq = Lq; p.Lk = Lk; p.G = B; p.scale = scale; p.kmask = kmask; p.p_drop = p_drop; p.seed = seed;
+  p.H = heads; p.Lq = Lq; p.Lk = Lk; p.G = B; p.scale = scale; p.kmask = kmask; p.p_drop = p_drop; p.seed = seed; p.seed_base = seed_base;
   return D == 32 ? launch_fwd<32>(p, stream) : launch_fwd<64>(p, stream);
 }
 
@@ -806,7 +806,7 @@ extern "C" int fiber_mha_bwd_bf16(const void* q, const void* k, const void* v, c
                                   const void* dout, const float* lse, void* dq, void* dk, void* dv, float* delta_ws,
                                   int B, int heads, int Lq, int Lk, int D, int ldq, int ldk, int ldv, int ldo, int lddo,
                                   int lddq, int lddk, int lddv, float scale, float p_drop, uint64_t seed,
-                                  hipStream_t stream) {
+                                  const uint64_t* seed_base, hipStream_t stream) {
   if ((D != 32 && D != 64) || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 7) || (lddo & 7) || (lddq & 3) || (lddk & 3) ||
       (lddv & 3) || Lq <= 0 || Lk <= 0)
     return FIBER_EINVAL;
@@ -815,6 +815,6 @@ extern "C" int fiber_mha_bwd_bf16(const void* q, const void* k, const void* v, c
   p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.o = (bf16*)o; p.lse = (float*)lse;
   p.dout = (const bf16*)dout; p.dq = (bf16*)dq; p.dk = (bf16*)dk; p.dv = (bf16*)dv;
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
-  p.H = heads; p.Lq = Lq; p.Lk = Lk; p.G = B; p.scale = scale; p.kmask = kmask; p.p_drop = p_drop; p.seed = seed;
+  p.H = heads; p.Lq = Lq; p.Lk = Lk; p.G = B; p.scale = scale; p.kmask = kmask; p.p_drop = p_drop; p.seed = seed; p.seed_base = seed_base;
   return D == 32 ? launch_bwd<32>(p, delta_ws, nullptr, nullptr, 1, stream) : launch_bwd<64>(p, delta_ws, nullptr, nullptr, 1, stream);
 }

@@ -197,13 +197,26 @@ __global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restric
 }
 
 __global__ __launch_bounds__(256) void dropout_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, size_t nvec,
-                                                      uint64_t seed, uint32_t thresh, float inv_keep) {
+                                                      uint64_t seed, const uint64_t* __restrict__ seed_base, uint32_t thresh,
+                                                      float inv_keep) {
+  if (seed_base) seed += *seed_base;                   // graph replay: the per-step part of the key lives in device memory
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
     const bf16x8 v = reinterpret_cast<const bf16x8*>(x)[i];
     bf16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = drop_keep(seed, i * 8 + e, thresh) ? f2bf(bf2f(v[e]) * inv_keep) : f2bf(0.f);
     reinterpret_cast<bf16x8*>(y)[i] = o;
+  }
+}
+
+// timm DropPath factor per sample: floor(keep + U[0,1)) / keep, U from the counter-based hash of (key, sample)
+__global__ __launch_bounds__(256) void droppath_scale_kernel(float* __restrict__ out, int n, float keep, uint64_t seed,
+                                                             const uint64_t* __restrict__ seed_base) {
+  if (seed_base) seed += *seed_base;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const float u = (float)hash_u32(seed, (uint64_t)i) * (1.0f / 4294967296.0f);
+    out[i] = floorf(keep + u) / keep;
   }
 }
 
@@ -338,12 +351,24 @@ extern "C" int fiber_fold_rows_f32(const float* part, float* out, int rows, int 
   return FIBER_OK;
 }
 
-// y = keep(seed, i) ? x / (1-p) : 0 ; the same call with dy as x gives the backward.
-extern "C" int fiber_dropout_bf16(const void* x, void* y, long n, float p, uint64_t seed, hipStream_t stream) {
+// y = keep(key, i) ? x / (1-p) : 0 ; the same call with dy as x gives the backward.  key = seed + *seed_base (seed_base:
+// optional DEVICE pointer to the per-step part of the key, so that a captured hipGraph draws new masks on every replay).
+extern "C" int fiber_dropout_bf16(const void* x, void* y, long n, float p, uint64_t seed, const uint64_t* seed_base,
+                                  hipStream_t stream) {
   if (n <= 0) return FIBER_OK;
   if ((n & 7) || p < 0.f || p >= 1.f) return FIBER_EINVAL;
   const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
-  hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, (size_t)n / 8, seed, thresh, 1.f / (1.f - p));
+  hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, (size_t)n / 8, seed, seed_base, thresh, 1.f / (1.f - p));
+  FIBER_CHECK_LAUNCH();
+  return FIBER_OK;
+}
+
+// timm 0.4.12 DropPath per-sample factors (swin_transformer.py:322): out[b] = floor(keep + U_b) / keep, fp32 [n]
+extern "C" int fiber_droppath_scale_f32(float* out, int n, float keep, uint64_t seed, const uint64_t* seed_base,
+                                        hipStream_t stream) {
+  if (n <= 0) return FIBER_OK;
+  if (keep <= 0.f || keep > 1.f) return FIBER_EINVAL;
+  hipLaunchKernelGGL(droppath_scale_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, out, n, keep, seed, seed_base);
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }

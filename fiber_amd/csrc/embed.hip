@@ -16,7 +16,9 @@ __global__ __launch_bounds__(256) void roberta_embed_fwd_kernel(const int64_t* _
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 bf16* __restrict__ y, int* __restrict__ pos_out,
                                                                 float* __restrict__ mean, float* __restrict__ rstd, int S, int C,
-                                                                int pad, float eps, float p_drop, uint64_t seed) {
+                                                                int pad, float eps, float p_drop, uint64_t seed,
+                                                                const uint64_t* __restrict__ seed_base) {
+  if (seed_base) seed += *seed_base;
   __shared__ int spos[1024];
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) {
@@ -85,7 +87,9 @@ __global__ __launch_bounds__(256) void roberta_embed_bwd_kernel(const bf16* __re
                                                                 const float* __restrict__ rstd, float* __restrict__ dword,
                                                                 float* __restrict__ dpos, float* __restrict__ dtype,
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
-                                                                int C, int pad, float p_drop, uint64_t seed) {
+                                                                int C, int pad, float p_drop, uint64_t seed,
+                                                                const uint64_t* __restrict__ seed_base) {
+  if (seed_base) seed += *seed_base;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = C >> 2;
   const uint32_t thresh = (uint32_t)((double)p_drop * 4294967296.0);
@@ -182,11 +186,12 @@ __global__ __launch_bounds__(256) void im2col4_kernel(const float* __restrict__ 
 // ids int64 [B,S]; tables fp32; y bf16 [B*S, C]; pos_out int32 [B*S]; mean/rstd fp32 [B*S].  C % 4 == 0, C <= 2048, S <= 1024
 extern "C" int fiber_roberta_embed_fwd(const int64_t* ids, const float* word, const float* pos_tab, const float* type_tab,
                                        const float* gamma, const float* beta, void* y, int* pos_out, float* mean, float* rstd,
-                                       int B, int S, int C, int pad, float eps, float p_drop, uint64_t seed, hipStream_t stream) {
+                                       int B, int S, int C, int pad, float eps, float p_drop, uint64_t seed, const uint64_t* seed_base,
+                                       hipStream_t stream) {
   if (B <= 0) return FIBER_OK;
   if ((C & 3) || S > 1024 || C > 2048) return FIBER_EINVAL;
   const int nv = cdiv(C >> 2, 64);
-#define L(NV) hipLaunchKernelGGL((roberta_embed_fwd_kernel<NV>), dim3(B), dim3(256), 0, stream, ids, word, pos_tab, type_tab, gamma, beta, (bf16*)y, pos_out, mean, rstd, S, C, pad, eps, p_drop, seed)
+#define L(NV) hipLaunchKernelGGL((roberta_embed_fwd_kernel<NV>), dim3(B), dim3(256), 0, stream, ids, word, pos_tab, type_tab, gamma, beta, (bf16*)y, pos_out, mean, rstd, S, C, pad, eps, p_drop, seed, seed_base)
   if (nv <= 1) L(1); else if (nv <= 2) L(2); else if (nv <= 4) L(4); else L(8);
 #undef L
   FIBER_CHECK_LAUNCH();
@@ -197,13 +202,13 @@ extern "C" int fiber_roberta_embed_fwd(const int64_t* ids, const float* word, co
 extern "C" int fiber_roberta_embed_bwd(const void* dy, const int64_t* ids, const int* pos, const float* word, const float* pos_tab,
                                        const float* type_tab, const float* gamma, const float* mean, const float* rstd,
                                        float* dword, float* dpos, float* dtype, float* dgamma, float* dbeta, int B, int S, int C,
-                                       int pad, float p_drop, uint64_t seed, hipStream_t stream) {
+                                       int pad, float p_drop, uint64_t seed, const uint64_t* seed_base, hipStream_t stream) {
   if (B <= 0) return FIBER_OK;
   if ((C & 3) || C > 2048) return FIBER_EINVAL;
   const int rows = B * S, nv = cdiv(C >> 2, 64);
   int grid = cdiv(rows, 4 * 4);
   grid = grid < 1 ? 1 : (grid > 256 ? 256 : grid);
-#define L(NV) hipLaunchKernelGGL((roberta_embed_bwd_kernel<NV>), dim3(grid), dim3(256), 0, stream, (const bf16*)dy, ids, pos, word, pos_tab, type_tab, gamma, mean, rstd, dword, dpos, dtype, dgamma, dbeta, rows, C, pad, p_drop, seed)
+#define L(NV) hipLaunchKernelGGL((roberta_embed_bwd_kernel<NV>), dim3(grid), dim3(256), 0, stream, (const bf16*)dy, ids, pos, word, pos_tab, type_tab, gamma, mean, rstd, dword, dpos, dtype, dgamma, dbeta, rows, C, pad, p_drop, seed, seed_base)
   if (nv <= 1) L(1); else if (nv <= 2) L(2); else if (nv <= 4) L(4); else L(8);
 #undef L
   FIBER_CHECK_LAUNCH();

@@ -20,6 +20,7 @@ struct AdamArgs {
   const long long* numel;     // [n]
   const int* chunks;          // [nchunks][2] = (tensor index, chunk index within the tensor)
   float lr, wd, b1, b2, eps, step_size;   // step_size = lr * sqrt(1 - b2^t) / (1 - b1^t)
+  const float* hyper;                     // optional DEVICE {lr, step_size}: overrides the two by-value fields (hipGraph replay)
 };
 
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamArgs& a) {
@@ -30,6 +31,7 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, con
 }
 
 __global__ __launch_bounds__(256) void adamw_multi_kernel(AdamArgs a) {
+  if (a.hyper) { a.lr = a.hyper[0]; a.step_size = a.hyper[1]; }
   const int t = a.chunks[2 * blockIdx.x], c = a.chunks[2 * blockIdx.x + 1];
   float* p = reinterpret_cast<float*>(a.table[5 * t + 0]);
   const float* g = reinterpret_cast<const float*>(a.table[5 * t + 1]);
@@ -84,12 +86,15 @@ extern "C" int fiber_adamw_chunk(void) { return CHUNK; }
 // One AdamW step for every tensor of a parameter group.  table: int64[n*5] device pointers (param, grad, exp_avg,
 // exp_avg_sq, bf16 working copy or 0), numel: int64[n], chunks: int32[nchunks*2] (tensor, chunk) pairs covering each tensor
 // in pieces of fiber_adamw_chunk() elements -- all three arrays in device memory.  step >= 1 is the step being taken.
+// hyper (nullable): DEVICE float[2] = {lr, lr * sqrt(1 - beta2^step) / (1 - beta1^step)} read by the kernel instead of the
+// by-value lr / step, so that a captured hipGraph follows the learning-rate schedule (the host refreshes it before a replay).
 extern "C" int fiber_adamw_multi_f32(const long long* table, const long long* numel, const int* chunks, int nchunks, float lr,
-                                     float weight_decay, float beta1, float beta2, float eps, int step, hipStream_t stream) {
+                                     float weight_decay, float beta1, float beta2, float eps, int step, const float* hyper,
+                                     hipStream_t stream) {
   if (nchunks <= 0) return FIBER_OK;
   if (step < 1) return FIBER_EINVAL;
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-  AdamArgs a{table, numel, chunks, lr, weight_decay, beta1, beta2, eps, (float)((double)lr * sqrt(bc2) / bc1)};
+  AdamArgs a{table, numel, chunks, lr, weight_decay, beta1, beta2, eps, (float)((double)lr * sqrt(bc2) / bc1), hyper};
   hipLaunchKernelGGL(adamw_multi_kernel, dim3(nchunks), dim3(256), 0, stream, a);
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;

@@ -23,10 +23,10 @@ SIGNATURES = {
     "fiber_patch_merge_ln_bwd_bf16": [P, P, P, P, P, P, P, P, P, I, I, I, I],
     "fiber_window_attn_fwd_bf16": [P, P, P, P, I, I, I, I, I, I, I, I],
     "fiber_window_attn_bwd_bf16": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I],
-    "fiber_mha_fwd_bf16": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, F, U64],
-    "fiber_mha_bwd_bf16": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, F, F, U64],
-    "fiber_roberta_embed_fwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, U64],
-    "fiber_roberta_embed_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, U64],
+    "fiber_mha_fwd_bf16": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, F, U64, P],
+    "fiber_mha_bwd_bf16": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, F, F, U64, P],
+    "fiber_roberta_embed_fwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, U64, P],
+    "fiber_roberta_embed_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, U64, P],
     "fiber_im2col_patch4": [P, P, I, I, I],
     "fiber_gelu_bwd_bf16": [P, P, P, L],
     "fiber_gelu_bwd_colsum_bf16": [P, P, P, P, P, I, I],
@@ -34,12 +34,13 @@ SIGNATURES = {
     "fiber_dot_bf16": [P, P, P, L],
     "fiber_colsum_bf16": [P, P, P, I, I, I],
     "fiber_fold_rows_f32": [P, P, I, I],
-    "fiber_dropout_bf16": [P, P, L, F, U64],
+    "fiber_dropout_bf16": [P, P, L, F, U64, P],
+    "fiber_droppath_scale_f32": [P, I, F, U64, P],
     "fiber_rowscale_add_bf16": [P, P, P, P, L, L],
     "fiber_rowscale_colsum_bf16": [P, P, P, P, P, I, I, I],
     "fiber_ce_fwd_bf16": [P, P, P, P, I, I, L],
     "fiber_ce_bwd_bf16": [P, P, P, P, P, I, I, L],
-    "fiber_adamw_multi_f32": [P, P, P, I, F, F, F, F, F, I],
+    "fiber_adamw_multi_f32": [P, P, P, I, F, F, F, F, F, I, P],
     "fiber_resize_bicubic_norm_u8": [P, I, P, P, P, I, I, P, P],
     "fiber_mlm_mask_i64": [P, P, P, L, U64, C.c_uint, I, I, I, I],
 }

@@ -178,6 +178,9 @@ _lib_gemm_last = {"event": None, "stream": None}
 
 class lib_gemm:
     def __enter__(self):
+        self.capturing = torch.cuda.is_current_stream_capturing()
+        if self.capturing:                                   # one stream by construction: nothing to order
+            return self
         self.cur = torch.cuda.current_stream()
         last = _lib_gemm_last
         if last["event"] is not None and last["stream"] != self.cur.cuda_stream:
@@ -185,6 +188,8 @@ class lib_gemm:
         return self
 
     def __exit__(self, *exc):
+        if self.capturing:
+            return False
         ev = torch.cuda.Event()
         ev.record(self.cur)
         _lib_gemm_last["event"], _lib_gemm_last["stream"] = ev, self.cur.cuda_stream
@@ -646,15 +651,15 @@ class _MHA(torch.autograd.Function):
         o = torch.empty((q.shape[0], heads * D), dtype=BF16, device=q.device)
         lse = torch.empty((q.shape[0], heads), dtype=torch.float32, device=q.device)
         lib.call("fiber_mha_fwd_bf16", lib.ptr(q), lib.ptr(k), lib.ptr(v), lib.ptr(kmask), lib.ptr(o), lib.ptr(lse), B, heads, Lq, Lk, D,
-                 _ld(q), _ld(k), _ld(v), _ld(o), scale, p_drop, seed)
+                 _ld(q), _ld(k), _ld(v), _ld(o), scale, p_drop, seed, seed_base_ptr())
         ctx.save_for_backward(q, k, v, kmask, o, lse)
-        ctx.cfg = (B, heads, Lq, Lk, D, scale, p_drop, seed)
+        ctx.cfg = (B, heads, Lq, Lk, D, scale, p_drop, seed, seed_base_ptr())
         return o
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, kmask, o, lse = ctx.saved_tensors
-        B, heads, Lq, Lk, D, scale, p_drop, seed = ctx.cfg
+        B, heads, Lq, Lk, D, scale, p_drop, seed, base = ctx.cfg
         do = _c(do)
         dq = torch.empty((q.shape[0], heads * D), dtype=BF16, device=q.device)
         dk = torch.empty((k.shape[0], heads * D), dtype=BF16, device=q.device)
@@ -662,7 +667,7 @@ class _MHA(torch.autograd.Function):
         delta = torch.empty((q.shape[0], heads), dtype=torch.float32, device=q.device)
         lib.call("fiber_mha_bwd_bf16", lib.ptr(q), lib.ptr(k), lib.ptr(v), lib.ptr(kmask), lib.ptr(o), lib.ptr(do), lib.ptr(lse),
                  lib.ptr(dq), lib.ptr(dk), lib.ptr(dv), lib.ptr(delta), B, heads, Lq, Lk, D, _ld(q), _ld(k), _ld(v), _ld(o), _ld(do),
-                 _ld(dq), _ld(dk), _ld(dv), scale, p_drop, seed)
+                 _ld(dq), _ld(dk), _ld(dv), scale, p_drop, seed, base)
         return dq, dk, dv, None, None, None, None, None, None
 
 
@@ -722,8 +727,9 @@ class _Dropout(torch.autograd.Function):
     def forward(ctx, x, p, seed):
         x = _c(x)
         y = torch.empty_like(x)
-        lib.call("fiber_dropout_bf16", lib.ptr(x), lib.ptr(y), x.numel(), p, seed)
-        ctx.cfg = (p, seed)
+        base = seed_base_ptr()
+        lib.call("fiber_dropout_bf16", lib.ptr(x), lib.ptr(y), x.numel(), p, seed, base)
+        ctx.cfg = (p, seed, base)
         return y
 
     @staticmethod
@@ -734,12 +740,34 @@ class _Dropout(torch.autograd.Function):
         return dx, None, None
 
 
-_seed_state = {"seed": 0x5EED, "ctr": 0, "step": None}
+# Dropout / DropPath keys.  key = BASE(seed, step) + call-site counter, where the counter restarts at every training step:
+#   eager:  the whole key is passed to the kernels by value;
+#   graph:  (enable_graph_rng) BASE lives in a device int64 scalar that set_rng_step() rewrites before every replay, the
+#           kernels receive only the counter by value + the pointer -- a captured step draws new masks on every replay and
+#           the SAME masks an eager run of that step would draw.
+_seed_state = {"seed": 0x5EED, "ctr": 0, "step": None, "base_dev": None}
+_M64 = (1 << 64) - 1
+
+
+def _base_value():
+    hi, step = _seed_state["seed"], _seed_state["step"]
+    if step is None:
+        return (hi << 32) & _M64
+    hi = (hi ^ ((int(step) >> 12) * 0x9E3779B1)) & 0xFFFFFFFF
+    return ((hi << 32) | ((int(step) & 0xFFF) << 20)) & _M64
+
+
+def _write_base_dev():
+    t = _seed_state["base_dev"]
+    if t is not None:
+        v = _base_value()
+        t.fill_(v - (1 << 64) if v >= (1 << 63) else v)    # the bit pattern, through torch's signed int64
 
 
 def manual_seed(seed):
     """Seed of the dropout / DropPath streams (lightning.seed_everything and the Trainer call this with config["seed"] + rank)."""
     _seed_state["seed"], _seed_state["ctr"], _seed_state["step"] = int(seed) & 0xFFFFFFFF, 0, None
+    _write_base_dev()
 
 
 def set_rng_step(step):
@@ -747,16 +775,34 @@ def set_rng_step(step):
     2^20 keys owned by that step, so a run resumed at step s draws the masks of step s, not those of step 0."""
     if _seed_state["step"] != step:
         _seed_state["step"] = step
-        _seed_state["ctr"] = (int(step) & 0xFFF) << 20
+        _seed_state["ctr"] = 0
+        if _seed_state["base_dev"] is not None and not torch.cuda.is_current_stream_capturing():
+            _write_base_dev()
+
+
+def enable_graph_rng(device):
+    """Keep the per-step part of every dropout key in device memory (see above); returns the int64 scalar."""
+    if _seed_state["base_dev"] is None or _seed_state["base_dev"].device != torch.device(device):
+        _seed_state["base_dev"] = torch.zeros((), dtype=torch.int64, device=device)
+    _write_base_dev()
+    return _seed_state["base_dev"]
+
+
+def disable_graph_rng():
+    _seed_state["base_dev"] = None
+
+
+def seed_base_ptr():
+    t = _seed_state["base_dev"]
+    return None if t is None else t.data_ptr()
 
 
 def next_seed():
-    """A fresh 64-bit dropout key per call site (counter-based: forward and backward share it through ctx)."""
+    """The by-value part of a fresh 64-bit dropout key for one call site (forward and backward share it through ctx)."""
     _seed_state["ctr"] += 1
-    hi = _seed_state["seed"]
-    if _seed_state["step"] is not None:
-        hi = (hi ^ ((int(_seed_state["step"]) >> 12) * 0x9E3779B1)) & 0xFFFFFFFF
-    return (hi << 32) | (_seed_state["ctr"] & 0xFFFFFFFF)
+    if _seed_state["base_dev"] is not None:
+        return _seed_state["ctr"]
+    return (_base_value() + _seed_state["ctr"]) & _M64
 
 
 def dropout(x, p, training):
@@ -788,11 +834,11 @@ class _RowScaleAdd(torch.autograd.Function):
 
 
 def drop_path_scale(batch, p, device):
-    """timm 0.4.12 DropPath factor per sample: floor(keep + U[0,1)) / keep (fp32 [batch])."""
-    keep = 1.0 - p
-    g = torch.Generator(device=device)
-    g.manual_seed(next_seed() & 0x7FFFFFFFFFFFFFFF)
-    return (torch.floor(keep + torch.rand(batch, device=device, generator=g)) / keep).float()
+    """timm 0.4.12 DropPath factor per sample: floor(keep + U[0,1)) / keep (fp32 [batch]), U from the path's counter-based
+    key stream (csrc/elementwise.hip) -- no host generator, so the draw is capturable in a hipGraph."""
+    out = torch.empty(batch, dtype=torch.float32, device=device)
+    lib.call("fiber_droppath_scale_f32", lib.ptr(out), batch, 1.0 - p, next_seed(), seed_base_ptr())
+    return out
 
 
 def rowscale_add(resid, x, scale):
@@ -817,22 +863,22 @@ class _RobertaEmbed(torch.autograd.Function):
         mean = torch.empty(B * S, dtype=torch.float32, device=ids.device)
         rstd = torch.empty_like(mean)
         lib.call("fiber_roberta_embed_fwd", lib.ptr(ids), lib.ptr(word), lib.ptr(pos_tab), lib.ptr(type_tab), lib.ptr(gamma), lib.ptr(beta),
-                 lib.ptr(y), lib.ptr(pos), lib.ptr(mean), lib.ptr(rstd), B, S, C, pad, eps, p_drop, seed)
+                 lib.ptr(y), lib.ptr(pos), lib.ptr(mean), lib.ptr(rstd), B, S, C, pad, eps, p_drop, seed, seed_base_ptr())
         ctx.save_for_backward(ids, pos, word, pos_tab, type_tab, gamma, mean, rstd)
-        ctx.cfg = (B, S, C, pad, p_drop, seed)
+        ctx.cfg = (B, S, C, pad, p_drop, seed, seed_base_ptr())
         return y
 
     @staticmethod
     def backward(ctx, dy):
         ids, pos, word, pos_tab, type_tab, gamma, mean, rstd = ctx.saved_tensors
-        B, S, C, pad, p_drop, seed = ctx.cfg
+        B, S, C, pad, p_drop, seed, base = ctx.cfg
         dy = _c(dy)
         dword, dpos, dtype = torch.zeros_like(word), torch.zeros_like(pos_tab), torch.zeros_like(type_tab)
         dg = torch.zeros(C, dtype=torch.float32, device=dy.device)
         db = torch.zeros_like(dg)
         lib.call("fiber_roberta_embed_bwd", lib.ptr(dy), lib.ptr(ids), lib.ptr(pos), lib.ptr(word), lib.ptr(pos_tab), lib.ptr(type_tab),
                  lib.ptr(gamma), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dword), lib.ptr(dpos), lib.ptr(dtype), lib.ptr(dg), lib.ptr(db),
-                 B, S, C, pad, p_drop, seed)
+                 B, S, C, pad, p_drop, seed, base)
         return None, dword, dpos, dtype, dg, db, None, None, None, None
 
 

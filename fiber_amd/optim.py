@@ -50,6 +50,36 @@ class FiberAdamW(torch.optim.Optimizer):
         self._chunk = None
         self._tables = {}                       # group index -> cached device tables
         self.rebuilds = 0                       # how often a table had to be rebuilt (diagnostics)
+        self._hyper = None                      # graph mode: (device float [groups, 2], pinned host copy)
+
+    # ---- hipGraph support ---------------------------------------------------------------------------------------------
+    # A captured step bakes every by-value kernel argument.  In graph mode the two arguments that change per step -- the
+    # group's learning rate and its bias-corrected step size -- live in device memory; `prepare_replay()` advances the step
+    # counters on the host, recomputes them from the (scheduler-updated) param_groups and uploads them ahead of the replay.
+    def enable_graph_mode(self):
+        if not self._tables:
+            raise lib.FiberHipError("FiberAdamW.enable_graph_mode: take one eager step first (device tables not built yet)")
+        dev = next(p for g in self.param_groups for p in g["params"]).device
+        n = len(self.param_groups)
+        self._hyper = (torch.zeros((n, 2), dtype=torch.float32, device=dev), torch.zeros((n, 2), dtype=torch.float32).pin_memory())
+
+    def disable_graph_mode(self):
+        self._hyper = None
+
+    def prepare_replay(self):
+        dev_t, host_t = self._hyper
+        for gi, group in enumerate(self.param_groups):
+            tab = self._tables.get(gi)
+            if tab is None:
+                continue
+            step = tab["states"][0]["step"] + 1
+            for st in tab["states"]:
+                st["step"] = step
+            b1, b2 = group["betas"]
+            lr = float(group["lr"])
+            host_t[gi, 0] = lr
+            host_t[gi, 1] = lr * (1.0 - b2 ** step) ** 0.5 / (1.0 - b1 ** step)
+        dev_t.copy_(host_t, non_blocking=True)
 
     def load_state_dict(self, state_dict):
         """Loaded moments and step counters live in NEW tensors / dicts: drop every cached device table."""
@@ -61,6 +91,7 @@ class FiberAdamW(torch.optim.Optimizer):
         self._tables = {}
         self.__dict__.setdefault("_chunk", None)
         self.__dict__.setdefault("rebuilds", 0)
+        self.__dict__.setdefault("_hyper", None)
 
     def _state_of(self, p):
         st = self.state[p]
@@ -122,12 +153,17 @@ class FiberAdamW(torch.optim.Optimizer):
                 host[:, 4] = torch.tensor(key[2], dtype=torch.int64)
                 tab["table"].copy_(host, non_blocking=True)
                 tab["key"] = key
-            step = tab["states"][0]["step"] + 1
-            for st in tab["states"]:
-                st["step"] = step
             b1, b2 = group["betas"]
+            if self._hyper is None:
+                step = tab["states"][0]["step"] + 1
+                for st in tab["states"]:
+                    st["step"] = step
+                hyper = None
+            else:                                  # graph mode: prepare_replay() owns the counters and the device scalars
+                step = max(1, tab["states"][0]["step"])
+                hyper = self._hyper[0][gi].data_ptr()
             lib.call("fiber_adamw_multi_f32", lib.ptr(tab["table"]), lib.ptr(tab["numel"]), lib.ptr(tab["chunks"]), tab["n"],
-                     float(group["lr"]), float(group["weight_decay"]), float(b1), float(b2), float(group["eps"]), int(step))
+                     float(group["lr"]), float(group["weight_decay"]), float(b1), float(b2), float(group["eps"]), int(step), hyper)
             ops.restamp_bf16_copies(plist, bump=not bumped)
             bumped = True
         return loss

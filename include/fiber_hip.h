@@ -71,23 +71,26 @@ int fiber_window_attn_bwd_bf16(const void* qkv, const float* bias_table, const v
 
 /* Generic MHA core softmax(q.k^T*scale + kmask).v with optional attention-prob dropout: RoBERTa self-attention
  * (roberta.py:256-326), image->text cross-attention (swin_transformer.py:226-256) and text->image cross-attention
- * (roberta.py:272-276).  D in {32,64}. */
+ * (roberta.py:272-276).  D in {32,64}.
+ * Every dropout-capable entry point takes the 64-bit key as `seed` + an optional DEVICE pointer `seed_base` (key = seed +
+ * *seed_base; NULL = seed alone): a captured hipGraph keeps the per-call-site part by value and re-reads the per-step part from
+ * device memory on every replay. */
 int fiber_mha_fwd_bf16(const void* q, const void* k, const void* v, const float* kmask, void* o, float* lse, int B, int heads,
                        int Lq, int Lk, int D, int ldq, int ldk, int ldv, int ldo, float scale, float p_drop, uint64_t seed,
-                       fiber_stream_t stream);
+                       const uint64_t* seed_base, fiber_stream_t stream);
 int fiber_mha_bwd_bf16(const void* q, const void* k, const void* v, const float* kmask, const void* o, const void* dout,
                        const float* lse, void* dq, void* dk, void* dv, float* delta_ws, int B, int heads, int Lq, int Lk, int D,
                        int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk, int lddv, float scale, float p_drop,
-                       uint64_t seed, fiber_stream_t stream);
+                       uint64_t seed, const uint64_t* seed_base, fiber_stream_t stream);
 
 /* RobertaEmbeddings.forward (roberta.py:169-199, 877-888) and its backward (scatter-add into fp32 gradient tables) */
 int fiber_roberta_embed_fwd(const int64_t* ids, const float* word, const float* pos_tab, const float* type_tab,
                             const float* gamma, const float* beta, void* y, int* pos_out, float* mean, float* rstd, int B, int S,
-                            int C, int pad, float eps, float p_drop, uint64_t seed, fiber_stream_t stream);
+                            int C, int pad, float eps, float p_drop, uint64_t seed, const uint64_t* seed_base, fiber_stream_t stream);
 int fiber_roberta_embed_bwd(const void* dy, const int64_t* ids, const int* pos, const float* word, const float* pos_tab,
                             const float* type_tab, const float* gamma, const float* mean, const float* rstd, float* dword,
                             float* dpos, float* dtype, float* dgamma, float* dbeta, int B, int S, int C, int pad, float p_drop,
-                            uint64_t seed, fiber_stream_t stream);
+                            uint64_t seed, const uint64_t* seed_base, fiber_stream_t stream);
 
 /* timm PatchEmbed Conv2d(3->C,k=4,s=4) as im2col (K=48 ordered [c][kh][kw], zero padded to 64) feeding fiber_gemm_nt_bf16 */
 int fiber_im2col_patch4(const float* img, void* cols, int B, int H, int W, fiber_stream_t stream);
@@ -101,7 +104,9 @@ int fiber_dot_bf16(const void* a, const void* b, float* out, long n, fiber_strea
 int fiber_colsum_slabs(int M, int N); /* workspace = slabs*N floats when slabs > 1 */
 int fiber_colsum_bf16(const void* x, float* out, float* workspace, int M, int N, int ld, fiber_stream_t stream);
 int fiber_fold_rows_f32(const float* part, float* out, int rows, int N, fiber_stream_t stream);
-int fiber_dropout_bf16(const void* x, void* y, long n, float p, uint64_t seed, fiber_stream_t stream);
+int fiber_dropout_bf16(const void* x, void* y, long n, float p, uint64_t seed, const uint64_t* seed_base, fiber_stream_t stream);
+/* timm 0.4.12 DropPath factors (swin_transformer.py:322,390-391): out[b] = floor(keep + U_b) / keep, fp32 [n] */
+int fiber_droppath_scale_f32(float* out, int n, float keep, uint64_t seed, const uint64_t* seed_base, fiber_stream_t stream);
 int fiber_rowscale_add_bf16(const void* r, const void* x, const float* scale, void* out, long n, long per_sample,
                             fiber_stream_t stream);
 /* y = scale[row / rows_per_sample] * x (DropPath backward, swin_transformer.py:390-391) and db = column sums of y (bias
@@ -120,10 +125,12 @@ int fiber_ce_bwd_bf16(const void* logits, const long long* labels, const float* 
 /* AdamW step of one parameter group in one launch (caller side of the path: transformers 4.6.0 AdamW(correct_bias=True) as
  * configured by fiber_utils.set_schedule, fiber_utils.py:248-252), also refreshing the bf16 working copies of the weights.
  * table: int64[n*5] device pointers (param fp32, grad fp32, exp_avg, exp_avg_sq, bf16 copy or 0); numel: int64[n];
- * chunks: int32[nchunks*2] (tensor, chunk) pairs of fiber_adamw_chunk() elements; all three in device memory; step >= 1. */
+ * chunks: int32[nchunks*2] (tensor, chunk) pairs of fiber_adamw_chunk() elements; all three in device memory; step >= 1.
+ * hyper (nullable): device float[2] {lr, lr*sqrt(1-beta2^step)/(1-beta1^step)} read instead of the by-value lr / step (hipGraph). */
 int fiber_adamw_chunk(void);
 int fiber_adamw_multi_f32(const long long* table, const long long* numel, const int* chunks, int nchunks, float lr,
-                          float weight_decay, float beta1, float beta2, float eps, int step, fiber_stream_t stream);
+                          float weight_decay, float beta1, float beta2, float eps, int step, const float* hyper,
+                          fiber_stream_t stream);
 /* On-device input pipeline.
  * fiber_resize_bicubic_norm_u8 replaces transforms/transform.py:10-17 `albef_transform`: torchvision Resize((S,S), BICUBIC) on a
  * PIL RGB image (= Pillow ImagingResample: anti-aliased separable bicubic, 22-bit fixed-point coefficients, 8-bit rounding after
