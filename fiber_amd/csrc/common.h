@@ -82,11 +82,11 @@ __device__ __forceinline__ bf16x8 gelu8(bf16x8 v, float scale) {
   return o;
 }
 // dy * gelu'(h)
-__device__ __forceinline__ bf16x8 gelu_grad_mul8(bf16x8 dy, bf16x8 h) {
+__device__ __forceinline__ bf16x8 gelu_grad_mul8(bf16x8 dy, bf16x8 h, float scale = 1.f) {
   bf16x8 o;
 #pragma unroll
   for (int e = 0; e < 8; e += 2) {
-    const f32x2 g = gelu_grad2(f32x2{bf2f(h[e]), bf2f(h[e + 1])}) * f32x2{bf2f(dy[e]), bf2f(dy[e + 1])};
+    const f32x2 g = gelu_grad2(f32x2{bf2f(h[e]), bf2f(h[e + 1])}) * f32x2{bf2f(dy[e]), bf2f(dy[e + 1])} * scale;
     o[e] = f2bf(g.x); o[e + 1] = f2bf(g.y);
   }
   return o;

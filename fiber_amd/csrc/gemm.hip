@@ -667,7 +667,7 @@ extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bia
   const long wide = (long)cdiv(M, 256) * cdiv(N, 256);
   const int mode = act & 0xff;
   if ((mode == 2 || colpart) && !((K % 64 == 0) && (N % 8 == 0) && (ldy % 8 == 0))) return FIBER_EINVAL;   // LDS-DMA kernels only
-  if (mode == 2 && (residual || rowscale)) return FIBER_EINVAL;
+  if (mode == 2 && residual) return FIBER_EINVAL;
   if (colpart && mode != 2 && !(act & 0x200)) return FIBER_EINVAL;
   const bool v2 = (K % 64 == 0) && (N % 8 == 0) && (ldy % 8 == 0) && (!residual || ldr % 8 == 0) && !getenv("FIBER_GEMM_V1");
   // Tile choice.  256x256 (K step 32, two wave groups half a tile apart) whenever N is a multiple of 256 and there are
@@ -698,7 +698,7 @@ extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bia
   }
   if (shape == 4) hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), dim3((unsigned)big), dim3(256), 0, stream, a);
   else if (shape == 5) hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), dim3((unsigned)small), dim3(256), 0, stream, a);
-  else if (mode == 2) FIBER_LAUNCH_EPI(2, false, false);
+  else if (mode == 2) { if (rowscale) FIBER_LAUNCH_EPI(2, false, true); else FIBER_LAUNCH_EPI(2, false, false); }
   else if (mode == 1 && residual) { if (rowscale) FIBER_LAUNCH_EPI(1, true, true); else FIBER_LAUNCH_EPI(1, true, false); }
   else if (mode == 1) { if (rowscale) FIBER_LAUNCH_EPI(1, false, true); else FIBER_LAUNCH_EPI(1, false, false); }
   else if (residual && rowscale) FIBER_LAUNCH_EPI(0, true, true);

@@ -23,7 +23,8 @@ __device__ __forceinline__ int swz(int row, int chunk) { return (row * 8 + (chun
 // tools/gemm_dbg.py) -- as much as the tile's MFMAs at K = 512.
 //   EPI 0: Y = rowscale * (acc + bias) + R          (HAS_RS / HAS_R)
 //   EPI 1: Ypre = acc + bias (optional);  Y = rowscale * gelu(bf16(acc + bias))
-//   EPI 2: Y = acc * gelu'(aux);  optional per-row-tile column sums of Y (colpart)
+//   EPI 2: Y = rowscale * acc * gelu'(aux);  optional per-row-tile column sums of Y (colpart)   (HAS_RS: the DropPath factor
+//          of the branch whose backward this is -- (s dY) W2^T = s (dY W2^T), so the scale rides in the epilogue)
 //   FULL:  the tile lies entirely inside [M, N] (no row / column predicates)
 // Y is read by the next kernel and is stored normally: marking it non-temporal made the isolated GEMM faster (fc1 845 ->
 // 772 us at M = 295k, less L2 pollution) but the whole step slower (670 -> 658 images/s, the consumer then misses the
@@ -72,14 +73,14 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x16 (&acc)[B
     const int mbase = tm0 + h * HM + erow;              // this thread's first output row in the round
     // side rows / DropPath scales are requested BEFORE the staging pass so their latency hides behind it
     bf16x8 side[SIDE ? NPH : 1];
-    float prs[(EPI == 1 && HAS_RS) ? NPH : 1];
+    float prs[((EPI == 1 || EPI == 2) && HAS_RS) ? NPH : 1];
     if constexpr (SIDE) {
       const bf16* sp = sidep + (size_t)mbase * sideld + n_out;
 #pragma unroll
       for (int pp = 0; pp < NPH; ++pp)
         if (FULL || (mbase + pp * RPP < a.M && col_ok)) side[pp] = *reinterpret_cast<const bf16x8*>(sp + (size_t)pp * RPP * sideld);
     }
-    if constexpr (EPI == 1 && HAS_RS) {
+    if constexpr ((EPI == 1 || EPI == 2) && HAS_RS) {
 #pragma unroll
       for (int pp = 0; pp < NPH; ++pp) prs[pp] = a.rowscale[min(mbase + pp * RPP, a.M - 1) / a.rows_per_sample];
     }
@@ -127,7 +128,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x16 (&acc)[B
             if (prep) st_stream(reinterpret_cast<bf16x8*>(prep + pp * ystep), v);
             v = gelu8(v, HAS_RS ? prs[pp] : 1.f);
           } else if constexpr (EPI == 2) {
-            v = gelu_grad_mul8(v, side[pp]);
+            v = gelu_grad_mul8(v, side[pp], HAS_RS ? prs[pp] : 1.f);
           }
           if constexpr (HAS_R) {
 #pragma unroll

@@ -25,7 +25,10 @@
 //    SIMD one wave feeds the matrix pipe while its partner reads fragments.  A 128x128 / 4-wave instance covers the narrow
 //    weights (stage-0 / stage-1 linears, patch embedding, test configurations);
 //  * the bias gradient: waves of the first K-column tile add their dY fragments up with v_dot2_f32_bf16 against (1, 1) --
-//    two VALU issues per MFMA gap -- so no separate pass ever streams dY for its column sums.
+//    two VALU issues per MFMA gap -- so no separate pass ever streams dY for its column sums;
+//  * DropPath backward (timm 0.4.12, swin_transformer.py:390-391): the branch gradient is s_b dY with a per-sample factor
+//    s_b in {0, 1/keep}.  Instead of a pass that writes s_b dY, the kernel skips the K tiles of dropped samples (row_mask)
+//    and multiplies the result by 1/keep (scale): dW = (1/keep) sum over kept samples of dY^T X.
 #include <stdlib.h>
 
 #include "common.h"
@@ -39,6 +42,9 @@ struct TnArgs {
   float* cs;          // slabs [S][N] or db itself; nullable
   int M, N, K, lda, ldb;
   int S, tiles_n, tiles_k, kt_per_split, nk_total;
+  const float* row_mask;   // optional fp32 [M / rows_per_sample]: rows of samples whose entry is 0 do not contribute
+  int rows_per_sample;     // (a multiple of the K-tile depth: a K tile never straddles two samples)
+  float scale;             // the result (and the bias sums) are multiplied by this
 };
 
 __device__ __attribute__((aligned(16))) unsigned g_tn_zeros[128];   // 512 zero bytes: the source of dY rows past M
@@ -151,6 +157,8 @@ __global__ __launch_bounds__(TS * 2) void gemm_tn_kernel(TnArgs a) {
 #pragma unroll
   for (int t = 0; t < TA; ++t) csa[t] = 0.f;
   const bool do_cs = a.cs != nullptr && tk == 0 && wb == 0;       // wave-uniform
+  // K tile kt belongs to sample (m0 + kt*BKM) / rows_per_sample; its MFMAs are skipped when that sample was dropped
+  auto kept = [&](int kt) { return a.row_mask == nullptr || a.row_mask[(m0 + kt * BKM) / a.rows_per_sample] != 0.f; };
 
   bf16x8 fa[2][TA], fb[2][TB];
   auto load_phase = [&](int kt, int sub) {
@@ -195,14 +203,15 @@ __global__ __launch_bounds__(TS * 2) void gemm_tn_kernel(TnArgs a) {
     phase_barrier(true);
     if (wa == 1) phase_barrier(false);                   // group 1 runs one phase behind (see gemm.hip, wide kernel)
     for (int kt = 0; kt < nk; ++kt) {
+      const bool inc = kept(kt);
       load_phase(kt, 0);
       if (kt + 1 < nk) dma(kt + 1);
       phase_barrier(false);
-      math_phase();
+      if (inc) math_phase();
       phase_barrier(false);
       load_phase(kt, 1);
       phase_barrier(wa == 1);
-      math_phase();
+      if (inc) math_phase();
       phase_barrier(wa == 0);
     }
     if (wa == 0) phase_barrier(false);
@@ -219,10 +228,12 @@ __global__ __launch_bounds__(TS * 2) void gemm_tn_kernel(TnArgs a) {
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       if (kt + NS - 1 < nk) dma(kt + NS - 1);             // into the stage tile kt-1 just vacated
+      if (kept(kt)) {
 #pragma unroll
-      for (int sub = 0; sub < NSUB; ++sub) {
-        load_phase(kt, sub);
-        math_phase();
+        for (int sub = 0; sub < NSUB; ++sub) {
+          load_phase(kt, sub);
+          math_phase();
+        }
       }
     }
   }
@@ -240,7 +251,7 @@ __global__ __launch_bounds__(TS * 2) void gemm_tn_kernel(TnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int n = nb + (r & 3) + 8 * (r >> 2);
-          if (n < a.N) outp[(size_t)n * a.K + kk] = acc[t][u][r];
+          if (n < a.N) outp[(size_t)n * a.K + kk] = acc[t][u][r] * a.scale;
         }
       }
     }
@@ -248,7 +259,7 @@ __global__ __launch_bounds__(TS * 2) void gemm_tn_kernel(TnArgs a) {
     float* csp = a.cs + (size_t)s * a.N;
 #pragma unroll
     for (int t = 0; t < TA; ++t) {
-      const float v = csa[t] + __shfl_xor(csa[t], 32);
+      const float v = (csa[t] + __shfl_xor(csa[t], 32)) * a.scale;
       const int n = n0 + wa * WTA + t * 32 + (lane & 31);
       if (lane < 32 && n < a.N) csp[n] = v;
     }
@@ -308,12 +319,16 @@ extern "C" int fiber_gemm_tn_splits(int M, int N, int K) {
   return tn_plan(M, N, K).S;
 }
 
-// dW[N,K] (fp32, contiguous) = dY[M,lddy]^T . X[M,ldx];  dbias (nullable, fp32[N]) = column sums of dY.
+// dW[N,K] (fp32, contiguous) = scale * sum over rows m of kept samples of dY[m,:]^T X[m,:];  dbias (nullable, fp32[N]) = the same
+// sum of dY rows.  row_mask (nullable): fp32 [M / rows_per_sample], sample b is kept iff row_mask[b] != 0 (the DropPath factors
+// of the branch: pass 1/keep as `scale`); rows_per_sample must be a multiple of 64 then.  Without a mask every row counts.
 // N % 8 == 0, K % 8 == 0, lddy % 8 == 0, ldx % 8 == 0, 16-byte aligned bases.
 extern "C" int fiber_gemm_tn_bf16(const void* dY, const void* X, float* dW, float* dbias, float* workspace, int M, int N, int K,
-                                  int lddy, int ldx, hipStream_t stream) {
+                                  int lddy, int ldx, const float* row_mask, int rows_per_sample, float scale,
+                                  hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0) return FIBER_OK;
   if ((N & 7) || (K & 7) || (lddy & 7) || (ldx & 7)) return FIBER_EINVAL;
+  if (row_mask && (rows_per_sample <= 0 || (rows_per_sample & 63))) return FIBER_EINVAL;
   const TnPlan p = tn_plan(M, N, K);
   if (p.S > 1 && !workspace) return FIBER_EINVAL;
   TnArgs a;
@@ -322,6 +337,7 @@ extern "C" int fiber_gemm_tn_bf16(const void* dY, const void* X, float* dW, floa
   a.cs = dbias ? (p.S > 1 ? workspace + (size_t)p.S * N * K : dbias) : nullptr;
   a.M = M; a.N = N; a.K = K; a.lda = lddy; a.ldb = ldx;
   a.S = p.S; a.tiles_n = p.tiles_n; a.tiles_k = p.tiles_k; a.kt_per_split = p.kt_per_split; a.nk_total = p.nk_total;
+  a.row_mask = row_mask; a.rows_per_sample = rows_per_sample; a.scale = scale;
   const unsigned grid = (unsigned)(p.tiles_n * p.tiles_k * p.S);
   if (p.ts == 256) hipLaunchKernelGGL((gemm_tn_kernel<256, 64, 2, true>), dim3(grid), dim3(512), 0, stream, a);
   else hipLaunchKernelGGL((gemm_tn_kernel<128, 32, 4, false>), dim3(grid), dim3(256), 0, stream, a);

@@ -16,7 +16,7 @@ P, I, F, L, U64 = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_uint64
 # name -> argtypes (stream appended automatically)
 SIGNATURES = {
     "fiber_gemm_nt_bf16": [P, P, P, P, P, P, P, I, P, I, P, I, I, I, I, I, I, I, I],
-    "fiber_gemm_tn_bf16": [P, P, P, P, P, I, I, I, I, I],
+    "fiber_gemm_tn_bf16": [P, P, P, P, P, I, I, I, I, I, P, I, F],
     "fiber_layernorm_fwd_bf16": [P, P, P, P, P, P, I, I, F],
     "fiber_layernorm_bwd_bf16": [P, P, P, P, P, P, P, P, P, P, I, I],
     "fiber_patch_merge_ln_fwd_bf16": [P, P, P, P, P, P, I, I, I, I, F],

@@ -78,8 +78,9 @@ class WindowAttention(nn.Module):
             self.alpha_i2t = nn.Parameter(torch.Tensor([0]))
             self.norm_i2t_i = nn.LayerNorm(dim)
 
-    def forward(self, u, res, shift, shortcut=None, y=None, y_mask=None, rowscale=None):
-        """u: LayerNorm'ed tokens [B, H*W, C] in image order.  Returns [rowscale *] (proj(attn) (+ i2t branch)) (+ shortcut)."""
+    def forward(self, u, res, shift, shortcut=None, y=None, y_mask=None, rowscale=None, rowscale_value=None):
+        """u: LayerNorm'ed tokens [B, H*W, C] in image order.  Returns [rowscale *] (proj(attn) (+ i2t branch)) (+ shortcut).
+        rowscale_value = 1/keep, the one non-zero value of the DropPath factors (lets the backward fold them into its GEMMs)."""
         B, L, C = u.shape
         H, W = res
         ws = self.window_size[0]
@@ -90,7 +91,7 @@ class WindowAttention(nn.Module):
             qkv = ops.linear(u, self.qkv.weight, self.qkv.bias)
             o = ops.window_attention(qkv, self.relative_position_bias_table, B, H, W, self.num_heads, ws, shift)
         if y is None:
-            return ops.linear(o, self.proj.weight, self.proj.bias, residual=shortcut, rowscale=rowscale)
+            return ops.linear(o, self.proj.weight, self.proj.bias, residual=shortcut, rowscale=rowscale, rowscale_value=rowscale_value)
         a = ops.linear(o, self.proj.weight, self.proj.bias)
         S = y.shape[1]
         assert y.shape[0] == B, "text batch must match image batch"
@@ -132,9 +133,10 @@ class SwinTransformerBlock(nn.Module):
         s1 = ops.drop_path_scale(B, dp, x.device) if dp > 0.0 else None
         s2 = ops.drop_path_scale(B, dp, x.device) if dp > 0.0 else None
         u, x = ops.layernorm_res(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        x = self.attn(u, (H, W), self.shift_size, shortcut=x, y=y, y_mask=y_mask, rowscale=s1)
+        rv = 1.0 / (1.0 - dp) if dp > 0.0 else None
+        x = self.attn(u, (H, W), self.shift_size, shortcut=x, y=y, y_mask=y_mask, rowscale=s1, rowscale_value=rv)
         v, x = ops.layernorm_res(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        return ops.mlp(v, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=x, rowscale=s2)
+        return ops.mlp(v, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=x, rowscale=s2, rowscale_value=rv)
 
 
 class PatchMerging(nn.Module):

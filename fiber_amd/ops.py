@@ -264,10 +264,12 @@ def lib_linear(x, w, b=None):
     return _LibLinear.apply(x, w, b)
 
 
-def wgrad(dh, x2, want_bias=False):
+def wgrad(dh, x2, want_bias=False, row_mask=None, scale=1.0):
     """dW[N,K] = dh[M,N]^T . x2[M,K] in fp32 on the hand-written TN kernel (csrc/gemm_tn.hip): both operands are read as
     they lie (row-major, M slow) and transposed on the LDS -> register path; the M reduction is split inside the launch
-    (fp32 slabs + one fold).  want_bias: also return the column sums of dh (the bias gradient) from the same pass."""
+    (fp32 slabs + one fold).  want_bias: also return the column sums of dh (the bias gradient) from the same pass.
+    row_mask / scale: DropPath backward folded in -- samples whose factor in `row_mask` is 0 are skipped, the result is
+    multiplied by `scale` (= 1/keep); see droppath_foldable()."""
     M, N = dh.shape
     K = x2.shape[1]
     assert dh.dtype == BF16 and x2.dtype == BF16 and dh.stride(1) == 1 and x2.stride(1) == 1 and x2.shape[0] == M
@@ -275,8 +277,23 @@ def wgrad(dh, x2, want_bias=False):
     db = torch.empty(N, dtype=torch.float32, device=dh.device) if want_bias else None
     S = lib.plain("fiber_gemm_tn_splits", M, N, K)
     ws = torch.empty(S * (N * K + N), dtype=torch.float32, device=dh.device) if S > 1 else None
-    lib.call("fiber_gemm_tn_bf16", lib.ptr(dh), lib.ptr(x2), lib.ptr(dw), lib.ptr(db), lib.ptr(ws), M, N, K, dh.stride(0), x2.stride(0))
+    rps = (M // row_mask.numel()) if row_mask is not None else 0
+    lib.call("fiber_gemm_tn_bf16", lib.ptr(dh), lib.ptr(x2), lib.ptr(dw), lib.ptr(db), lib.ptr(ws), M, N, K, dh.stride(0), x2.stride(0),
+             lib.ptr(row_mask), rps, float(scale))
     return (dw, db) if want_bias else dw
+
+
+def droppath_foldable(rows, rowscale, rs_value):
+    """The DropPath backward factor s_b in {0, 1/keep} can ride in the consumers of the branch gradient instead of a pass of
+    its own -- (s dY) W = s (dY W) in the dgrad epilogue, dW = (1/keep) * sum over kept samples in the weight-gradient kernel --
+    when the caller knows 1/keep (`rs_value`) and a sample's rows are whole 64-row K tiles (true for Swin stages 0-2 at
+    384^2: 9216 / 2304 / 576 tokens per image; stage 3 has 144)."""
+    return (_DROPPATH_FOLD and rowscale is not None and rs_value and rows % rowscale.numel() == 0
+            and (rows // rowscale.numel()) % 64 == 0)
+
+
+_DROPPATH_FOLD = os.environ.get("FIBER_DROPPATH_FOLD", "1") != "0"      # A/B switch (tools): 0 = the separate s_b * dy pass
+
 
 
 # Column sums that a backward kernel produced together with its output (window attention: the qkv bias gradient).  The
@@ -315,7 +332,7 @@ def _dgrad(dh, weight):
 
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, act, rowscale):
+    def forward(ctx, x, weight, bias, residual, act, rowscale, rs_value=None):
         shp = x.shape
         x2 = _c(x).view(-1, shp[-1])
         wb = bf16_weight(weight)
@@ -324,7 +341,7 @@ class _Linear(torch.autograd.Function):
         rps = (x2.shape[0] // rowscale.numel()) if rowscale is not None else 0
         y, pre = gemm_nt(x2, wb, bias, r2, act, need_pre, rowscale, rps)
         ctx.save_for_backward(x2, weight, pre, rowscale)
-        ctx.act, ctx.has_bias, ctx.has_res, ctx.shp = act, bias is not None, residual is not None, shp
+        ctx.act, ctx.has_bias, ctx.has_res, ctx.shp, ctx.rs_value = act, bias is not None, residual is not None, shp, rs_value
         return y.view(*shp[:-1], weight.shape[0])
 
     @staticmethod
@@ -334,7 +351,8 @@ class _Linear(torch.autograd.Function):
         dres = dy if ctx.has_res else None
         db = None
         hint = _take_colsum(dy2)
-        if rowscale is not None:                      # branch gradient = per-sample scale * dy
+        fold = not ctx.act and dy2.shape[1] % 8 == 0 and droppath_foldable(dy2.shape[0], rowscale, ctx.rs_value)
+        if rowscale is not None and not fold:         # branch gradient = per-sample scale * dy, as a pass of its own
             if ctx.has_bias and ctx.needs_input_grad[2] and not ctx.act and dy2.shape[1] % 8 == 0:
                 dy2, db = rowscale_colsum(dy2, rowscale)       # ... and the bias gradient from the same pass
             else:
@@ -346,8 +364,19 @@ class _Linear(torch.autograd.Function):
             dh, db = gelu_bwd_colsum(dy2, pre)
         else:
             dh = dy2
-        dx = _dgrad(dh, weight).view(ctx.shp) if ctx.needs_input_grad[0] else None
         need_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if fold:                                       # DropPath factor inside the dgrad epilogue and the weight-gradient kernel
+            rps = dh.shape[0] // rowscale.numel()
+            dx = gemm_nt(dh, bf16_weight_t(weight), None, None, 0, False, rowscale, rps)[0].view(ctx.shp) if ctx.needs_input_grad[0] else None
+            dw = db = None
+            if ctx.needs_input_grad[1]:
+                dw = wgrad(dh, x2, want_bias=need_db, row_mask=rowscale, scale=ctx.rs_value)
+                if need_db:
+                    dw, db = dw
+            elif need_db:
+                db = rowscale_colsum(dh, rowscale)[1]
+            return dx, dw, db, dres, None, None, None
+        dx = _dgrad(dh, weight).view(ctx.shp) if ctx.needs_input_grad[0] else None
         if need_db and db is None and hint is not None and dh is dy2:
             db = hint                                  # produced by the kernel that wrote dy (window attention backward)
         want = need_db and db is None                  # otherwise the bias gradient rides in the weight-gradient pass
@@ -360,10 +389,10 @@ class _Linear(torch.autograd.Function):
             db = colsum(dh)
         if not need_db:
             db = None
-        return dx, dw, db, dres, None, None
+        return dx, dw, db, dres, None, None, None
 
 
-def linear(x, weight, bias=None, residual=None, act=None, rowscale=None):
+def linear(x, weight, bias=None, residual=None, act=None, rowscale=None, rowscale_value=None):
     """nn.Linear with fused bias / exact GELU / residual, forward and both backward GEMMs on the hand-written kernels.
     A library GEMM is used only for shapes the tile kernels do not cover (N % 8 != 0, e.g. the 2-way ITM head, or K % 8 != 0)."""
     N, K = weight.shape
@@ -373,7 +402,7 @@ def linear(x, weight, bias=None, residual=None, act=None, rowscale=None):
             y = torch.nn.functional.gelu(y)
         assert rowscale is None
         return y + residual if residual is not None else y
-    return _Linear.apply(x, weight, bias, residual, 1 if act else 0, rowscale)
+    return _Linear.apply(x, weight, bias, residual, 1 if act else 0, rowscale, rowscale_value)
 
 
 class _MLP(torch.autograd.Function):
@@ -385,7 +414,7 @@ class _MLP(torch.autograd.Function):
     column-sum passes over the 4C-wide tensor disappear.  The remaining plain GEMMs (dX, dW1, dW2) use the library."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, residual, rowscale):
+    def forward(ctx, x, w1, b1, w2, b2, residual, rowscale, rs_value=None):
         shp = x.shape
         x2 = _c(x).view(-1, shp[-1])
         r2 = _c(residual).view(-1, w2.shape[0]) if residual is not None else None
@@ -393,7 +422,7 @@ class _MLP(torch.autograd.Function):
         rps = (x2.shape[0] // rowscale.numel()) if rowscale is not None else 0
         y, _ = gemm_nt(g, bf16_weight(w2), b2, r2, 0, False, rowscale, rps)
         ctx.save_for_backward(x2, w1, w2, h, g, rowscale)
-        ctx.has_res, ctx.shp = residual is not None, shp
+        ctx.has_res, ctx.shp, ctx.rs_value = residual is not None, shp, rs_value
         return y.view(*shp[:-1], w2.shape[0])
 
     @staticmethod
@@ -402,7 +431,13 @@ class _MLP(torch.autograd.Function):
         dy2 = _c(dy).view(-1, w2.shape[0])
         dres = dy if ctx.has_res else None
         db2 = None
-        if rowscale is not None:
+        C, C4 = dy2.shape[1], h.shape[1]
+        fused = C % 64 == 0 and C4 % 8 == 0 and (_FUSED_MLP_BWD == "1" or (_FUSED_MLP_BWD == "auto" and C < 1024))
+        fold = fused and dy2.shape[1] % 8 == 0 and droppath_foldable(dy2.shape[0], rowscale, ctx.rs_value)
+        rs_arg, rps, mask, scale = None, 0, None, 1.0
+        if fold:                                       # DropPath factor rides in the gelu' GEMM epilogue and the wgrad kernel
+            rs_arg, rps, mask, scale = rowscale, dy2.shape[0] // rowscale.numel(), rowscale, ctx.rs_value
+        elif rowscale is not None:
             if dy2.shape[1] % 8 == 0:
                 dy2, db2 = rowscale_colsum(dy2, rowscale)      # DropPath backward + fc2 bias gradient in one pass
             else:
@@ -410,14 +445,13 @@ class _MLP(torch.autograd.Function):
                 lib.call("fiber_rowscale_add_bf16", None, lib.ptr(dy2), lib.ptr(rowscale), lib.ptr(ds), dy2.numel(),
                          dy2.numel() // rowscale.numel())
                 dy2 = ds
-        C, C4 = dy2.shape[1], h.shape[1]
-        if C % 64 == 0 and C4 % 8 == 0 and (_FUSED_MLP_BWD == "1" or (_FUSED_MLP_BWD == "auto" and C < 1024)):
-            dh, _ = gemm_nt(dy2, bf16_weight_t(w2), None, None, 2, False, aux=h)
+        if fused:
+            dh, _ = gemm_nt(dy2, bf16_weight_t(w2), None, None, 2, False, rs_arg, rps, aux=h)
             db1 = None
         else:                                         # C = 1024, or shapes the DMA kernel does not cover (e.g. Swin-T C=96)
             dh, db1 = gelu_bwd_colsum(_dgrad(dy2, w2), h)
         if db2 is None:
-            dw2, db2 = wgrad(dy2, g, want_bias=True)
+            dw2, db2 = wgrad(dy2, g, want_bias=True, row_mask=mask, scale=scale)
         else:
             dw2 = wgrad(dy2, g)
         dx = _dgrad(dh, w1).view(ctx.shp)
@@ -425,11 +459,11 @@ class _MLP(torch.autograd.Function):
             dw1, db1 = wgrad(dh, x2, want_bias=True)   # fc1 bias gradient = column sums of dH, from the same pass
         else:
             dw1 = wgrad(dh, x2)
-        return dx, dw1, db1, dw2, db2, dres, None
+        return dx, dw1, db1, dw2, db2, dres, None, None
 
 
-def mlp(x, w1, b1, w2, b2, residual=None, rowscale=None):
-    return _MLP.apply(x, w1, b1, w2, b2, residual, rowscale)
+def mlp(x, w1, b1, w2, b2, residual=None, rowscale=None, rowscale_value=None):
+    return _MLP.apply(x, w1, b1, w2, b2, residual, rowscale, rowscale_value)
 
 
 class _LayerNorm(torch.autograd.Function):

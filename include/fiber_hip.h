@@ -23,7 +23,7 @@ typedef struct ihipStream_t* fiber_stream_t;
  * replaces: swin_transformer.py:197,221,233,238,257 (qkv/proj/i2t linears), timm Mlp fc1/fc2 (:325), PatchMerging.reduction
  * (:431), roberta.py:231-241,337,398,415, fiber_module.py:349-350.  act: 0 none, 1 GELU (Ypre, if non-NULL, gets the
  * pre-activation).  Requires K%8==0, N%4==0, ldx/ldw%8==0, ldy/ldr%4==0. */
-/* act 2 = fused GELU backward: Y = (X.W^T) * gelu'(aux) with aux = saved pre-activation [M, ldaux];
+/* act 2 = fused GELU backward: Y = rowscale * (X.W^T) * gelu'(aux) with aux = saved pre-activation [M, ldaux];
  * colpart (nullable) receives per-row-tile column sums of Y, [ceil(M / fiber_gemm_row_tile(M,N,K)), N] fp32 (bias gradient). */
 int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bias, const void* residual, void* Y, void* Ypre,
                        const float* rowscale, int rows_per_sample, const void* aux, int ldaux, float* colpart, int M, int N,
@@ -34,10 +34,13 @@ int fiber_gemm_row_tile(int M, int N, int K);
  * column sums of dY.  replaces the ATen addmm-backward (TN GEMM + sum(0)) behind every Linear the reference back-propagates
  * through: swin_transformer.py:197,221,233,238,257, timm Mlp (:325), PatchMerging.reduction (:431), PatchEmbed.proj,
  * roberta.py:231-241,337,398,415, fiber_module.py:349-350.  The M reduction is split inside the launch: workspace must hold
- * S*(N*K + N) floats when S = fiber_gemm_tn_splits(M,N,K) > 1 (NULL otherwise).  N%8==0, K%8==0, lddy%8==0, ldx%8==0. */
+ * S*(N*K + N) floats when S = fiber_gemm_tn_splits(M,N,K) > 1 (NULL otherwise).  N%8==0, K%8==0, lddy%8==0, ldx%8==0.
+ * DropPath backward (timm 0.4.12 DropPath on the branch, swin_transformer.py:390-391) folded in: row_mask (nullable, fp32
+ * [M / rows_per_sample], the per-sample factors in {0, 1/keep}) makes the rows of dropped samples not contribute, `scale` (= 1/keep;
+ * 1 without a mask) multiplies dW and dbias.  rows_per_sample % 64 == 0 when a mask is given. */
 int fiber_gemm_tn_splits(int M, int N, int K);
 int fiber_gemm_tn_bf16(const void* dY, const void* X, float* dW, float* dbias, float* workspace, int M, int N, int K, int lddy,
-                       int ldx, fiber_stream_t stream);
+                       int ldx, const float* row_mask, int rows_per_sample, float scale, fiber_stream_t stream);
 
 /* nn.LayerNorm over the last dim (C%8==0, C<=4096); saves mean/rstd.  replaces swin_transformer.py:362,391,244; roberta.py:485,422 */
 int fiber_layernorm_fwd_bf16(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int rows,

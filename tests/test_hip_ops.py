@@ -524,6 +524,49 @@ def test_adamw_load_state_dict_and_moved_storage(ops):
     assert all(int(v["step"]) == 4 for v in sd.values())
 
 
+@pytest.mark.parametrize("B,L,C", [(4, 576, 512), (5, 2304, 256), (3, 144, 1024), (4, 128, 64)])
+def test_droppath_folded_backward(ops, B, L, C):
+    """timm DropPath on both residual branches of a Swin block (swin_transformer.py:390-391): y = r + s_b * branch(x) with
+    s_b in {0, 1/keep}.  With `rowscale_value` = 1/keep the backward never materialises s_b * dy: the factor rides in the dgrad
+    epilogue / the fused gelu' GEMM and the weight-gradient kernel skips the dropped samples (csrc/gemm_tn.hip); 144 rows per
+    sample is not a multiple of the 64-row K tile and takes the separate pass.  Checked against autograd on the fp32 formula."""
+    keep = 0.8
+    s = torch.tensor([1 / keep, 0.0, 1 / keep, 1 / keep, 0.0][:B], device=DEV)
+    g = bf(rnd(B, L, C, seed=3))
+    # proj-like linear with residual
+    x = bf(rnd(B, L, C)).requires_grad_(True)
+    w = rnd(C, C, std=C ** -0.5).to(DEV).requires_grad_(True)
+    b = rnd(C, seed=1).to(DEV).requires_grad_(True)
+    r = bf(rnd(B, L, C, seed=2)).requires_grad_(True)
+    y = ops.linear(x, w, b, residual=r, rowscale=s, rowscale_value=1 / keep)
+    xr, wr, br, rr = (t.detach().float().requires_grad_(True) for t in (x, w.to(BF), b, r))
+    yr = rr + s.view(B, 1, 1) * (xr @ wr.t() + br)
+    assert_close("y", y, yr, 4e-3)
+    y.backward(g)
+    yr.backward(g.float())
+    for name, got, ref in (("dx", x.grad, xr.grad), ("dw", w.grad, wr.grad), ("db", b.grad, br.grad), ("dr", r.grad, rr.grad)):
+        assert_close("linear " + name, got, ref, 8e-3)
+    assert float(x.grad[1].abs().max()) == 0.0                        # dropped sample: exactly no gradient
+    # MLP with residual
+    w1 = rnd(4 * C, C, seed=5, std=C ** -0.5).to(DEV).requires_grad_(True)
+    b1 = rnd(4 * C, seed=6, std=0.1).to(DEV).requires_grad_(True)
+    w2 = rnd(C, 4 * C, seed=7, std=(4 * C) ** -0.5).to(DEV).requires_grad_(True)
+    b2 = rnd(C, seed=8, std=0.1).to(DEV).requires_grad_(True)
+    x2 = bf(rnd(B, L, C, seed=9)).requires_grad_(True)
+    r2 = bf(rnd(B, L, C, seed=10)).requires_grad_(True)
+    y2 = ops.mlp(x2, w1, b1, w2, b2, residual=r2, rowscale=s, rowscale_value=1 / keep)
+    ref = [t.detach().float().requires_grad_(True) for t in (x2, w1.to(BF), b1, w2.to(BF), b2, r2)]
+    h = F.gelu(ref[0] @ ref[1].t() + ref[2])
+    y2r = ref[5] + s.view(B, 1, 1) * (h.to(BF).float() @ ref[3].t() + ref[4])
+    assert_close("mlp y", y2, y2r, 6e-3)
+    y2.backward(g)
+    y2r.backward(g.float())
+    for name, got, rf in zip(("dx", "dw1", "db1", "dw2", "db2", "dr"), (x2.grad, w1.grad, b1.grad, w2.grad, b2.grad, r2.grad),
+                             (t.grad for t in ref)):
+        assert_close("mlp " + name, got, rf, 1.2e-2)
+    assert float(x2.grad[1].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("B,L,K,N", [(3, 1000, 128, 136), (4, 576, 512, 512)])
 def test_linear_droppath_scale_backward(ops, B, L, K, N):
     """y = shortcut + s_b * (x.W^T + b): the backward computes s_b * dy and the bias gradient in ONE pass
