@@ -164,6 +164,9 @@ def _window_ref(qkv, table, B, H, W, heads, ws, shift):
     (2, 6, 6, 1, 3, 0), (2, 6, 6, 2, 3, 1), (2, 8, 8, 2, 4, 2), (2, 14, 14, 3, 7, 3), (1, 24, 24, 4, 12, 6),
     (2, 12, 12, 8, 12, 0), (1, 48, 48, 4, 12, 6), (1, 36, 36, 2, 18, 9), (2, 18, 18, 4, 18, 0),
     (1, 28, 28, 2, 14, 7), (1, 32, 32, 2, 16, 0),      # 21-tile kernels with 13 / 16 real tiles (the rest is padding)
+    # fine-grained backbone geometries (fusion_swin_transformer_v2.py:293-345): rectangular padded grids, and a SHIFTED
+    # single-window grid (there odd blocks shift regardless of the resolution)
+    (1, 24, 36, 4, 12, 6), (2, 12, 24, 2, 12, 6), (2, 12, 12, 2, 12, 6), (1, 48, 60, 2, 12, 0),
 ])
 def test_window_attention(ops, B, H, W, heads, ws, shift):
     C = heads * 32
