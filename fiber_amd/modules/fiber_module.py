@@ -217,10 +217,13 @@ class FIBERTransformerSS(LightningModule):
         # The text stack below the first fusion block (embeddings + layers 0..5: 20k-row GEMMs, 80-240 tiles for 256 CUs)
         # does not depend on the image stack below it (stages 0-1 and stage-2 blocks 0..13, mostly HBM-bound kernels), so it
         # can be issued on a second HIP stream and joined where the reference first mixes the two (autograd replays every
-        # node on its forward stream, so the backward halves overlap the same way).  OFF by default
-        # (config["overlap_text_stream"] / FIBER_OVERLAP=1): the +1.5 % it measured came from library stream-K GEMMs of the
-        # two streams running concurrently, which can deadlock (ops.lib_gemm); with those kept in one order the gain is
-        # within noise.
+        # node on its forward stream, so the backward halves overlap the same way).  ON by default since round 2
+        # (config["overlap_text_stream"] = False or FIBER_NO_OVERLAP=1 turns it off): +2.3 % on the step (same-box A/B 338.3 ->
+        # 330.6 ms at B=256).  In round 1 it was off because hipBLASLt's stream-K GEMMs (persistent grids whose workgroups wait
+        # for each other) from the two streams could deadlock; every GEMM of the two stacks is a hand-written kernel now
+        # (no inter-workgroup waits), the library is left with the heads, which run after the join.  Parameter gradients are
+        # accumulated by autograd on the parameters' own stream behind event waits, so DDP's bucket hooks see finished
+        # gradients.  Not used while a hipGraph is being captured.
         num_pre_text = self.num_text_layer - self.num_fuse_block
 
         def text_prefix():
@@ -231,7 +234,8 @@ class FIBERTransformerSS(LightningModule):
             return t, e
 
         side = None
-        if (self.config.get("overlap_text_stream", False) or os.environ.get("FIBER_OVERLAP")) and not os.environ.get("FIBER_NO_OVERLAP"):
+        if (self.config.get("overlap_text_stream", True) and not os.environ.get("FIBER_NO_OVERLAP")
+                and text_ids.is_cuda and not torch.cuda.is_current_stream_capturing()):
             side = self._text_stream(text_ids)
         if side is not None:
             main = torch.cuda.current_stream(text_ids.device)
@@ -248,7 +252,7 @@ class FIBERTransformerSS(LightningModule):
         # Fusion blocks: image block (reads the text tokens) and text layer (reads the image tokens) of one step are
         # independent of each other (fiber_module.py:327-346 evaluates both from the previous step's pair), so the text layer
         # runs on the second stream next to the much larger image block; two event waits per step keep the pair in lock step.
-        prefix_only = self.config.get("overlap_text_stream", False) == "prefix" or bool(os.environ.get("FIBER_OVERLAP_PREFIX_ONLY"))
+        prefix_only = self.config.get("overlap_text_stream", True) == "prefix" or bool(os.environ.get("FIBER_OVERLAP_PREFIX_ONLY"))
 
         def fused_step(blk, layer, image_embeds, text_embeds, **kw):
             nonlocal side
@@ -257,10 +261,9 @@ class FIBERTransformerSS(LightningModule):
                 text_embeds.record_stream(main)
                 ext.record_stream(main)
                 side = None
-            if side is None:
-                fuse_image_embeds = blk(image_embeds, text_embeds, ext)
-                text_embeds = layer(text_embeds, ext, encoder_hidden_states=image_embeds, **kw)[0]
-                return fuse_image_embeds, text_embeds
+            if side is None:                                 # same call order as the two-stream form below: the dropout /
+                new_text = layer(text_embeds, ext, encoder_hidden_states=image_embeds, **kw)[0]   # DropPath key counters
+                return blk(image_embeds, text_embeds, ext), new_text                       # do not depend on the mode
             main.wait_stream(side)                           # text tokens of the previous step (produced on `side`)
             side.wait_stream(main)                           # image tokens of the previous step (produced on `main`)
             text_embeds.record_stream(main)
