@@ -300,24 +300,24 @@ _DROPPATH_FOLD = os.environ.get("FIBER_DROPPATH_FOLD", "1") != "0"      # A/B sw
 # producer leaves (data_ptr, shape, sums) here; the NEXT linear backward takes the slot -- and uses it only if it is about
 # the very tensor it received as dY.  Every linear backward clears the slot, so it can never be matched against a later
 # tensor that happens to reuse the address; a missed hand-over only costs the separate column-sum pass.
-_COLSUM_HINT = None
+import threading
+
+_hint_tls = threading.local()          # one hand-over slot per autograd thread (one per device): no cross-thread coupling
 
 
 def _clear_colsum():
-    global _COLSUM_HINT
-    _COLSUM_HINT = None
+    _hint_tls.slot = None
 
 
 def _offer_colsum(t2d, sums):
     """Called from inside a backward(): the offer never outlives the autograd pass it was made in."""
-    global _COLSUM_HINT
-    _COLSUM_HINT = (t2d.data_ptr(), tuple(t2d.shape), sums)
+    _hint_tls.slot = (t2d.data_ptr(), tuple(t2d.shape), sums)
     torch.autograd.Variable._execution_engine.queue_callback(_clear_colsum)
 
 
 def _take_colsum(t2d):
-    global _COLSUM_HINT
-    h, _COLSUM_HINT = _COLSUM_HINT, None
+    h = getattr(_hint_tls, "slot", None)
+    _hint_tls.slot = None
     if h is not None and h[0] == t2d.data_ptr() and h[1] == tuple(t2d.shape):
         return h[2]
     return None

@@ -185,7 +185,7 @@ def test_window_attention(ops, B, H, W, heads, ws, shift):
     # the backward passes also offer the column sums of dqkv (the qkv bias gradient) to the next linear backward; an offer
     # nobody took does not outlive its autograd pass
     from fiber_amd import ops as ops_mod
-    assert ops_mod._COLSUM_HINT is None
+    assert getattr(ops_mod._hint_tls, "slot", None) is None
     seen = []
     real_offer = ops_mod._offer_colsum
     ops_mod._offer_colsum = lambda t, sums: (seen.append((tuple(t.shape), sums)), real_offer(t, sums))[1]
@@ -194,7 +194,7 @@ def test_window_attention(ops, B, H, W, heads, ws, shift):
         ops.window_attention(qkv, table, B, H, W, heads, ws, shift).backward(do)
     finally:
         ops_mod._offer_colsum = real_offer
-    assert ops_mod._COLSUM_HINT is None and len(seen) == 1 and seen[0][0] == (B * H * W, 3 * C)
+    assert getattr(ops_mod._hint_tls, "slot", None) is None and len(seen) == 1 and seen[0][0] == (B * H * W, 3 * C)
     assert_close("colsum(dqkv)", seen[0][1], qr.grad.reshape(-1, 3 * C).sum(0), 1e-2)
 
 
@@ -226,7 +226,7 @@ def test_window_attention_qkv_bias_grad_handover(ops):
             assert_close("db", b.grad, ref, 1e-2)
     finally:
         lib_mod.call = real_call
-    assert ops_mod._COLSUM_HINT is None
+    assert getattr(ops_mod._hint_tls, "slot", None) is None
 
 
 @pytest.mark.parametrize("B,H,W,heads,ws,shift", [(2, 8, 8, 2, 4, 2), (1, 24, 24, 4, 12, 6), (2, 14, 14, 3, 7, 3)])

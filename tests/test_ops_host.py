@@ -42,18 +42,18 @@ def test_colsum_handover_matches_only_the_offered_tensor():
     got, grads = [], []
     _Producer.apply(_Consumer.apply(x, got), sums, grads).sum().backward()
     assert len(got) == 1 and got[0] is sums
-    assert ops._COLSUM_HINT is None
+    assert getattr(ops._hint_tls, "slot", None) is None
     # nobody takes the offer: it does not outlive the autograd pass
     x = torch.randn(4, 6, requires_grad=True)
     _Producer.apply(x, sums, []).sum().backward()
-    assert ops._COLSUM_HINT is None
+    assert getattr(ops._hint_tls, "slot", None) is None
     # a consumer whose dY is another tensor (different storage) gets nothing and clears the slot
     x = torch.randn(4, 6, requires_grad=True)
     got = []
     y = _Consumer.apply(x, got)
     z = _Producer.apply(y * 1.0, sums, [])          # the multiplication puts a fresh tensor between producer and consumer
     z.sum().backward()
-    assert got == [None] and ops._COLSUM_HINT is None
+    assert got == [None] and getattr(ops._hint_tls, "slot", None) is None
     # same storage but another shape is not a match either
     t = torch.zeros(4, 6)
 
