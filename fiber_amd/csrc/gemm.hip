@@ -633,6 +633,206 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_wide_persist_kernel(Gemm
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// v4 persistent: the same K loop, but nothing between two output tiles is a workgroup-wide event any more.
+//  * epilogue = wave_epilogue<>: each wave drains its own 128x64 sub-tile through a private 4-KB LDS slab (dedicated: 8 x 4 KB
+//    next to the two ring stages = the whole 160 KB), no barriers -- the v3 epilogue (4 rounds x 2 workgroup barriers, half
+//    the waves idle during each staging pass, MFMA pipe idle throughout) cost ~7 of the ~21 us of a K = 512 tile;
+//  * the two wave groups keep their stagger ACROSS tiles (one extra barrier for group 1 before the first tile, one for group 0
+//    after the last), so one group's epilogue runs under the other group's last / first MFMAs;
+//  * bias = accumulator seed: the first MFMAs of a tile take C from 32 VGPRs built out of scalar loads of the wave's 64 bias
+//    values (or constant 0) -- no zeroing pass (128 VALU per wave per tile), no bias adds, no bias slice in LDS.
+template <int WM, int WN, int EPI, bool HAS_R, bool HAS_RS, bool TRACE = false>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_wide_persist2_kernel(GemmArgs a) {
+  constexpr int BM = 256, BN = 256, NS = 2;
+  constexpr int NT = 64 * WM * WN;
+  static_assert(NT == 512 && WM == 2 && WN == 4, "two wave groups of four; DMA pass geometry for 8 waves");
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  static_assert(TN == 2 && WTN == 64, "wave_epilogue slab = 32 x 64");
+  constexpr int RPD = NT / 8;
+  constexpr int PA = BM / RPD, PB = BN / RPD;
+  constexpr int STAGE = (BM + BN) * BK;
+  constexpr int SLAB = 32 * 64;                                                   // elements of one wave's slab (4 KB)
+  __shared__ __attribute__((aligned(16))) bf16 smem[NS * STAGE + 8 * SLAB];       // ONE LDS object: 128 KB ring + 32 KB slabs
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  bf16* cw = smem + NS * STAGE + wave * SLAB;
+  const int tilesN = (a.N + BN - 1) / BN, tilesM = (a.M + BM - 1) / BM;
+  const int nblk = tilesM * tilesN;
+  const int P = gridDim.x >> 3, xcd = blockIdx.x & 7, widx = blockIdx.x >> 3;
+  const int q8 = nblk >> 3, r8 = nblk & 7;
+  const int first = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + widx;
+  const int count = q8 + (xcd < r8 ? 1 : 0);
+  const int T = widx < count ? (count - widx + P - 1) / P : 0;
+  if (T == 0) return;
+
+  const int srow = wave * 8 + (lane >> 3), spc = lane & 7;
+  const bf16* xbase; const bf16* wbase;
+  unsigned xo[PA], wo[PB];
+  auto aim = [&](int seq) {
+    const int id = first + seq * P;
+    const int m0 = (id / tilesN) * BM, n0 = (id % tilesN) * BN;
+    xbase = a.X + (size_t)m0 * a.ldx;
+    wbase = a.W + (size_t)n0 * a.ldw;
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      const int row = srow + p * RPD;
+      xo[p] = (unsigned)(min(row, a.M - 1 - m0) * a.ldx + ((spc ^ ((row >> 1) & 7)) << 3)) * 2u;
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      const int row = srow + p * RPD;
+      wo[p] = (unsigned)(min(row, a.N - 1 - n0) * a.ldw + ((spc ^ ((row >> 1) & 7)) << 3)) * 2u;
+    }
+  };
+  auto dma = [&](int g, int kt) {
+    bf16* st = smem + (g & 1) * STAGE;
+#pragma unroll
+    for (int p = 0; p < PA; ++p)
+      lds_dma16(xbase + kt * BK, xo[p], st + (p * RPD + wave * 8) * BK);
+#pragma unroll
+    for (int p = 0; p < PB; ++p)
+      lds_dma16(wbase + kt * BK, wo[p], st + BM * BK + (p * RPD + wave * 8) * BK);
+  };
+
+  f32x16 acc[TM][TN];
+  const int nk = a.K / BK;
+  const int frow = lane & 31, fk = lane >> 5;
+  bf16x8 fa[2][TM], fb[2][TN];
+  auto load_phase = [&](int g, int sub) {
+    const bf16* Ac = smem + (g & 1) * STAGE;
+    const bf16* Bc = Ac + BM * BK;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8*>(Ac + swz(wm * WTM + i * 32 + frow, sub * 4 + ks * 2 + fk));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[ks][j] = *reinterpret_cast<const bf16x8*>(Bc + swz(wn * WTN + j * 32 + frow, sub * 4 + ks * 2 + fk));
+    }
+  };
+  auto math_phase = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // first math phase of a tile: C = the bias of the wave's 64 columns in accumulator layout (element q*4+e of block j is
+  // column j*32 + q*8 + 4*(lane>>5) + e), read with SCALAR loads (wave-uniform address) and picked per half-wave
+  auto math_phase_seeded = [&](int n0w) {
+    f32x16 seed[TN];
+    if (EPI != 2 && a.bias) {
+      typedef __attribute__((address_space(4))) const float cfloat;
+      cfloat* bp = (cfloat*)(uintptr_t)(a.bias + n0w);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = bp[j * 32 + q * 8 + e], hi = bp[j * 32 + q * 8 + 4 + e];
+            seed[j][q * 4 + e] = fk ? hi : lo;
+          }
+    } else {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) seed[j][r] = 0.f;
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][j], fa[0][i], seed[j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[1][j], fa[1][i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto phase_barrier = [&](bool landed) {
+    if (landed) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  aim(0);
+  dma(0, 0);
+  phase_barrier(true);
+  if (wm == 1) phase_barrier(false);                      // group 1 runs one phase behind group 0 from here to the end
+  int g = 0;
+  // TRACE build (tools/gemm_trace.py persist): s_memtime ticks per wave, summed over its tiles --
+  //   [0] first K tile of a tile  [1] other K tiles  [2] epilogue  [3..6] the four barriers of a K tile (wait + barrier)  [7] load+dma issue
+  unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t0 = 0, tb = 0;
+  if constexpr (TRACE) t0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long tstart = t0;
+  auto mark = [&](int i) {
+    if constexpr (TRACE) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      tr[i] += t - t0;
+      t0 = t;
+    }
+  };
+  auto bar_t = [&](int i, bool landed) {
+    if constexpr (TRACE) tb = __builtin_amdgcn_s_memtime();
+    phase_barrier(landed);
+    if constexpr (TRACE) tr[3 + i] += __builtin_amdgcn_s_memtime() - tb;
+  };
+  for (int seq = 0; seq < T; ++seq) {
+    const int id = first + seq * P;
+    const int tm0 = (id / tilesN) * BM, tn0 = (id % tilesN) * BN;
+    for (int kt = 0; kt < nk; ++kt, ++g) {
+      if constexpr (TRACE) tb = __builtin_amdgcn_s_memtime();
+      load_phase(g, 0);
+      if (kt + 1 < nk) dma(g + 1, kt + 1);
+      else if (seq + 1 < T) { aim(seq + 1); dma(g + 1, 0); }
+      if constexpr (TRACE) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tr[7] += __builtin_amdgcn_s_memtime() - tb; }
+      bar_t(0, false);
+      if (kt == 0) math_phase_seeded(tn0 + wn * WTN); else math_phase();
+      bar_t(1, false);
+      load_phase(g, 1);
+      bar_t(2, wm == 1);
+      math_phase();
+      bar_t(3, wm == 0);
+      mark(kt == 0 ? 0 : 1);
+    }
+    if (tm0 + BM <= a.M)
+      wave_epilogue<TM, EPI, HAS_R, HAS_RS, true>(a, acc, cw, tm0 + wm * WTM, tn0 + wn * WTN);
+    else
+      wave_epilogue<TM, EPI, HAS_R, HAS_RS, false>(a, acc, cw, tm0 + wm * WTM, tn0 + wn * WTN);
+    mark(2);
+  }
+  if (wm == 0) phase_barrier(false);                      // every wave passes the same number of barriers
+  if constexpr (TRACE) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0 && blockIdx.x < 8) {
+      float* o = a.colpart + (blockIdx.x * 8 + wave) * 16;
+      for (int i = 0; i < 8; ++i) o[i] = (float)tr[i];
+      o[8] = (float)(__builtin_amdgcn_s_memtime() - tstart);
+      o[9] = (float)nk;
+      o[10] = (float)T;
+    }
+  }
+}
+
+// Variants the v4 (wave-private epilogue) persistent kernel serves: those it compiles without scratch.  gelu' * aux + column sums
+// (EPI 2) and the residual-without-DropPath forms spill 60-120 VGPRs around its longer live ranges and stay on v3.
+template <int EPI, bool R, bool RS>
+constexpr bool kV4Ok = (EPI == 0 && (!R || RS)) || (EPI == 1 && !R);
+
 }  // namespace
 
 // C ABI ---------------------------------------------------------------------------------------------------------
@@ -668,7 +868,7 @@ extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bia
   const int mode = act & 0xff;
   if ((mode == 2 || colpart) && !((K % 64 == 0) && (N % 8 == 0) && (ldy % 8 == 0))) return FIBER_EINVAL;   // LDS-DMA kernels only
   if (mode == 2 && residual) return FIBER_EINVAL;
-  if (colpart && mode != 2 && !(act & 0x200)) return FIBER_EINVAL;
+  if (colpart && mode != 2 && !(act & 0x600)) return FIBER_EINVAL;
   const bool v2 = (K % 64 == 0) && (N % 8 == 0) && (ldy % 8 == 0) && (!residual || ldr % 8 == 0) && !getenv("FIBER_GEMM_V1");
   // Tile choice.  256x256 (K step 32, two wave groups half a tile apart) whenever N is a multiple of 256 and there are
   // enough tiles; otherwise 256x128 / 128x128 / 64x64 on the 64-deep ring.  FIBER_GEMM_TILE / FIBER_GEMM_NOWIDE force a
@@ -685,12 +885,21 @@ extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bia
   const bool persist = persist_env && wide >= 512;        // at least two tiles per CU
 #define FIBER_LAUNCH_EPI(EPI, R, RS)                                                                                          \
   do {                                                                                                                        \
-    if (shape == 0 && persist) hipLaunchKernelGGL((gemm_nt_wide_persist_kernel<2, 4, EPI, R, RS>), dim3(256), dim3(512), 0, stream, a); \
+    if (shape == 0 && persist && persist_env == 2) hipLaunchKernelGGL((gemm_nt_wide_persist_kernel<2, 4, EPI, R, RS>), dim3(256), dim3(512), 0, stream, a); \
+    else if (shape == 0 && persist && kV4Ok<EPI, R, RS>) hipLaunchKernelGGL((gemm_nt_wide_persist2_kernel<2, 4, kV4Ok<EPI, R, RS> ? EPI : 0, kV4Ok<EPI, R, RS> && R, RS>), dim3(256), dim3(512), 0, stream, a); \
+    else if (shape == 0 && persist) hipLaunchKernelGGL((gemm_nt_wide_persist_kernel<2, 4, EPI, R, RS>), dim3(256), dim3(512), 0, stream, a); \
     else if (shape == 0) hipLaunchKernelGGL((gemm_nt_wide_kernel<2, 4, EPI, R, RS>), dim3((unsigned)wide), dim3(512), 0, stream, a);   \
     else if (shape == 1) hipLaunchKernelGGL((gemm_nt_glds_kernel<256, 128, 4, 2, 3, EPI, R, RS>), dim3((unsigned)huge), dim3(512), 0, stream, a); \
     else if (shape == 2) hipLaunchKernelGGL((gemm_nt_glds_kernel<128, 128, 2, 2, 2, EPI, R, RS>), dim3((unsigned)big), dim3(256), 0, stream, a);  \
     else hipLaunchKernelGGL((gemm_nt_glds_kernel<64, 64, 2, 2, 2, EPI, R, RS>), dim3((unsigned)small), dim3(256), 0, stream, a);                   \
   } while (0)
+  if (shape == 0 && (act & 0x400)) {                      // tools/gemm_trace.py persist: per-segment timing of the persistent kernel
+    a.act &= 0xff;
+    if ((act & 0xff) == 1) hipLaunchKernelGGL((gemm_nt_wide_persist2_kernel<2, 4, 1, false, false, true>), dim3(256), dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((gemm_nt_wide_persist2_kernel<2, 4, 0, false, false, true>), dim3(256), dim3(512), 0, stream, a);
+    FIBER_CHECK_LAUNCH();
+    return FIBER_OK;
+  }
   if (shape == 0 && (act & 0x200)) {                      // tools/gemm_trace.py: per-segment timing build of the wide kernel
     hipLaunchKernelGGL((gemm_nt_wide_kernel<2, 4, 0, false, false, true>), dim3((unsigned)wide), dim3(512), 0, stream, a);
     FIBER_CHECK_LAUNCH();

@@ -173,6 +173,129 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x16 (&acc)[B
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-private epilogue (persistent kernel): every wave drains its own 128x64 sub-tile, 32 rows at a time, through a private
+// 4-KB LDS slab.  No workgroup barrier anywhere: the two wave groups keep their half-sub-tile stagger across output tiles, one
+// group's staging / GELU / stores run under the other group's MFMAs, and a wave's stores drain under the next tile's K loop.
+// The bias is already in the accumulators (the tile's first MFMAs are seeded with it), so EPI 0 / 1 start from acc + bias.
+//   slab image: 32 rows x 128 B; 16-byte chunk c of row r lives at chunk c ^ ((r >> 1) & 7) -- the A/B tile swizzle: the 8-byte
+//   MFMA-layout writes of 16 consecutive rows and the 16-byte row-contiguous reads of 8 lanes per row both tile the banks
+//   stores: 8 rows x 128 B per instruction (one whole cache line per row)
+// Column sums (EPI 2) are per 128-row wave sub-tile: `colpart` has two rows per output tile (fiber_gemm_row_tile says 128).
+template <int TM, int EPI, bool HAS_R, bool HAS_RS, bool FULL>
+__device__ __forceinline__ void wave_epilogue(const GemmArgs& a, f32x16 (&acc)[TM][2], bf16* cw, int m0w, int n0w) {
+  const int lane = threadIdx.x & 63;
+  const int wr = lane & 31, wh = lane >> 5;              // staging: row of the slab, which 4-column half of an 8-column group
+  const int rr = lane >> 3, rc = lane & 7;               // read-back: row inside an 8-row pass, 16-byte chunk of the 128-B row
+  constexpr bool SIDE = HAS_R || EPI == 2;
+  const bf16* sidep = EPI == 2 ? a.aux : a.R;
+  const size_t sideld = EPI == 2 ? a.ldaux : a.ldr;
+  const int n_out = n0w + rc * 8;
+  bf16* wbase = cw + wr * 64 + wh * 4;
+  const int wsw = (wr >> 1) & 7;
+  const bf16* rbase = cw + rr * 64;
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // The LDS queue of a wave executes in order, so slab i+1 may be written right behind the reads of slab i (they still see
+  // slab i) without waiting for their data: stage(i+1) / read(i+1) are issued before slab i is processed and stored, and the
+  // write -> read -> return latency of a slab hides behind the previous slab's VALU work and store issue.
+  auto stage = [&](int i) {
+    float rsc = 1.f;
+    if constexpr (EPI == 0 && HAS_RS) rsc = a.rowscale[min(m0w + i * 32 + wr, a.M - 1) / a.rows_per_sample];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf((EPI == 0 && HAS_RS) ? acc[i][j][q * 4 + e] * rsc : acc[i][j][q * 4 + e]);
+        *reinterpret_cast<bf16x4*>(wbase + (((j * 4 + q) ^ wsw) << 3)) = o;
+      }
+  };
+  auto read_pass = [&](int pp) {
+    const int row = pp * 8 + rr;
+    return *reinterpret_cast<const bf16x8*>(rbase + pp * 8 * 64 + ((rc ^ ((row >> 1) & 7)) << 3));
+  };
+  auto load_side = [&](int i, bf16x8 (&sd)[4], float (&prs)[4]) {
+    const int mrow = m0w + i * 32 + rr;
+    if constexpr (SIDE) {
+      const bf16* sp = sidep + (size_t)mrow * sideld + n_out;
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp)
+        if (FULL || mrow + pp * 8 < a.M) sd[pp] = *reinterpret_cast<const bf16x8*>(sp + (size_t)pp * 8 * sideld);
+    }
+    if constexpr ((EPI == 1 || EPI == 2) && HAS_RS) {
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp) prs[pp] = a.rowscale[min(mrow + pp * 8, a.M - 1) / a.rows_per_sample];
+    }
+  };
+  constexpr bool PREF = EPI != 2;                        // side rows one slab ahead (EPI 2: gelu' temporaries + column sums leave no room)
+  bf16x8 cur[4], sd[4], sdn[PREF ? 4 : 1];
+  float prs[4] = {1.f, 1.f, 1.f, 1.f}, prsn[4] = {1.f, 1.f, 1.f, 1.f};
+  load_side(0, sd, prs);
+  stage(0);
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int pp = 0; pp < 4; ++pp) cur[pp] = read_pass(pp);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    if (i + 1 < TM) {
+      if constexpr (PREF) load_side(i + 1, sdn, prsn);
+      asm volatile("" ::: "memory");
+      stage(i + 1);                                      // queued behind the reads of slab i
+      asm volatile("" ::: "memory");
+    }
+    const int mrow = m0w + i * 32 + rr;                  // this lane's first read-back row of the slab
+    bf16* yp = a.Y + (size_t)mrow * a.ldy + n_out;
+    bf16* prep = (EPI == 1 && a.Ypre) ? a.Ypre + (size_t)mrow * a.ldy + n_out : nullptr;
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      if (FULL || mrow + pp * 8 < a.M) {
+        bf16x8 v = cur[pp];
+        if constexpr (EPI == 1) {
+          if (prep) st_stream(reinterpret_cast<bf16x8*>(prep + (size_t)pp * 8 * a.ldy), v);
+          v = gelu8(v, HAS_RS ? prs[pp] : 1.f);
+        } else if constexpr (EPI == 2) {
+          v = gelu_grad_mul8(v, sd[pp], HAS_RS ? prs[pp] : 1.f);
+        }
+        if constexpr (HAS_R) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(sd[pp][e]));
+        }
+        st_out(reinterpret_cast<bf16x8*>(yp + (size_t)pp * 8 * a.ldy), v);
+        if constexpr (EPI == 2) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) csum[e] += bf2f(v[e]);
+        }
+      }
+      if constexpr (EPI == 2 || HAS_R) __builtin_amdgcn_sched_barrier(0);   // one pass at a time: interleaving the passes' GELU / residual
+                                                                            // arithmetic for ILP is what pushes these variants into scratch
+      if (i + 1 < TM) {                                  // the register just drained takes the same pass of the next slab
+        asm volatile("" ::: "memory");
+        cur[pp] = read_pass(pp);
+        if constexpr (PREF) { sd[pp] = sdn[pp]; prs[pp] = prsn[pp]; }
+      }
+    }
+    if constexpr (!PREF) {
+      if (i + 1 < TM) load_side(i + 1, sd, prs);
+    }
+  }
+  if constexpr (EPI == 2) {
+    if (a.colpart && m0w < a.M) {                        // column sums of the stored 128x64 sub-tile: lanes of one chunk, then out
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = csum[e];
+        t += __shfl_xor(t, 8); t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
+        csum[e] = t;
+      }
+      if (lane < 8) {
+        float* cp = a.colpart + (size_t)(m0w >> 7) * a.N + n_out;
+        *reinterpret_cast<float4*>(cp) = float4{csum[0], csum[1], csum[2], csum[3]};
+        *reinterpret_cast<float4*>(cp + 4) = float4{csum[4], csum[5], csum[6], csum[7]};
+      }
+    }
+  }
+}
+
 // bias slice of the tile -> LDS once per workgroup (read by the staging pass many barriers later)
 template <int BN>
 __device__ __forceinline__ void stage_bias(const GemmArgs& a, float* bias_s, int tn0) {
