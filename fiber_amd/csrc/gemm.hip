@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
           const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
           v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
         }
-        if (a.act == 1) {
+        if ((a.act & 0xff) == 1) {
           if (a.Ypre) {
             bf16x4 o;
 #pragma unroll
@@ -153,6 +153,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
           const bf16x4 r = *reinterpret_cast<const bf16x4*>(a.R + (size_t)m * a.ldr + n);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += bf2f(r[e]);
+        }
+        if (a.act & 0x100) {                              // fp32 output (narrow heads whose consumers need full precision)
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.Y) + (size_t)m * a.ldy + n) = float4{v[0], v[1], v[2], v[3]};
+          continue;
         }
         bf16x4 o;
 #pragma unroll
@@ -849,6 +853,8 @@ extern "C" int fiber_gemm_row_tile(int M, int N, int K) {
 }
 
 // Y = rowscale * act(X.W^T + bias) + residual.  bias: fp32[N] or NULL; residual: bf16[M,ldr] or NULL; act: 0 none, 1 exact GELU;
+// act | 0x100 (act 0 only, no residual): Y is fp32 [M, ldy] -- narrow outputs whose consumers need more than bf16 (the
+// offset predictor of the deformable convolutions: sampling positions);
 // rowscale: fp32[M / rows_per_sample] or NULL (per-sample DropPath factor on the branch, swin_transformer.py:390-391)
 // (Ypre, if non-NULL with act=1, receives the pre-activation for the backward pass).  K % 8 == 0, N % 4 == 0,
 // all leading dimensions multiples of 8 elements (16-byte rows).
@@ -876,7 +882,10 @@ extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bia
   static const int force = getenv("FIBER_GEMM_TILE") ? atoi(getenv("FIBER_GEMM_TILE")) : 0;
   static const int nowide = getenv("FIBER_GEMM_NOWIDE") ? atoi(getenv("FIBER_GEMM_NOWIDE")) : 0;
   int shape;                                             // 0 wide, 1 256x128, 2 128x128, 3 64x64, 4/5 register-staged
-  if (v2 && !nowide && force == 0 && wide >= 200 && N % 256 == 0 && K >= 128) shape = 0;
+  if (act & 0x100) {                                      // fp32 output: the register-staged kernels only
+    if (mode != 0 || residual || colpart) return FIBER_EINVAL;
+    shape = big >= 192 ? 4 : 5;
+  } else if (v2 && !nowide && force == 0 && wide >= 200 && N % 256 == 0 && K >= 128) shape = 0;
   else if (v2 && ((huge >= 400 && K >= 256 && force == 0) || force == 256)) shape = 1;
   else if (big >= 192 || force == 128) shape = v2 ? 2 : 4;
   else shape = v2 ? 3 : 5;

@@ -43,11 +43,15 @@ SIGNATURES = {
     "fiber_adamw_multi_f32": [P, P, P, I, F, F, F, F, F, I, P],
     "fiber_resize_bicubic_norm_u8": [P, I, P, P, P, I, I, P, P],
     "fiber_mlm_mask_i64": [P, P, P, L, U64, C.c_uint, I, I, I, I],
+    "fiber_dcn_gather_bf16": [P, P, P, P, I, I, I, I, I, I, I, I, I, I],
+    "fiber_dcn_scatter_bf16": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I],
+    "fiber_dcn_dx_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I],
 }
 # host-side helpers without a stream argument
 PLAIN = {"fiber_layernorm_bwd_grid": [I], "fiber_window_attn_bwd_slices": [I, I], "fiber_window_attn_colsum_rows": [I, I, I], "fiber_colsum_slabs": [I, I], "fiber_gemm_row_tile": [I, I, I], "fiber_gemm_tn_splits": [I, I, I],
-         "fiber_adamw_chunk": [], "fiber_resample_ksize": [I, I]}
+         "fiber_adamw_chunk": [], "fiber_resample_ksize": [I, I], "fiber_dcn_dx_workspace": [I, I, I, I, I, I, I]}
 
+PLAIN_LONG = {"fiber_dcn_dx_workspace"}          # helpers returning a 64-bit count
 _lib = None
 
 
@@ -71,7 +75,7 @@ def load():
     for name, args in PLAIN.items():
         fn = getattr(lib, name)
         fn.argtypes = args
-        fn.restype = I
+        fn.restype = L if name in PLAIN_LONG else I
     _lib = lib
     return lib
 

@@ -111,12 +111,16 @@ def _c(t):
 
 
 def gemm_nt(x2, wb, bias=None, residual=None, act=0, want_pre=False, rowscale=None, rows_per_sample=0, aux=None,
-            want_colsum=False):
-    """y = act(x2 @ wb^T + bias) + residual  on the HIP kernel.  x2 [M,K] bf16 (row stride may exceed K)."""
+            want_colsum=False, out_fp32=False):
+    """y = act(x2 @ wb^T + bias) + residual  on the HIP kernel.  x2 [M,K] bf16 (row stride may exceed K).
+    out_fp32 (plain / bias only): the result is stored in fp32."""
     M, K = x2.shape
     N = wb.shape[0]
     assert x2.dtype == BF16 and wb.dtype == BF16 and x2.stride(1) == 1 and wb.stride(1) == 1
-    y = torch.empty((M, N), dtype=BF16, device=x2.device)
+    y = torch.empty((M, N), dtype=torch.float32 if out_fp32 else BF16, device=x2.device)
+    if out_fp32:
+        assert not act and residual is None and not want_colsum
+        act = 0x100
     pre = torch.empty((M, N), dtype=BF16, device=x2.device) if (want_pre and act) else None
     colpart = None
     if want_colsum:
@@ -954,3 +958,104 @@ class _PatchEmbedProj(torch.autograd.Function):
 
 def patch_embed_proj(img, weight, bias):
     return _PatchEmbedProj.apply(img, weight, bias)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Modulated deformable convolution (DyHead of the fine-grained model, SURVEY.md 8(f)-3): csrc/dcn.hip gather / scatter around the
+# hand-written NT / TN GEMMs.  Channels-last throughout.
+def _conv_weight_rows(weight, transposed=False):
+    """[Cout, Cin, kh, kw] fp32 parameter -> bf16 [Cp, kh*kw*Cin] in the tap-major column order of the gather kernel (rows padded
+    with zeros to a multiple of 8 -- the 27-channel offset convolution), or its transpose [kh*kw*Cin, Cp] for the dgrad GEMM."""
+    key = ("KCT" if transposed else "KC", id(weight))
+    hit = _cache_get(key, weight)
+    if hit is not None and hit[0] == _stamp(weight):
+        return hit[1]
+    if transposed:
+        v = _conv_weight_rows(weight).t().contiguous()
+    else:
+        Cout = weight.shape[0]
+        v = weight.detach().permute(0, 2, 3, 1).reshape(Cout, -1).to(BF16)
+        if Cout % 8:
+            v = torch.nn.functional.pad(v, (0, 0, 0, 8 - Cout % 8))
+        v = v.contiguous()
+    _cache_put(key, _stamp(weight), v, weight)
+    return v
+
+
+def _conv_out(n, k, stride, pad):
+    return (n + 2 * pad - k) // stride + 1
+
+
+class _DeformConv(torch.autograd.Function):
+    """y[B,Ho,Wo,Cout] = conv(x[B,H,W,Cin] sampled at taps + offset, * mask) + bias.  offset [M, 2*taps] / mask [M, taps] fp32 or
+    None (ordinary convolution).  Forward: one gather launch + one MFMA GEMM over the whole batch; backward: dgrad GEMM -> one
+    scatter launch (dx, doffset, dmask), weight + bias gradient on the TN kernel."""
+
+    @staticmethod
+    def forward(ctx, x, offset, mask, weight, bias, stride, pad, out_fp32=False):
+        B, H, W, C = x.shape
+        Cout, _, kh, kw = weight.shape
+        Ho, Wo = _conv_out(H, kh, stride, pad), _conv_out(W, kw, stride, pad)
+        x = _c(x)
+        offset = _c(offset.float()) if offset is not None else None
+        mask = _c(mask.float()) if mask is not None else None
+        M = B * Ho * Wo
+        cols = torch.empty((M, kh * kw * C), dtype=BF16, device=x.device)
+        lib.call("fiber_dcn_gather_bf16", lib.ptr(x), lib.ptr(offset), lib.ptr(mask), lib.ptr(cols), B, H, W, C, Ho, Wo, kh, kw, stride, pad)
+        wr = _conv_weight_rows(weight)
+        Cp = wr.shape[0]
+        bp = bias
+        if bias is not None and Cp != Cout:
+            bp = torch.nn.functional.pad(bias.detach().float(), (0, Cp - Cout))
+        y, _ = gemm_nt(cols, wr, bp, out_fp32=out_fp32)
+        if Cp != Cout:
+            y = y[:, :Cout].contiguous()
+        ctx.save_for_backward(x, offset, mask, cols, weight)
+        ctx.geom = (B, H, W, C, Ho, Wo, kh, kw, stride, pad, Cout, Cp)
+        ctx.has_bias = bias is not None
+        return y.view(B, Ho, Wo, Cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, offset, mask, cols, weight = ctx.saved_tensors
+        B, H, W, C, Ho, Wo, kh, kw, stride, pad, Cout, Cp = ctx.geom
+        dy2 = _c(dy.to(BF16)).view(-1, Cout)
+        if Cp != Cout:
+            dy2 = torch.nn.functional.pad(dy2, (0, Cp - Cout))
+        dx = doff = dmask = dw = db = None
+        need_x, need_off, need_mask = ctx.needs_input_grad[0], offset is not None and ctx.needs_input_grad[1], mask is not None and ctx.needs_input_grad[2]
+        if need_x or need_off or need_mask:
+            dcols, _ = gemm_nt(dy2, _conv_weight_rows(weight, transposed=True))
+            tiled = need_x and kh == 3 and kw == 3 and pad == 1 and stride in (1, 2) and C % 16 == 0      # atomics-free input gradient
+            dxf = torch.zeros((B, H, W, C), dtype=torch.float32, device=x.device) if (need_x and not tiled) else None
+            doff = torch.empty_like(offset) if need_off else None
+            dmask = torch.empty_like(mask) if need_mask else None
+            if dxf is not None or need_off or need_mask:
+                lib.call("fiber_dcn_scatter_bf16", lib.ptr(dcols), lib.ptr(x), lib.ptr(offset), lib.ptr(mask), lib.ptr(dxf), lib.ptr(doff),
+                         lib.ptr(dmask), B, H, W, C, Ho, Wo, kh, kw, stride, pad)
+            if tiled:
+                n = lib.plain("fiber_dcn_dx_workspace", B, H, W, C, Ho, Wo, stride)
+                ws = torch.empty(n, dtype=torch.float32, device=x.device)
+                ws[n - B * H * W * C - 4:].zero_()
+                dx = torch.empty((B, H, W, C), dtype=BF16, device=x.device)
+                lib.call("fiber_dcn_dx_bf16", lib.ptr(dcols), lib.ptr(offset), lib.ptr(mask), lib.ptr(dx), lib.ptr(ws), B, H, W, C, Ho, Wo,
+                         kh, kw, stride, pad)
+            elif need_x:
+                dx = dxf.to(BF16)
+        need_db = ctx.has_bias and ctx.needs_input_grad[4]
+        if ctx.needs_input_grad[3]:
+            dw = wgrad(dy2, cols, want_bias=need_db)
+            if need_db:
+                dw, db = dw
+                db = db[:Cout]
+            dw = dw[:Cout].view(Cout, kh, kw, C).permute(0, 3, 1, 2).contiguous()
+        elif need_db:
+            db = colsum(dy2)[:Cout]
+        return dx, doff, dmask, dw, db, None, None, None
+
+
+def deform_conv(x, offset, mask, weight, bias=None, stride=1, pad=1, out_fp32=False):
+    """Channels-last modulated deformable convolution; offset = mask = None gives the ordinary convolution.  out_fp32: the result
+    is stored in fp32 (the offset / mask predictor: the reference runs the whole operator in fp32, deform_conv.py:335, and sampling
+    positions rounded to bf16 move every bilinear weight by up to 2^-9 of the offset)."""
+    return _DeformConv.apply(x, offset, mask, weight, bias, stride, pad, out_fp32)

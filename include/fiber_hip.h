@@ -150,6 +150,26 @@ int fiber_resize_bicubic_norm_u8(const void* descs, int n, int* coef, void* tmp,
 int fiber_mlm_mask_i64(const long long* ids, long long* ids_mlm, long long* labels, long n, unsigned long long seed,
                        unsigned p_select, int mask_id, int vocab, int special_lo, int special_hi, fiber_stream_t stream);
 
+/* Modulated deformable convolution (DCNv2) of the fine-grained model's DyHead: the sampling half of
+ * layers/deform_conv.py:300-353 `ModulatedDeformConv` (csrc/cuda/deform_conv_kernel_cuda.cu:578-640 im2col, :643-700 col2im,
+ * :703-773 col2im_coord; host loop csrc/cuda/deform_conv_cuda.cu:497-692).  Channels-last: x bf16 [B,H,W,C], cols / dcols bf16
+ * [B*Ho*Wo, kh*kw*C] (tap-major, tap = i*kw + j), offset fp32 [B*Ho*Wo, 2*kh*kw] ((dy,dx) per tap) or NULL, mask fp32
+ * [B*Ho*Wo, kh*kw] (after the sigmoid) or NULL; both NULL = ordinary im2col.  The convolution itself is fiber_gemm_nt_bf16 on
+ * cols (weights reordered to [Cout, kh*kw*C]); its gradients are fiber_gemm_nt_bf16 / fiber_gemm_tn_bf16.
+ * fiber_dcn_scatter_bf16: dx fp32 [B,H,W,C] is accumulated into (caller zeroes; NULL skips), doffset / dmask are written (NULL skips).
+ * groups = deformable_groups = 1, dilation 1, C % 8 == 0. */
+int fiber_dcn_gather_bf16(const void* x, const float* offset, const float* mask, void* cols, int B, int H, int W, int C, int Ho,
+                          int Wo, int kh, int kw, int stride, int pad, fiber_stream_t stream);
+int fiber_dcn_scatter_bf16(const void* dcols, const void* x, const float* offset, const float* mask, float* dx, float* doffset,
+                           float* dmask, int B, int H, int W, int C, int Ho, int Wo, int kh, int kw, int stride, int pad,
+                           fiber_stream_t stream);
+/* Input gradient without device atomics (3x3, stride 1 or 2, pad 1, C % 16 == 0): per-tile fixed-point LDS accumulation + a
+ * window sum.  dx bf16 [B,H,W,C] is written; workspace = fiber_dcn_dx_workspace() 4-byte words whose LAST B*H*W*C + 4 must be
+ * zero on entry. */
+long fiber_dcn_dx_workspace(int B, int H, int W, int C, int Ho, int Wo, int stride);
+int fiber_dcn_dx_bf16(const void* dcols, const float* offset, const float* mask, void* dx, float* workspace, int B, int H, int W,
+                      int C, int Ho, int Wo, int kh, int kw, int stride, int pad, fiber_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

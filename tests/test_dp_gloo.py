@@ -166,7 +166,7 @@ def test_c_abi_exports_every_declared_symbol():
         __graft_entry__.build()          # cross-compiles for gfx950 without a GPU
     l = lib.load()
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "fiber_hip.h")).read()
-    declared = set(re.findall(r"\bint\s+(fiber_\w+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(?:int|long)\s+(fiber_\w+)\s*\(", hdr))
     assert len(declared) >= 20
     for name in declared:
         assert hasattr(l, name), f"{name} declared in fiber_hip.h but not exported"
