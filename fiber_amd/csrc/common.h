@@ -59,15 +59,38 @@ __device__ __forceinline__ f32x2 gelu_cdf2(f32x2 x) {
   return f32x2{__builtin_copysignf(d.x, x.x), __builtin_copysignf(d.y, x.y)} + 0.5f;
 }
 // gelu(x) = x Phi(x) = max(x, 0) - |x| q = 0.5 (x + |x|) - |x| q: no select at all (packed add, multiply, fma)
-__device__ __forceinline__ f32x2 gelu2(f32x2 x) {
+__device__ __forceinline__ f32x2 gelu2_exact(f32x2 x) {
   const f32x2 ax = {fabsf(x.x), fabsf(x.y)};
   return __builtin_elementwise_fma(x + ax, f32x2{0.5f, 0.5f}, -(ax * half_erfc2(ax)));
 }
 // d/dx gelu(x) = Phi(x) + x phi(x)
-__device__ __forceinline__ f32x2 gelu_grad2(f32x2 x) {
+__device__ __forceinline__ f32x2 gelu_grad2_exact(f32x2 x) {
   const f32x2 t = x * x * -0.72134752044448170368f;      // -0.5 x^2 log2(e)
   const f32x2 pdf = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} * 0.3989422804014327f;
   return gelu_cdf2(x) + x * pdf;
+}
+// Backward form without a transcendental: the quarter-rate v_rcp + v_exp of gelu_grad2_exact are 12 of its ~28 issue slots per
+// pair and the fused (dY W2^T) gelu'(H) epilogue is VALU-bound.  gelu'(t) - 1/2 = t Q(t^2), an odd minimax polynomial on |t| <= 4.5
+// with the argument clamped there and the end value scaled to exactly 1/2, so gelu' = 1 for x >= 4.5 and 0 for x <= -4.5.  fp32
+// Horner on packed pairs: max |gelu' - reference| 1.7e-4 over [-8, 8] (the product dy * gelu' is rounded to bf16: 4e-3), 14 slots
+// per pair; s2 fused backward GEMM 1311 -> 1174 us.  The FORWARD stays on the exact form: the same trick there (1.6e-4) bought
+// nothing (that epilogue is bound by its two 128-KB stores) and moved cancellation-dominated gradients past their test bounds.
+__device__ __forceinline__ f32x2 clamp45(f32x2 x) {
+  return f32x2{__builtin_amdgcn_fmed3f(x.x, -4.5f, 4.5f), __builtin_amdgcn_fmed3f(x.y, -4.5f, 4.5f)};
+}
+__device__ __forceinline__ f32x2 gelu2(f32x2 x) { return gelu2_exact(x); }   // forward: exact form (activations feed the loss)
+__device__ __forceinline__ f32x2 gelu_grad2(f32x2 x) {
+  const f32x2 t = clamp45(x), u = t * t;
+  f32x2 p = u * -2.2107319200e-11f + 2.5212396046e-09f;
+  p = p * u + -1.2680140542e-07f;
+  p = p * u + 3.7218184976e-06f;
+  p = p * u + -7.1219708718e-05f;
+  p = p * u + 9.4051189985e-04f;
+  p = p * u + -8.8155761709e-03f;
+  p = p * u + 5.8607425057e-02f;
+  p = p * u + -2.6491721243e-01f;
+  p = p * u + 7.9760069086e-01f;
+  return __builtin_elementwise_fma(t, p, f32x2{0.5f, 0.5f});
 }
 __device__ __forceinline__ float gelu_erf(float x) { return gelu2(f32x2{x, x}).x; }
 __device__ __forceinline__ float gelu_erf_grad(float x) { return gelu_grad2(f32x2{x, x}).x; }

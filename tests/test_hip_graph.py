@@ -59,9 +59,12 @@ def test_graph_replay_matches_eager_with_dropout_and_lr_schedule():
     _, eager, w_e, lr_e = _run(False)
     n_done, graphed, w_g, lr_g = _run(True)
     assert n_done >= 1 and len(graphed) == len(eager) - n_done
-    # identical keys, identical schedule: the trajectories agree to fp32 round-off of the optimizer scalars
-    for a, b in zip(eager[n_done:], graphed):
-        assert abs(a - b) < 2e-4 * max(1.0, abs(a)), (eager, graphed)
+    # identical keys, identical schedule: the first replayed step agrees to the round-off of the optimizer scalars and the order
+    # of the fp32 atomics (measured 2.2e-4 .. 2.4e-4 absolute on a loss of 5.7).  This toy run (batch 4, lr 1e-3 x 5 on the
+    # heads) amplifies such a difference by anything between 0.02 x and 25 x over the next step depending on the build (exact vs
+    # polynomial GELU: 5e-6 vs 5.7e-3 at the second replayed step, from the same first-step gap), so later steps get 2e-3 relative.
+    for k, (a, b) in enumerate(zip(eager[n_done:], graphed)):
+        assert abs(a - b) < (2e-4 if k == 0 else 2e-3) * max(1.0, abs(a)), (eager, graphed)
     assert lr_e[n_done:] == lr_g
     # weights: Adam turns round-off-level differences of (mathematically) zero gradients into +-lr steps -- the embedding
     # scatter-add uses fp32 atomics, so two EAGER runs differ by the same ~1e-3 -- hence a loose bound here, a tight one on the loss
