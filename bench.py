@@ -168,12 +168,12 @@ def time_dominant_kernel(B, device):
     # output streams this kernel is HBM-bound by construction (floor 340 us at 8 TB/s vs 247 us of MFMA time), so its
     # roofline is stated against HBM bandwidth; the MFMA fraction is given beside it.
     gbps = alg_bytes / us / 1e3
-    out = {"kernel": "gemm_nt_wide_persist_kernel<2,4,1,false,false> (stage-2 fc1: bias + GELU + pre-activation store)", "shape": [M, N, K], "us": round(us, 2),
+    out = {"kernel": "gemm_nt_wide_persist2_kernel<2,4,1,false,false> (stage-2 fc1: bias + GELU + pre-activation store)", "shape": [M, N, K], "us": round(us, 2),
            "bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
            "algorithmic_bytes": alg_bytes, "mfma_TFLOPs": round(tf, 1), "mfma_frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None}
     try:   # HBM bytes per launch from the committed PMC pass (profiles/, collected with rocprofv3 --pmc on this same shape)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")))
-        if pmc["shape"] == [M, N, K]:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_kernels.json")))["gemm"]
+        if pmc["algorithmic_bytes_per_launch"] == alg_bytes:      # same shape as the PMC pass (tools/pmc_gemm.py at the bench batch)
             out["traffic"] = int(pmc["traffic_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         pass
@@ -207,10 +207,11 @@ def main():
                     help="per-GPU batch (default: 256 for the headline task, 96 for mlm_itm_itc whose 1+3 fused passes hold "
                          "more activations, 160 for vqa at 576^2)")
     ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
-                    help="capture the whole step (fwd + bwd + AdamW) in a hipGraph: auto = single process and per-GPU batch <= 8 "
-                         "(measured: 38.4 vs 40.2 ms at B=8, but 50.4 vs 48.1 at B=16 and 71.6 vs 69.0 at B=32 -- small batches "
-                         "are bound by ~2500 short kernels, not by the host, and the persistent gradients of graph mode add ~300 "
-                         "accumulate kernels); N > 1 always runs eager (the DDP reducer is host code)")
+                    help="on = capture the whole step (fwd + bwd + AdamW) in a hipGraph and replay it; auto = off = eager.  Measured: "
+                         "single-stream eager 40.2 ms vs replay 38.4 at B=8 (50.4 vs 48.1 at B=16: small batches are bound by ~2500 "
+                         "short kernels on the GPU, not by the host, and graph mode's persistent gradients add ~300 accumulate "
+                         "kernels), but eager with the text stack on its second stream -- the default, not capturable -- is 36.3 ms; "
+                         "N > 1 always runs eager (the DDP reducer is host code)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the forward-only and dominant-kernel timings (clean rocprof runs)")
     ap.add_argument("--task", choices=sorted(TASKS), default="mlm_itm",
@@ -267,7 +268,7 @@ def main():
         model.global_step += 1
         return loss
 
-    use_graph = args.graph == "on" or (args.graph == "auto" and args.batch <= 8)
+    use_graph = args.graph == "on"          # "auto" = eager: with the text stack on its own stream eager beats replay at every batch (36.3 vs 37.5 ms at B=8)
     use_graph = use_graph and world == 1 and args.task == "mlm_itm" and hasattr(opt, "enable_graph_mode")
     step = eager_step
     if use_graph:

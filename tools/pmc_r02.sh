@@ -3,7 +3,9 @@
 # (tools/pmc_step.sh), FETCH_SIZE / WRITE_SIZE + kernel-trace passes on the two dominant hand-written kernels.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-rocprofv3 --kernel-trace --stats -d gpurun_out/r02_trace --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > gpurun_out/r02_trace.log 2>&1
+# per-kernel durations are taken with ONE stream (FIBER_NO_OVERLAP=1): with the text stack on its own stream kernels of the two
+# streams share the CUs and every duration in the trace is inflated by its neighbours
+FIBER_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -d gpurun_out/r02_trace --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > gpurun_out/r02_trace.log 2>&1
 bash tools/pmc_step.sh > gpurun_out/r02_pmc_step.log 2>&1
 for k in gemm tn; do
   rocprofv3 --kernel-trace --stats -d gpurun_out/r02_${k}_trace --output-format csv -- python tools/pmc_$k.py 256 > gpurun_out/r02_${k}_trace.log 2>&1
@@ -22,7 +24,7 @@ def dur(d, kern):
             return float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, int(r["Calls"])
     return None, None, 0
 out = {}
-for tag, kern, alg in (("gemm", "gemm_nt_wide_persist_kernel<2, 4, 1", 2 * (294912 * 512 + 2048 * 512 + 2 * 294912 * 2048)),
+for tag, kern, alg in (("gemm", "gemm_nt_wide_persist2_kernel<2, 4, 1", 2 * (294912 * 512 + 2048 * 512 + 2 * 294912 * 2048)),
                        ("tn", "gemm_tn_kernel<256", 2 * (294912 * 2048 + 294912 * 512) + 4 * 2048 * 512)):
     f, nf = ctr(f"r02_{tag}_fetch", "FETCH_SIZE", kern)
     w, nw = ctr(f"r02_{tag}_write", "WRITE_SIZE", kern)

@@ -2,6 +2,7 @@
 # Per-kernel PMC summary of a short training run: separate rocprofv3 --pmc passes (kernel trace in its own pass).
 # usage: tools/pmc_step.sh   -> gpurun_out/pmc_step_{busy,mfma,fetch,write}/..., gpurun_out/pmc_step_summary.csv
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export FIBER_NO_OVERLAP=1    # one stream: per-kernel counters and durations without a concurrent neighbour
 CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats -d gpurun_out/pmc_step_trace --output-format csv -- $CMD > gpurun_out/pmc_step_trace.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d gpurun_out/pmc_step_mfma --output-format csv -- $CMD > gpurun_out/pmc_step_mfma.log 2>&1
