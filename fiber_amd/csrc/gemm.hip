@@ -9,8 +9,11 @@
 //
 // Kernel family (CDNA4, all NT = both operands K-contiguous, v_mfma_f32_32x32x16_bf16 issued with swapped operands so each
 // lane owns 4 consecutive output columns):
-//   gemm_nt_wide_persist_kernel  256x256 tile, 8 waves, two 64-KB LDS-DMA stages, two wave groups half a sub-tile apart,
-//                                persistent over output tiles (>= 512 tiles, N % 256 == 0)          <- the large shapes
+//   gemm_nt_wide_persist2_kernel 256x256 tile, 8 waves, two 64-KB LDS-DMA stages, two wave groups half a sub-tile apart,
+//                                persistent over output tiles (>= 512 tiles, N % 256 == 0), wave-private epilogue with no
+//                                workgroup barrier, bias as accumulator seed                          <- the large shapes
+//   gemm_nt_wide_persist_kernel  its predecessor (workgroup-wide staged epilogue): still serves the fused gelu' * aux + column
+//                                sums backward and the residual-without-DropPath forms, which spill in the v4 structure
 //   gemm_nt_wide_kernel          the same K loop, one tile per workgroup (200..511 tiles)
 //   gemm_nt_glds_kernel          256x128 (3-stage ring, counted vmcnt) / 128x128 / 64x64 tiles for N not a multiple of 256 or
 //                                few tiles (stage-0 qkv / proj, text layers at small batch, edge configs)

@@ -184,17 +184,17 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x16 (&acc)[B
 // Column sums (EPI 2) are per 128-row wave sub-tile: `colpart` has two rows per output tile (fiber_gemm_row_tile says 128).
 template <int TM, int EPI, bool HAS_R, bool HAS_RS, bool FULL>
 __device__ __forceinline__ void wave_epilogue(const GemmArgs& a, f32x16 (&acc)[TM][2], bf16* cw, int m0w, int n0w) {
+  static_assert(EPI == 0 || EPI == 1, "gelu' * aux + column sums (EPI 2) spills in this structure and stays on tile_epilogue<>");
   const int lane = threadIdx.x & 63;
   const int wr = lane & 31, wh = lane >> 5;              // staging: row of the slab, which 4-column half of an 8-column group
   const int rr = lane >> 3, rc = lane & 7;               // read-back: row inside an 8-row pass, 16-byte chunk of the 128-B row
-  constexpr bool SIDE = HAS_R || EPI == 2;
-  const bf16* sidep = EPI == 2 ? a.aux : a.R;
-  const size_t sideld = EPI == 2 ? a.ldaux : a.ldr;
+  constexpr bool SIDE = HAS_R;
+  const bf16* sidep = a.R;
+  const size_t sideld = a.ldr;
   const int n_out = n0w + rc * 8;
   bf16* wbase = cw + wr * 64 + wh * 4;
   const int wsw = (wr >> 1) & 7;
   const bf16* rbase = cw + rr * 64;
-  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   // The LDS queue of a wave executes in order, so slab i+1 may be written right behind the reads of slab i (they still see
   // slab i) without waiting for their data: stage(i+1) / read(i+1) are issued before slab i is processed and stored, and the
   // write -> read -> return latency of a slab hides behind the previous slab's VALU work and store issue.
@@ -223,13 +223,12 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& a, f32x16 (&acc)[T
       for (int pp = 0; pp < 4; ++pp)
         if (FULL || mrow + pp * 8 < a.M) sd[pp] = *reinterpret_cast<const bf16x8*>(sp + (size_t)pp * 8 * sideld);
     }
-    if constexpr ((EPI == 1 || EPI == 2) && HAS_RS) {
+    if constexpr (EPI == 1 && HAS_RS) {
 #pragma unroll
       for (int pp = 0; pp < 4; ++pp) prs[pp] = a.rowscale[min(mrow + pp * 8, a.M - 1) / a.rows_per_sample];
     }
   };
-  constexpr bool PREF = EPI != 2;                        // side rows one slab ahead (EPI 2: gelu' temporaries + column sums leave no room)
-  bf16x8 cur[4], sd[4], sdn[PREF ? 4 : 1];
+  bf16x8 cur[4], sd[4], sdn[4];                          // side rows (residual) one slab ahead
   float prs[4] = {1.f, 1.f, 1.f, 1.f}, prsn[4] = {1.f, 1.f, 1.f, 1.f};
   load_side(0, sd, prs);
   stage(0);
@@ -239,7 +238,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& a, f32x16 (&acc)[T
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     if (i + 1 < TM) {
-      if constexpr (PREF) load_side(i + 1, sdn, prsn);
+      load_side(i + 1, sdn, prsn);
       asm volatile("" ::: "memory");
       stage(i + 1);                                      // queued behind the reads of slab i
       asm volatile("" ::: "memory");
@@ -254,43 +253,18 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& a, f32x16 (&acc)[T
         if constexpr (EPI == 1) {
           if (prep) st_stream(reinterpret_cast<bf16x8*>(prep + (size_t)pp * 8 * a.ldy), v);
           v = gelu8(v, HAS_RS ? prs[pp] : 1.f);
-        } else if constexpr (EPI == 2) {
-          v = gelu_grad_mul8(v, sd[pp], HAS_RS ? prs[pp] : 1.f);
         }
         if constexpr (HAS_R) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(sd[pp][e]));
         }
         st_out(reinterpret_cast<bf16x8*>(yp + (size_t)pp * 8 * a.ldy), v);
-        if constexpr (EPI == 2) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) csum[e] += bf2f(v[e]);
-        }
       }
-      if constexpr (EPI == 2 || HAS_R) __builtin_amdgcn_sched_barrier(0);   // one pass at a time: interleaving the passes' GELU / residual
-                                                                            // arithmetic for ILP is what pushes these variants into scratch
+      if constexpr (HAS_R) __builtin_amdgcn_sched_barrier(0);     // one pass at a time (keeps the residual variants out of scratch)
       if (i + 1 < TM) {                                  // the register just drained takes the same pass of the next slab
         asm volatile("" ::: "memory");
         cur[pp] = read_pass(pp);
-        if constexpr (PREF) { sd[pp] = sdn[pp]; prs[pp] = prsn[pp]; }
-      }
-    }
-    if constexpr (!PREF) {
-      if (i + 1 < TM) load_side(i + 1, sd, prs);
-    }
-  }
-  if constexpr (EPI == 2) {
-    if (a.colpart && m0w < a.M) {                        // column sums of the stored 128x64 sub-tile: lanes of one chunk, then out
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float t = csum[e];
-        t += __shfl_xor(t, 8); t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
-        csum[e] = t;
-      }
-      if (lane < 8) {
-        float* cp = a.colpart + (size_t)(m0w >> 7) * a.N + n_out;
-        *reinterpret_cast<float4*>(cp) = float4{csum[0], csum[1], csum[2], csum[3]};
-        *reinterpret_cast<float4*>(cp + 4) = float4{csum[4], csum[5], csum[6], csum[7]};
+        sd[pp] = sdn[pp]; prs[pp] = prsn[pp];
       }
     }
   }
