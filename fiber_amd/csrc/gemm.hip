@@ -835,10 +835,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_wide_persist2_kernel(Gem
   }
 }
 
-// Variants the v4 (wave-private epilogue) persistent kernel serves: those it compiles without scratch.  gelu' * aux + column sums
-// (EPI 2) and the residual-without-DropPath forms spill 60-120 VGPRs around its longer live ranges and stay on v3.
+// Variants the v4 (wave-private epilogue) persistent kernel serves: those it compiles without scratch.  gelu' * aux WITH column sums
+// and the residual-without-DropPath forms spill 60-120 VGPRs around its longer live ranges and stay on v3; gelu' * aux without
+// column sums (the caller takes the bias gradient from the weight-gradient kernel) is served.
 template <int EPI, bool R, bool RS>
-constexpr bool kV4Ok = (EPI == 0 && (!R || RS)) || (EPI == 1 && !R);
+constexpr bool kV4Ok = (EPI == 0 && (!R || RS)) || (EPI == 1 && !R) || EPI == 2;
 
 }  // namespace
 
@@ -898,7 +899,7 @@ extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bia
 #define FIBER_LAUNCH_EPI(EPI, R, RS)                                                                                          \
   do {                                                                                                                        \
     if (shape == 0 && persist && persist_env == 2) hipLaunchKernelGGL((gemm_nt_wide_persist_kernel<2, 4, EPI, R, RS>), dim3(256), dim3(512), 0, stream, a); \
-    else if (shape == 0 && persist && kV4Ok<EPI, R, RS>) hipLaunchKernelGGL((gemm_nt_wide_persist2_kernel<2, 4, kV4Ok<EPI, R, RS> ? EPI : 0, kV4Ok<EPI, R, RS> && R, RS>), dim3(256), dim3(512), 0, stream, a); \
+    else if (shape == 0 && persist && kV4Ok<EPI, R, RS> && !(EPI == 2 && a.colpart)) hipLaunchKernelGGL((gemm_nt_wide_persist2_kernel<2, 4, kV4Ok<EPI, R, RS> ? EPI : 0, kV4Ok<EPI, R, RS> && R, RS>), dim3(256), dim3(512), 0, stream, a); \
     else if (shape == 0 && persist) hipLaunchKernelGGL((gemm_nt_wide_persist_kernel<2, 4, EPI, R, RS>), dim3(256), dim3(512), 0, stream, a); \
     else if (shape == 0) hipLaunchKernelGGL((gemm_nt_wide_kernel<2, 4, EPI, R, RS>), dim3((unsigned)wide), dim3(512), 0, stream, a);   \
     else if (shape == 1) hipLaunchKernelGGL((gemm_nt_glds_kernel<256, 128, 4, 2, 3, EPI, R, RS>), dim3((unsigned)huge), dim3(512), 0, stream, a); \

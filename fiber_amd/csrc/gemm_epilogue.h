@@ -184,13 +184,12 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x16 (&acc)[B
 // Column sums (EPI 2) are per 128-row wave sub-tile: `colpart` has two rows per output tile (fiber_gemm_row_tile says 128).
 template <int TM, int EPI, bool HAS_R, bool HAS_RS, bool FULL>
 __device__ __forceinline__ void wave_epilogue(const GemmArgs& a, f32x16 (&acc)[TM][2], bf16* cw, int m0w, int n0w) {
-  static_assert(EPI == 0 || EPI == 1, "gelu' * aux + column sums (EPI 2) spills in this structure and stays on tile_epilogue<>");
   const int lane = threadIdx.x & 63;
   const int wr = lane & 31, wh = lane >> 5;              // staging: row of the slab, which 4-column half of an 8-column group
   const int rr = lane >> 3, rc = lane & 7;               // read-back: row inside an 8-row pass, 16-byte chunk of the 128-B row
-  constexpr bool SIDE = HAS_R;
-  const bf16* sidep = a.R;
-  const size_t sideld = a.ldr;
+  constexpr bool SIDE = HAS_R || EPI == 2;
+  const bf16* sidep = EPI == 2 ? a.aux : a.R;
+  const size_t sideld = EPI == 2 ? a.ldaux : a.ldr;
   const int n_out = n0w + rc * 8;
   bf16* wbase = cw + wr * 64 + wh * 4;
   const int wsw = (wr >> 1) & 7;
@@ -223,12 +222,18 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& a, f32x16 (&acc)[T
       for (int pp = 0; pp < 4; ++pp)
         if (FULL || mrow + pp * 8 < a.M) sd[pp] = *reinterpret_cast<const bf16x8*>(sp + (size_t)pp * 8 * sideld);
     }
-    if constexpr (EPI == 1 && HAS_RS) {
+    if constexpr ((EPI == 1 || EPI == 2) && HAS_RS) {
 #pragma unroll
       for (int pp = 0; pp < 4; ++pp) prs[pp] = a.rowscale[min(mrow + pp * 8, a.M - 1) / a.rows_per_sample];
     }
   };
-  bf16x8 cur[4], sd[4], sdn[4];                          // side rows (residual) one slab ahead
+  auto load_side_pass = [&](int i, int pp, bf16x8& sdp, float& prp) {
+    const int mrow = m0w + i * 32 + rr + pp * 8;
+    if (FULL || mrow < a.M) sdp = *reinterpret_cast<const bf16x8*>(sidep + (size_t)mrow * sideld + n_out);
+    if constexpr (HAS_RS) prp = a.rowscale[min(mrow, a.M - 1) / a.rows_per_sample];
+  };
+  constexpr bool PREF = EPI != 2;                        // side rows a whole slab ahead; gelu' * aux (register budget): pass by pass
+  bf16x8 cur[4], sd[4], sdn[PREF ? 4 : 1];
   float prs[4] = {1.f, 1.f, 1.f, 1.f}, prsn[4] = {1.f, 1.f, 1.f, 1.f};
   load_side(0, sd, prs);
   stage(0);
@@ -238,7 +243,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& a, f32x16 (&acc)[T
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     if (i + 1 < TM) {
-      load_side(i + 1, sdn, prsn);
+      if constexpr (PREF) load_side(i + 1, sdn, prsn);
       asm volatile("" ::: "memory");
       stage(i + 1);                                      // queued behind the reads of slab i
       asm volatile("" ::: "memory");
@@ -253,6 +258,8 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& a, f32x16 (&acc)[T
         if constexpr (EPI == 1) {
           if (prep) st_stream(reinterpret_cast<bf16x8*>(prep + (size_t)pp * 8 * a.ldy), v);
           v = gelu8(v, HAS_RS ? prs[pp] : 1.f);
+        } else if constexpr (EPI == 2) {
+          v = gelu_grad_mul8(v, sd[pp], HAS_RS ? prs[pp] : 1.f);
         }
         if constexpr (HAS_R) {
 #pragma unroll
@@ -260,11 +267,12 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& a, f32x16 (&acc)[T
         }
         st_out(reinterpret_cast<bf16x8*>(yp + (size_t)pp * 8 * a.ldy), v);
       }
-      if constexpr (HAS_R) __builtin_amdgcn_sched_barrier(0);     // one pass at a time (keeps the residual variants out of scratch)
+      if constexpr (HAS_R || EPI == 2) __builtin_amdgcn_sched_barrier(0);     // one pass at a time (keeps the residual variants out of scratch)
       if (i + 1 < TM) {                                  // the register just drained takes the same pass of the next slab
         asm volatile("" ::: "memory");
         cur[pp] = read_pass(pp);
-        sd[pp] = sdn[pp]; prs[pp] = prsn[pp];
+        if constexpr (PREF) { sd[pp] = sdn[pp]; prs[pp] = prsn[pp]; }
+        else load_side_pass(i + 1, pp, sd[pp], prs[pp]);  // rolling: the register just consumed takes the same pass of the next slab
       }
     }
   }
