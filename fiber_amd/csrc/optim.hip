@@ -99,3 +99,56 @@ extern "C" int fiber_adamw_multi_f32(const long long* table, const long long* nu
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// All transposed bf16 working copies in ONE launch.  The dgrad GEMMs read W^T [K, N] (both operands K-contiguous in the NT kernel);
+// those copies were one strided-copy kernel per weight per optimizer step: 233 launches x 8.6 us.  Here a table of
+// {src [N, K] bf16, dst [K, N] bf16, N, K, first tile} drives 64 x 64 tiles through LDS: 16-byte row reads, 16-byte row writes.
+namespace {
+
+struct TrDesc { const bf16* src; bf16* dst; int N, K, tile0, tiles_k; };   // 32 bytes
+
+__global__ __launch_bounds__(256) void transpose_multi_kernel(const TrDesc* __restrict__ table, int ndesc) {
+  __shared__ bf16 tile[64][72];                          // 144-byte rows: the 2-byte column reads of 8 lanes fall on 8 bank pairs
+  int lo = 0, hi = ndesc - 1;                            // descriptor whose tile range holds blockIdx.x (tile0 ascending)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const TrDesc d = table[lo];
+  const int t = blockIdx.x - d.tile0;
+  const int n0 = (t / d.tiles_k) * 64, k0 = (t % d.tiles_k) * 64;
+  const int r = threadIdx.x >> 3, c = threadIdx.x & 7;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int n = n0 + r + h * 32, k = k0 + c * 8;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = f2bf(0.f);
+    if (n < d.N && k < d.K) v = *reinterpret_cast<const bf16x8*>(d.src + (size_t)n * d.K + k);   // K % 8 == 0
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tile[r + h * 32][c * 8 + e] = v[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int k = k0 + r + h * 32, n = n0 + c * 8;
+    if (k < d.K && n < d.N) {                            // N % 8 == 0
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = tile[c * 8 + e][r + h * 32];
+      *reinterpret_cast<bf16x8*>(d.dst + (size_t)k * d.N + n) = v;
+    }
+  }
+}
+
+}  // namespace
+
+// table: device array of ndesc 32-byte records {src, dst (8-byte pointers), int32 N, K, tile0, tiles_k}, tile0 ascending with
+// tile0[0] = 0, tiles of a [N, K] weight = ceil(N/64) * ceil(K/64); ntiles = their total.  dst[k][n] = src[n][k].  N % 8 == K % 8 == 0.
+extern "C" int fiber_transpose_multi_bf16(const void* table, int ndesc, int ntiles, hipStream_t stream) {
+  if (ndesc <= 0 || ntiles <= 0) return FIBER_OK;
+  hipLaunchKernelGGL(transpose_multi_kernel, dim3((unsigned)ntiles), dim3(256), 0, stream, (const TrDesc*)table, ndesc);
+  FIBER_CHECK_LAUNCH();
+  return FIBER_OK;
+}

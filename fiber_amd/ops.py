@@ -66,14 +66,61 @@ def bf16_weight(w):
 
 def bf16_weight_t(w):
     """bf16 TRANSPOSED copy of an fp32 [N, K] parameter -> [K, N] (the B operand of the dgrad GEMM dX = dY . W in the
-    kernel's NT form), refreshed when the parameter's version counter changes."""
+    kernel's NT form), refreshed when the parameter's version counter changes.  Copies made here are remembered: after an
+    optimizer step refresh_transposed_copies() rewrites all of them in one launch instead of one strided copy per weight."""
     key = ("T", id(w))
     hit = _cache_get(key, w)
     if hit is not None and hit[0] == _stamp(w):
         return hit[1]
-    wt = bf16_weight(w).t().contiguous()                 # one transposing copy of the (optimizer-refreshed) bf16 working copy
+    wb = bf16_weight(w)
+    if hit is not None and hit[1].shape == (wb.shape[1], wb.shape[0]) and hit[1].device == wb.device:
+        wt = hit[1]
+        wt.copy_(wb.t())                                 # same storage: pointer tables built on it stay valid
+    else:
+        wt = wb.t().contiguous()
+        _t_registry_version[0] += 1
     _cache_put(key, _stamp(w), wt, w)
     return wt
+
+
+_t_registry_version = [0]            # bumped whenever a transposed copy gets new storage
+_t_table = {}                        # device -> (registry version, members, device table, tiles)
+
+
+def refresh_transposed_copies():
+    """Rewrite every cached transposed copy whose plain bf16 copy is current (i.e. was just rewritten by the fused optimizer) in
+    ONE kernel launch and mark it current.  Called by FiberAdamW.step() after it restamped the plain copies."""
+    if not _wcache:
+        return
+    by_dev = {}
+    for key, (stamp, wt, ref) in list(_wcache.items()):
+        if not (isinstance(key, tuple) and key[0] == "T"):
+            continue
+        w = ref()
+        if w is None or not wt.is_cuda:
+            continue
+        plain = _cache_get(id(w), w)
+        if plain is None or plain[0] != _stamp(w) or plain[1].shape != (wt.shape[1], wt.shape[0]):
+            continue                                     # plain copy stale or gone: the lazy path rebuilds both
+        if (wt.shape[0] % 8) or (wt.shape[1] % 8):
+            continue
+        by_dev.setdefault(wt.device, []).append((key, w, plain[1], wt, ref))
+    for dev, items in by_dev.items():
+        members = tuple((p.data_ptr(), t.data_ptr()) for _, _, p, t, _ in items)
+        ent = _t_table.get(dev)
+        if ent is None or ent[0] != members:
+            rows, tile0 = [], 0
+            for _, _, p, t, _ in items:
+                N, K = p.shape
+                tk = -(-K // 64)
+                rows.append((p.data_ptr(), t.data_ptr(), N | (K << 32), tile0 | (tk << 32)))
+                tile0 += -(-N // 64) * tk
+            ent = (members, torch.tensor(rows, dtype=torch.int64).to(dev), tile0)
+            _t_table[dev] = ent
+        with torch.cuda.device(dev):
+            lib.call("fiber_transpose_multi_bf16", lib.ptr(ent[1]), len(items), ent[2])
+        for key, w, _, wt, ref in items:
+            _wcache[key] = (_stamp(w), wt, ref)
 
 
 def bf16_copy_if_cached(w):

@@ -166,4 +166,6 @@ class FiberAdamW(torch.optim.Optimizer):
                      float(group["lr"]), float(group["weight_decay"]), float(b1), float(b2), float(group["eps"]), int(step), hyper)
             ops.restamp_bf16_copies(plist, bump=not bumped)
             bumped = True
+        if bumped:
+            ops.refresh_transposed_copies()            # every W^T working copy in one launch (233 strided copies per step before)
         return loss

@@ -134,6 +134,11 @@ int fiber_adamw_chunk(void);
 int fiber_adamw_multi_f32(const long long* table, const long long* numel, const int* chunks, int nchunks, float lr,
                           float weight_decay, float beta1, float beta2, float eps, int step, const float* hyper,
                           fiber_stream_t stream);
+/* All transposed bf16 working copies of the linear weights (the W^T operand of every dX GEMM) in one launch, after the optimizer
+ * step -- caller side, next to fiber_adamw_multi_f32 (which rewrites the plain bf16 copies).  table: device array of ndesc 32-byte
+ * records {const bf16* src [N,K]; bf16* dst [K,N]; int32 N, K, tile0, tiles_k}; tile0 ascending from 0, a weight owns
+ * ceil(N/64)*ceil(K/64) tiles, tiles_k = ceil(K/64); ntiles = the total.  N % 8 == K % 8 == 0. */
+int fiber_transpose_multi_bf16(const void* table, int ndesc, int ntiles, fiber_stream_t stream);
 /* On-device input pipeline.
  * fiber_resize_bicubic_norm_u8 replaces transforms/transform.py:10-17 `albef_transform`: torchvision Resize((S,S), BICUBIC) on a
  * PIL RGB image (= Pillow ImagingResample: anti-aliased separable bicubic, 22-bit fixed-point coefficients, 8-bit rounding after

@@ -609,3 +609,27 @@ def test_cross_entropy_bf16(ops, rows, V):
     (want * 1.7).backward()
     assert_close("dlogits", x.grad, xr.grad, 6e-3)
     assert float(x.grad[lab == -100].abs().max()) == 0.0
+
+
+def test_transposed_weight_copies_refreshed_in_one_launch():
+    """FiberAdamW.step() rewrites every cached W^T working copy with one multi-tensor transpose: same storage as before the
+    step, contents = transpose of the updated bf16 copy, and the lazy path is not taken again (stamps current)."""
+    from fiber_amd import ops as ops_mod
+    from fiber_amd.optim import FiberAdamW
+    torch.manual_seed(0)
+    shapes = [(128, 64), (72, 200), (256, 256), (8, 40), (3072, 768)]
+    ws = [torch.nn.Parameter(torch.randn(n, k, device=DEV)) for n, k in shapes]
+    opt = FiberAdamW(ws, lr=1e-2, weight_decay=0.01)
+    x = [torch.randn(4, k, device=DEV).to(BF).requires_grad_(True) for _, k in shapes]
+    for it in range(3):
+        opt.zero_grad(set_to_none=True)
+        loss = sum(ops_mod.linear(xi, w).float().square().mean() for xi, w in zip(x, ws))
+        loss.backward()                                           # dX uses bf16_weight_t(w): creates / reuses the copies
+        ptrs = [ops_mod.bf16_weight_t(w).data_ptr() for w in ws]
+        opt.step()
+        for w, p0 in zip(ws, ptrs):
+            hit = ops_mod._cache_get(("T", id(w)), w)
+            assert hit is not None and hit[0] == ops_mod._stamp(w), "transposed copy not marked current after the step"
+            assert hit[1].data_ptr() == p0
+            assert torch.equal(hit[1], w.detach().to(BF).t().contiguous())
+            assert torch.equal(ops_mod.bf16_weight(w), w.detach().to(BF))
