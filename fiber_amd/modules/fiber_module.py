@@ -239,6 +239,7 @@ class FIBERTransformerSS(LightningModule):
             side = self._text_stream(text_ids)
         if side is not None:
             main = torch.cuda.current_stream(text_ids.device)
+            object.__setattr__(self, "_main_stream", main)     # parallel.wrap_ddp's comm hook orders buckets behind both streams
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 text_embeds, ext = text_prefix()

@@ -52,7 +52,20 @@ def wrap_ddp(model, device=None, bucket_cap_mb=64, bf16_grads=None):
     if bf16_grads is None:
         env = os.environ.get("FIBER_DDP_BF16")
         bf16_grads = (dist.get_backend() == "nccl") if env is None else env == "1"
-    if bf16_grads:
-        from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
-        ddp.register_comm_hook(state=None, hook=default_hooks.bf16_compress_hook)
+    from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+    inner = default_hooks.bf16_compress_hook if bf16_grads else default_hooks.allreduce_hook
+    on_gpu = device is not None and device.type == "cuda"
+
+    def hook(state, bucket):
+        # The text stack runs (forward AND backward) on the module's second HIP stream, so one bucket can hold gradients written
+        # on two streams, while the reducer orders the all-reduce only behind the stream of the LAST gradient that arrived.
+        # Every gradient of a ready bucket has been enqueued by now: wait for both streams' tails before the collective.
+        if on_gpu:
+            cur = torch.cuda.current_stream()
+            for st in (getattr(model, "_side_stream", None), getattr(model, "_main_stream", None)):
+                if st is not None and st != cur:
+                    cur.wait_stream(st)
+        return inner(state, bucket)
+
+    ddp.register_comm_hook(state=None, hook=hook)
     return ddp
