@@ -172,7 +172,8 @@ __global__ __launch_bounds__(256) void absmax_bf16_kernel(const bf16* v, long n8
 __device__ __forceinline__ float dcn_fixed_scale(unsigned maxbits) {
   // 2^(19 - e), 2^e > max: the exponent field of max gives floor(log2 max) = E - 127
   const int E = (int)(maxbits >> 23);
-  return maxbits ? __uint_as_float((unsigned)(127 + 19 - (E - 127 + 1)) << 23) : 1.f;
+  const int ef = min(max(127 + 19 - (E - 127 + 1), 1), 254);      // clamped: a denormal maximum would ask for 2^146
+  return maxbits ? __uint_as_float((unsigned)ef << 23) : 1.f;
 }
 
 __global__ __launch_bounds__(256) void dcn_dx_tile_kernel(DcnP p, DcnT g, const bf16* dcols, int* tiles, float* far, const unsigned* maxbits) {
