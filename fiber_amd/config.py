@@ -21,6 +21,9 @@ DEFAULTS = dict(
     get_recall_metric=False, get_recall_metric_itc=True, cider_path=None,
     resume_from=None, fast_dev_run=False, val_check_interval=1.0, test_only=False,
     data_root="", log_dir="result", per_gpu_batchsize=0, num_gpus=8, num_nodes=1, load_path="", num_workers=8, precision=32,
+    # not a reference key: storage type of the residual streams of both backbones -- "bf16" (rounded at every block) or "fp32"
+    # (fiber_amd/ops.py "fp32 residual stream"; the reference's fp32 run keeps them in fp32).  None = FIBER_RESIDUAL_DTYPE or bf16.
+    residual_dtype=None,
 )
 
 

@@ -239,6 +239,132 @@ __global__ __launch_bounds__(256) void rowscale_add_kernel(const bf16* __restric
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Residual-stream add with everything the reference does between a branch and its residual in ONE pass:
+//     out = res + rowscale[sample] * ( drop_a(a) + alpha * drop_b(b) )
+//   res:  fp32 (RES = 2, the fp32 residual stream), bf16 (RES = 1) or absent (RES = 0)
+//   a, b: bf16 branches (b optional); alpha: device scalar (alpha_i2t / alpha_t2i) or NULL = 1
+//   drop_a / drop_b: hidden dropout of the branch (RoBERTa dense -> dropout -> add, roberta.py:337-340,417-423), counter-based
+//         keep-masks keyed by (seed, element): thresh 0 = off.  rowscale: per-sample timm DropPath factor or NULL
+//   out32 (fp32) and / or out16 (bf16 shadow) -- at least one.
+// Replaces scale_add + rowscale_add (Swin fused blocks, swin_transformer.py:259 + :390), dropout + add and scale_add + add
+// (RobertaSelfOutput / RobertaOutput / RobertaLayer, roberta.py:339,420,483-485): 2-3 launches and as many passes -> one.
+struct StreamAddArgs {
+  const void* res; const bf16* a; const bf16* b; const float* alpha; const float* rowscale;
+  float* out32; bf16* out16;
+  size_t nvec, vec_per_sample;
+  uint64_t seed_a, seed_b; const uint64_t* seed_base;
+  uint32_t thresh_a, thresh_b; float inv_keep_a, inv_keep_b;
+};
+
+template <int RES>
+__global__ __launch_bounds__(256) void stream_add_kernel(StreamAddArgs p) {
+  const float al = p.alpha ? p.alpha[0] : 1.f;
+  uint64_t sa = p.seed_a, sb = p.seed_b;
+  if (p.seed_base) { sa += *p.seed_base; sb += *p.seed_base; }
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < p.nvec; i += (size_t)gridDim.x * 256) {
+    const float rs = p.rowscale ? p.rowscale[i / p.vec_per_sample] : 1.f;
+    const bf16x8 av = reinterpret_cast<const bf16x8*>(p.a)[i];
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = bf2f(av[e]);
+    if (p.thresh_a) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = drop_keep(sa, i * 8 + e, p.thresh_a) ? v[e] * p.inv_keep_a : 0.f;
+    }
+    if (p.b) {
+      const bf16x8 bv = reinterpret_cast<const bf16x8*>(p.b)[i];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = bf2f(bv[e]);
+        if (p.thresh_b) t = drop_keep(sb, i * 8 + e, p.thresh_b) ? t * p.inv_keep_b : 0.f;
+        v[e] += al * t;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= rs;
+    if constexpr (RES == 2) {
+      const float* rp = reinterpret_cast<const float*>(p.res) + i * 8;
+      const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+      v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+    } else if constexpr (RES == 1) {
+      const bf16x8 rv = reinterpret_cast<const bf16x8*>(p.res)[i];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bf2f(rv[e]);
+    }
+    if (p.out32) {
+      float* op = p.out32 + i * 8;
+      *reinterpret_cast<float4*>(op) = float4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<float4*>(op + 4) = float4{v[4], v[5], v[6], v[7]};
+    }
+    if (p.out16) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+      reinterpret_cast<bf16x8*>(p.out16)[i] = o;
+    }
+  }
+}
+
+// Backward of stream_add with respect to the branches: da = rowscale * mask_a * dy, db = rowscale * alpha * mask_b * dy,
+// dalpha += sum(rowscale * dy * drop_b(b)) (one fp32 atomic per workgroup; the caller zeroes it).  The residual gradient is dy.
+struct StreamAddBwdArgs {
+  const bf16* dy; const bf16* b; const float* alpha; const float* rowscale;
+  bf16* da; bf16* db; float* dalpha;
+  size_t nvec, vec_per_sample;
+  uint64_t seed_a, seed_b; const uint64_t* seed_base;
+  uint32_t thresh_a, thresh_b; float inv_keep_a, inv_keep_b;
+};
+
+__global__ __launch_bounds__(256) void stream_add_bwd_kernel(StreamAddBwdArgs p) {
+  __shared__ float red[4];
+  const float al = p.alpha ? p.alpha[0] : 1.f;
+  uint64_t sa = p.seed_a, sb = p.seed_b;
+  if (p.seed_base) { sa += *p.seed_base; sb += *p.seed_base; }
+  float acc = 0.f;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < p.nvec; i += (size_t)gridDim.x * 256) {
+    const float rs = p.rowscale ? p.rowscale[i / p.vec_per_sample] : 1.f;
+    const bf16x8 dv = reinterpret_cast<const bf16x8*>(p.dy)[i];
+    float g[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = rs * bf2f(dv[e]);
+    if (p.da) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        o[e] = f2bf(p.thresh_a ? (drop_keep(sa, i * 8 + e, p.thresh_a) ? g[e] * p.inv_keep_a : 0.f) : g[e]);
+      reinterpret_cast<bf16x8*>(p.da)[i] = o;
+    }
+    if (p.db) {
+      bf16x8 bv;
+      if (p.dalpha) bv = reinterpret_cast<const bf16x8*>(p.b)[i];
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float m = p.thresh_b ? (drop_keep(sb, i * 8 + e, p.thresh_b) ? p.inv_keep_b : 0.f) : 1.f;
+        o[e] = f2bf(al * m * g[e]);
+        if (p.dalpha) acc += g[e] * m * bf2f(bv[e]);
+      }
+      reinterpret_cast<bf16x8*>(p.db)[i] = o;
+    }
+  }
+  if (p.dalpha) {
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(p.dalpha, red[0] + red[1] + red[2] + red[3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ y, size_t nvec) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+    const float4 a = *reinterpret_cast<const float4*>(x + i * 8), b = *reinterpret_cast<const float4*>(x + i * 8 + 4);
+    bf16x8 o = {f2bf(a.x), f2bf(a.y), f2bf(a.z), f2bf(a.w), f2bf(b.x), f2bf(b.y), f2bf(b.z), f2bf(b.w)};
+    reinterpret_cast<bf16x8*>(y)[i] = o;
+  }
+}
+
 inline int ew_grid(size_t nvec) {
   size_t g = (nvec + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -379,6 +505,55 @@ extern "C" int fiber_rowscale_add_bf16(const void* r, const void* x, const float
   if (n <= 0) return FIBER_OK;
   if ((n & 7) || (per_sample & 7)) return FIBER_EINVAL;
   hipLaunchKernelGGL(rowscale_add_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, stream, (const bf16*)r, (const bf16*)x, scale, (bf16*)out, (size_t)n / 8, (size_t)per_sample / 8);
+  FIBER_CHECK_LAUNCH();
+  return FIBER_OK;
+}
+
+// out = res + rowscale[sample] * (drop_a(a) + alpha * drop_b(b)); see stream_add_kernel.  res_kind: 0 none, 1 bf16, 2 fp32.
+// p_a / p_b: dropout probabilities of the two branches (0 = off) with by-value keys seed_a / seed_b (+ *seed_base if non-NULL).
+// out32 / out16: fp32 result and / or its bf16 rounding (at least one).  n % 8 == 0, per_sample % 8 == 0 when rowscale is given.
+extern "C" int fiber_stream_add(const void* res, int res_kind, const void* a, const void* b, const float* alpha,
+                                const float* rowscale, long per_sample, float p_a, uint64_t seed_a, float p_b, uint64_t seed_b,
+                                const uint64_t* seed_base, float* out32, void* out16, long n, hipStream_t stream) {
+  if (n <= 0) return FIBER_OK;
+  if ((n & 7) || !a || (!out32 && !out16) || (res_kind && !res) || res_kind < 0 || res_kind > 2) return FIBER_EINVAL;
+  if (rowscale && (per_sample <= 0 || (per_sample & 7))) return FIBER_EINVAL;
+  if (p_a < 0.f || p_a >= 1.f || p_b < 0.f || p_b >= 1.f || (p_b > 0.f && !b)) return FIBER_EINVAL;
+  StreamAddArgs p{res, (const bf16*)a, (const bf16*)b, alpha, rowscale, out32, (bf16*)out16, (size_t)n / 8,
+                  rowscale ? (size_t)per_sample / 8 : (size_t)1, seed_a, seed_b, seed_base,
+                  (uint32_t)((double)p_a * 4294967296.0), (uint32_t)((double)p_b * 4294967296.0), 1.f / (1.f - p_a), 1.f / (1.f - p_b)};
+  const int grid = ew_grid(p.nvec);
+  if (res_kind == 2) hipLaunchKernelGGL(stream_add_kernel<2>, dim3(grid), dim3(256), 0, stream, p);
+  else if (res_kind == 1) hipLaunchKernelGGL(stream_add_kernel<1>, dim3(grid), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(stream_add_kernel<0>, dim3(grid), dim3(256), 0, stream, p);
+  FIBER_CHECK_LAUNCH();
+  return FIBER_OK;
+}
+
+// Branch gradients of fiber_stream_add: da (optional), db (optional; needs b when dalpha is wanted), dalpha (optional fp32
+// scalar, accumulated: zero it first).  dy bf16 [n].
+extern "C" int fiber_stream_add_bwd(const void* dy, const void* b, const float* alpha, const float* rowscale, long per_sample,
+                                    float p_a, uint64_t seed_a, float p_b, uint64_t seed_b, const uint64_t* seed_base, void* da,
+                                    void* db, float* dalpha, long n, hipStream_t stream) {
+  if (n <= 0) return FIBER_OK;
+  if ((n & 7) || !dy || (dalpha && (!b || !db))) return FIBER_EINVAL;
+  if (rowscale && (per_sample <= 0 || (per_sample & 7))) return FIBER_EINVAL;
+  if (p_a < 0.f || p_a >= 1.f || p_b < 0.f || p_b >= 1.f) return FIBER_EINVAL;
+  StreamAddBwdArgs p{(const bf16*)dy, (const bf16*)b, alpha, rowscale, (bf16*)da, (bf16*)db, dalpha, (size_t)n / 8,
+                     rowscale ? (size_t)per_sample / 8 : (size_t)1, seed_a, seed_b, seed_base,
+                     (uint32_t)((double)p_a * 4294967296.0), (uint32_t)((double)p_b * 4294967296.0), 1.f / (1.f - p_a), 1.f / (1.f - p_b)};
+  int grid = ew_grid(p.nvec);
+  if (dalpha && grid > 512) grid = 512;                  // one atomic per workgroup
+  hipLaunchKernelGGL(stream_add_bwd_kernel, dim3(grid), dim3(256), 0, stream, p);
+  FIBER_CHECK_LAUNCH();
+  return FIBER_OK;
+}
+
+// y (bf16) = x (fp32), n % 8 == 0: the bf16 shadow of an fp32 stream tensor where a GEMM consumes it and no producer wrote one
+extern "C" int fiber_cast_f32_bf16(const float* x, void* y, long n, hipStream_t stream) {
+  if (n <= 0) return FIBER_OK;
+  if (n & 7) return FIBER_EINVAL;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, stream, x, (bf16*)y, (size_t)n / 8);
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }

@@ -152,6 +152,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] *= rsc;
         }
+        if (a.act & 0x800) {                              // fp32 residual stream (EPI 3 of gemm_epilogue.h): branch rounded once
+          const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.R) + (size_t)m * a.ldr + n);
+          const float4 o = {bf2f(f2bf(v[0])) + r.x, bf2f(f2bf(v[1])) + r.y, bf2f(f2bf(v[2])) + r.z, bf2f(f2bf(v[3])) + r.w};
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.Ypre) + (size_t)m * a.ldy + n) = o;
+          if (a.Y) {
+            bf16x4 ob = {f2bf(o.x), f2bf(o.y), f2bf(o.z), f2bf(o.w)};
+            *reinterpret_cast<bf16x4*>(a.Y + (size_t)m * a.ldy + n) = ob;
+          }
+          continue;
+        }
         if (a.R) {
           const bf16x4 r = *reinterpret_cast<const bf16x4*>(a.R + (size_t)m * a.ldr + n);
 #pragma unroll
@@ -839,7 +849,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_wide_persist2_kernel(Gem
 // and the residual-without-DropPath forms spill 60-120 VGPRs around its longer live ranges and stay on v3; gelu' * aux without
 // column sums (the caller takes the bias gradient from the weight-gradient kernel) is served.
 template <int EPI, bool R, bool RS>
-constexpr bool kV4Ok = (EPI == 0 && (!R || RS)) || (EPI == 1 && !R) || EPI == 2;
+constexpr bool kV4Ok = (EPI == 0 && (!R || RS)) || (EPI == 1 && !R) || EPI == 2 || (EPI == 3 && RS);
 
 }  // namespace
 
@@ -860,6 +870,8 @@ extern "C" int fiber_gemm_row_tile(int M, int N, int K) {
 // act | 0x100 (act 0 only, no residual): Y is fp32 [M, ldy] -- narrow outputs whose consumers need more than bf16 (the
 // offset predictor of the deformable convolutions: sampling positions);
 // rowscale: fp32[M / rows_per_sample] or NULL (per-sample DropPath factor on the branch, swin_transformer.py:390-391)
+// act | 0x800 (act 0, residual required): the fp32 RESIDUAL STREAM form -- `residual` is fp32 [M, ldr], the sum goes to `Ypre`
+// viewed as fp32 [M, ldy] and, if Y is non-NULL, once more as bf16 to Y (the shadow GEMM consumers of the stream read);
 // (Ypre, if non-NULL with act=1, receives the pre-activation for the backward pass).  K % 8 == 0, N % 4 == 0,
 // all leading dimensions multiples of 8 elements (16-byte rows).
 extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bias, const void* residual, void* Y,
@@ -878,6 +890,7 @@ extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bia
   const int mode = act & 0xff;
   if ((mode == 2 || colpart) && !((K % 64 == 0) && (N % 8 == 0) && (ldy % 8 == 0))) return FIBER_EINVAL;   // LDS-DMA kernels only
   if (mode == 2 && residual) return FIBER_EINVAL;
+  if ((act & 0x800) && (mode != 0 || !residual || !Ypre || colpart || (act & 0x100))) return FIBER_EINVAL;
   if (colpart && mode != 2 && !(act & 0x600)) return FIBER_EINVAL;
   const bool v2 = (K % 64 == 0) && (N % 8 == 0) && (ldy % 8 == 0) && (!residual || ldr % 8 == 0) && !getenv("FIBER_GEMM_V1");
   // Tile choice.  256x256 (K step 32, two wave groups half a tile apart) whenever N is a multiple of 256 and there are
@@ -920,6 +933,7 @@ extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bia
   }
   if (shape == 4) hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), dim3((unsigned)big), dim3(256), 0, stream, a);
   else if (shape == 5) hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), dim3((unsigned)small), dim3(256), 0, stream, a);
+  else if (act & 0x800) { if (rowscale) FIBER_LAUNCH_EPI(3, true, true); else FIBER_LAUNCH_EPI(3, true, false); }
   else if (mode == 2) { if (rowscale) FIBER_LAUNCH_EPI(2, false, true); else FIBER_LAUNCH_EPI(2, false, false); }
   else if (mode == 1 && residual) { if (rowscale) FIBER_LAUNCH_EPI(1, true, true); else FIBER_LAUNCH_EPI(1, true, false); }
   else if (mode == 1) { if (rowscale) FIBER_LAUNCH_EPI(1, false, true); else FIBER_LAUNCH_EPI(1, false, false); }

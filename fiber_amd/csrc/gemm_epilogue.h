@@ -23,6 +23,10 @@ __device__ __forceinline__ int swz(int row, int chunk) { return (row * 8 + (chun
 // tools/gemm_dbg.py) -- as much as the tile's MFMAs at K = 512.
 //   EPI 0: Y = rowscale * (acc + bias) + R          (HAS_RS / HAS_R)
 //   EPI 1: Ypre = acc + bias (optional);  Y = rowscale * gelu(bf16(acc + bias))
+//   EPI 3: EPI 0 on the fp32 RESIDUAL STREAM (HAS_R must be set): R is fp32 [M, ldr], the sum rowscale * (acc + bias) + R is
+//          stored in fp32 at Ypre (viewed as float [M, ldy]) and, if Y is non-NULL, once more rounded to bf16 at Y -- the
+//          "shadow" that GEMM consumers of the stream read (ops.py: stream pair).  The branch goes through the bf16 staging
+//          slab like every other output (rounded once, relative to the BRANCH); the stream itself is never rounded.
 //   EPI 2: Y = rowscale * acc * gelu'(aux);  optional per-row-tile column sums of Y (colpart)   (HAS_RS: the DropPath factor
 //          of the branch whose backward this is -- (s dY) W2^T = s (dY W2^T), so the scale rides in the epilogue)
 //   FULL:  the tile lies entirely inside [M, N] (no row / column predicates)
@@ -62,7 +66,8 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x16 (&acc)[B
   const int erow = tid / CPR, echunk = tid % CPR;
   const int n_out = tn0 + echunk * 8;
   const bool col_ok = FULL || n_out < a.N;
-  constexpr bool SIDE = HAS_R || EPI == 2;
+  constexpr bool E0 = EPI == 0 || EPI == 3;            // bias / DropPath scale / residual family
+  constexpr bool SIDE = (HAS_R && EPI != 3) || EPI == 2;
   const bf16* sidep = EPI == 2 ? a.aux : a.R;
   const size_t sideld = EPI == 2 ? a.ldaux : a.ldr;
   const bool has_bias = a.bias != nullptr;
@@ -89,7 +94,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x16 (&acc)[B
       if (ROUNDS == 1 || (wm * WTM + i * 32) / HM == h) {          // this wave's 32-row slab i belongs to round h
         const int ml = wm * WTM + i * 32 + (lane & 31);
         float rsc = 1.f;
-        if constexpr (EPI == 0 && HAS_RS) rsc = a.rowscale[min(tm0 + ml, a.M - 1) / a.rows_per_sample];
+        if constexpr (E0 && HAS_RS) rsc = a.rowscale[min(tm0 + ml, a.M - 1) / a.rows_per_sample];
         bf16* crow = Cs + (ml - h * HM) * CLD + wn * WTN + (lane >> 5) * 4;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -103,7 +108,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x16 (&acc)[B
               const float4 bb = *reinterpret_cast<const float4*>(bias_s + nl);
               v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
             }
-            if constexpr (EPI == 0 && HAS_RS) {
+            if constexpr (E0 && HAS_RS) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] *= rsc;
             }
@@ -129,6 +134,22 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x16 (&acc)[B
             v = gelu8(v, HAS_RS ? prs[pp] : 1.f);
           } else if constexpr (EPI == 2) {
             v = gelu_grad_mul8(v, side[pp], HAS_RS ? prs[pp] : 1.f);
+          }
+          if constexpr (EPI == 3) {                      // fp32 residual stream: R and the sum in fp32 (+ bf16 shadow)
+            const size_t row = (size_t)(mbase + pp * RPP);
+            const float* rp = reinterpret_cast<const float*>(a.R) + row * a.ldr + n_out;
+            float* op = reinterpret_cast<float*>(a.Ypre) + row * a.ldy + n_out;
+            const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+            const float4 o0 = {bf2f(v[0]) + r0.x, bf2f(v[1]) + r0.y, bf2f(v[2]) + r0.z, bf2f(v[3]) + r0.w};
+            const float4 o1 = {bf2f(v[4]) + r1.x, bf2f(v[5]) + r1.y, bf2f(v[6]) + r1.z, bf2f(v[7]) + r1.w};
+            *reinterpret_cast<float4*>(op) = o0;
+            *reinterpret_cast<float4*>(op + 4) = o1;
+            if (a.Y) {
+              v[0] = f2bf(o0.x); v[1] = f2bf(o0.y); v[2] = f2bf(o0.z); v[3] = f2bf(o0.w);
+              v[4] = f2bf(o1.x); v[5] = f2bf(o1.y); v[6] = f2bf(o1.z); v[7] = f2bf(o1.w);
+              st_out(reinterpret_cast<bf16x8*>(yp + pp * ystep), v);
+            }
+            continue;
           }
           if constexpr (HAS_R) {
 #pragma unroll
@@ -187,7 +208,8 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& a, f32x16 (&acc)[T
   const int lane = threadIdx.x & 63;
   const int wr = lane & 31, wh = lane >> 5;              // staging: row of the slab, which 4-column half of an 8-column group
   const int rr = lane >> 3, rc = lane & 7;               // read-back: row inside an 8-row pass, 16-byte chunk of the 128-B row
-  constexpr bool SIDE = HAS_R || EPI == 2;
+  constexpr bool E0 = EPI == 0 || EPI == 3;
+  constexpr bool SIDE = (HAS_R && EPI != 3) || EPI == 2;
   const bf16* sidep = EPI == 2 ? a.aux : a.R;
   const size_t sideld = EPI == 2 ? a.ldaux : a.ldr;
   const int n_out = n0w + rc * 8;
@@ -199,14 +221,14 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& a, f32x16 (&acc)[T
   // write -> read -> return latency of a slab hides behind the previous slab's VALU work and store issue.
   auto stage = [&](int i) {
     float rsc = 1.f;
-    if constexpr (EPI == 0 && HAS_RS) rsc = a.rowscale[min(m0w + i * 32 + wr, a.M - 1) / a.rows_per_sample];
+    if constexpr (E0 && HAS_RS) rsc = a.rowscale[min(m0w + i * 32 + wr, a.M - 1) / a.rows_per_sample];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         bf16x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = f2bf((EPI == 0 && HAS_RS) ? acc[i][j][q * 4 + e] * rsc : acc[i][j][q * 4 + e]);
+        for (int e = 0; e < 4; ++e) o[e] = f2bf((E0 && HAS_RS) ? acc[i][j][q * 4 + e] * rsc : acc[i][j][q * 4 + e]);
         *reinterpret_cast<bf16x4*>(wbase + (((j * 4 + q) ^ wsw) << 3)) = o;
       }
   };
@@ -232,10 +254,26 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& a, f32x16 (&acc)[T
     if (FULL || mrow < a.M) sdp = *reinterpret_cast<const bf16x8*>(sidep + (size_t)mrow * sideld + n_out);
     if constexpr (HAS_RS) prp = a.rowscale[min(mrow, a.M - 1) / a.rows_per_sample];
   };
-  constexpr bool PREF = EPI != 2;                        // side rows a whole slab ahead; gelu' * aux (register budget): pass by pass
+  // fp32 residual rows (EPI 3): two 16-byte loads per pass, requested one pass ahead (rolling registers)
+  const float* r32 = reinterpret_cast<const float*>(a.R);
+  float* y32 = reinterpret_cast<float*>(a.Ypre);
+  float4 rf[EPI == 3 ? 4 : 1][2];
+  auto load_r32 = [&](int i, int pp) {
+    const int mrow = m0w + i * 32 + rr + pp * 8;
+    if (FULL || mrow < a.M) {
+      const float* rp = r32 + (size_t)mrow * a.ldr + n_out;
+      rf[pp][0] = *reinterpret_cast<const float4*>(rp);
+      rf[pp][1] = *reinterpret_cast<const float4*>(rp + 4);
+    }
+  };
+  constexpr bool PREF = EPI != 2 && EPI != 3;            // side rows a whole slab ahead; gelu' * aux / fp32 rows (register budget): pass by pass
   bf16x8 cur[4], sd[4], sdn[PREF ? 4 : 1];
   float prs[4] = {1.f, 1.f, 1.f, 1.f}, prsn[4] = {1.f, 1.f, 1.f, 1.f};
   load_side(0, sd, prs);
+  if constexpr (EPI == 3) {
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) load_r32(0, pp);
+  }
   stage(0);
   asm volatile("" ::: "memory");
 #pragma unroll
@@ -261,17 +299,31 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& a, f32x16 (&acc)[T
         } else if constexpr (EPI == 2) {
           v = gelu_grad_mul8(v, sd[pp], HAS_RS ? prs[pp] : 1.f);
         }
-        if constexpr (HAS_R) {
+        if constexpr (EPI == 3) {
+          const float4 o0 = {bf2f(v[0]) + rf[pp][0].x, bf2f(v[1]) + rf[pp][0].y, bf2f(v[2]) + rf[pp][0].z, bf2f(v[3]) + rf[pp][0].w};
+          const float4 o1 = {bf2f(v[4]) + rf[pp][1].x, bf2f(v[5]) + rf[pp][1].y, bf2f(v[6]) + rf[pp][1].z, bf2f(v[7]) + rf[pp][1].w};
+          float* op = y32 + (size_t)(mrow + pp * 8) * a.ldy + n_out;
+          *reinterpret_cast<float4*>(op) = o0;
+          *reinterpret_cast<float4*>(op + 4) = o1;
+          if (a.Y) {
+            v[0] = f2bf(o0.x); v[1] = f2bf(o0.y); v[2] = f2bf(o0.z); v[3] = f2bf(o0.w);
+            v[4] = f2bf(o1.x); v[5] = f2bf(o1.y); v[6] = f2bf(o1.z); v[7] = f2bf(o1.w);
+            st_out(reinterpret_cast<bf16x8*>(yp + (size_t)pp * 8 * a.ldy), v);
+          }
+        } else {
+          if constexpr (HAS_R) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(sd[pp][e]));
+            for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(sd[pp][e]));
+          }
+          st_out(reinterpret_cast<bf16x8*>(yp + (size_t)pp * 8 * a.ldy), v);
         }
-        st_out(reinterpret_cast<bf16x8*>(yp + (size_t)pp * 8 * a.ldy), v);
       }
       if constexpr (HAS_R || EPI == 2) __builtin_amdgcn_sched_barrier(0);     // one pass at a time (keeps the residual variants out of scratch)
       if (i + 1 < TM) {                                  // the register just drained takes the same pass of the next slab
         asm volatile("" ::: "memory");
         cur[pp] = read_pass(pp);
-        if constexpr (PREF) { sd[pp] = sdn[pp]; prs[pp] = prsn[pp]; }
+        if constexpr (EPI == 3) load_r32(i + 1, pp);
+        else if constexpr (PREF) { sd[pp] = sdn[pp]; prs[pp] = prsn[pp]; }
         else load_side_pass(i + 1, pp, sd[pp], prs[pp]);  // rolling: the register just consumed takes the same pass of the next slab
       }
     }

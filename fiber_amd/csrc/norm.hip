@@ -32,11 +32,15 @@ __device__ __forceinline__ float group_sum(float v) {
 
 // LPR lanes cooperate on one row (64/LPR rows per wave, so narrow rows such as C=128 still use all 64 lanes);
 // NV 16-byte vectors per lane (NV > 1 only when LPR == 64).
-template <int LPR, int NV, bool MERGE>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
+// X32: x is the fp32 residual stream (ops.py "stream pair": fp32 payload + bf16 shadow) instead of a bf16 tensor;  y32 (optional):
+// the output is ALSO stored in fp32 -- RoBERTa is post-LN, its LayerNorm output is the next residual (roberta.py:485,422).
+template <int LPR, int NV, bool MERGE, bool X32>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ xv, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16* __restrict__ y,
-                                                     float* __restrict__ mean, float* __restrict__ rstd, int rows,
-                                                     int C, float eps, MergeMap mm) {
+                                                     float* __restrict__ y32, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, int rows, int C, float eps, MergeMap mm) {
+  const bf16* x = reinterpret_cast<const bf16*>(xv);
+  const float* xf = reinterpret_cast<const float*>(xv);
   constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, gl = lane % LPR;
@@ -58,9 +62,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
       const int vi = gl + i * LPR;
       if (rok && vi < nvec) {
         const size_t off = MERGE ? mm.src(row, vi * 8) : (size_t)row * C + vi * 8;
-        const bf16x8 t = *reinterpret_cast<const bf16x8*>(x + off);
+        if constexpr (X32) {
+          const float4 t0 = *reinterpret_cast<const float4*>(xf + off), t1 = *reinterpret_cast<const float4*>(xf + off + 4);
+          v[i][0] = t0.x; v[i][1] = t0.y; v[i][2] = t0.z; v[i][3] = t0.w; v[i][4] = t1.x; v[i][5] = t1.y; v[i][6] = t1.z; v[i][7] = t1.w;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { v[i][e] = bf2f(t[e]); s += v[i][e]; }
+          for (int e = 0; e < 8; ++e) s += v[i][e];
+        } else {
+          const bf16x8 t = *reinterpret_cast<const bf16x8*>(x + off);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { v[i][e] = bf2f(t[e]); s += v[i][e]; }
+        }
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
@@ -80,23 +91,31 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x,
       const int vi = gl + i * LPR;
       if (rok && vi < nvec) {
         bf16x8 o;
+        float of[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f2bf((v[i][e] - mu) * rs * g[i][e] + b[i][e]);
+        for (int e = 0; e < 8; ++e) { of[e] = (v[i][e] - mu) * rs * g[i][e] + b[i][e]; o[e] = f2bf(of[e]); }
         *reinterpret_cast<bf16x8*>(y + (size_t)row * C + vi * 8) = o;
+        if (y32) {
+          float* yp = y32 + (size_t)row * C + vi * 8;
+          *reinterpret_cast<float4*>(yp) = float4{of[0], of[1], of[2], of[3]};
+          *reinterpret_cast<float4*>(yp + 4) = float4{of[4], of[5], of[6], of[7]};
+        }
       }
     }
   }
 }
 
 // dx = rstd * (dy*g - mean_c(dy*g) - xhat * mean_c(dy*g*xhat)); one fp32 partial row of dgamma/dbeta per wave.
-template <int LPR, int NV, bool MERGE>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+template <int LPR, int NV, bool MERGE, bool X32>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const void* __restrict__ xv,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const bf16* __restrict__ dres,
                                                      bf16* __restrict__ dx,
                                                      float* __restrict__ part /*[grid*4 waves][2][C]*/, int rows, int C,
                                                      MergeMap mm) {
   constexpr int RPW = 64 / LPR;
+  const bf16* x = reinterpret_cast<const bf16*>(xv);
+  const float* xf = reinterpret_cast<const float*>(xv);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, gl = lane % LPR;
   const int nvec = C >> 3;
@@ -118,12 +137,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
       const int vi = gl + i * LPR;
       if (rok && vi < nvec) {
         const size_t off = MERGE ? mm.src(row, vi * 8) : (size_t)row * C + vi * 8;
-        const bf16x8 tx = *reinterpret_cast<const bf16x8*>(x + off);
+        float xv8[8];
+        if constexpr (X32) {
+          const float4 t0 = *reinterpret_cast<const float4*>(xf + off), t1 = *reinterpret_cast<const float4*>(xf + off + 4);
+          xv8[0] = t0.x; xv8[1] = t0.y; xv8[2] = t0.z; xv8[3] = t0.w; xv8[4] = t1.x; xv8[5] = t1.y; xv8[6] = t1.z; xv8[7] = t1.w;
+        } else {
+          const bf16x8 tx = *reinterpret_cast<const bf16x8*>(x + off);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xv8[e] = bf2f(tx[e]);
+        }
         const bf16x8 td = *reinterpret_cast<const bf16x8*>(dy + (size_t)row * C + vi * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float d = bf2f(td[e]);
-          xh[i][e] = (bf2f(tx[e]) - mu) * rs;
+          xh[i][e] = (xv8[e] - mu) * rs;
           dg[i][e] = d * g[i][e];
           s1 += dg[i][e];
           s2 += dg[i][e] * xh[i][e];
@@ -212,22 +239,22 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
 
 inline int rows_per_wave(int C) { const int nvec = C >> 3; return nvec <= 8 ? 8 : nvec <= 16 ? 4 : nvec <= 32 ? 2 : 1; }
 
-template <bool MERGE>
-int launch_fwd(const bf16* x, const float* g, const float* b, bf16* y, float* mean, float* rstd, int rows, int C,
+template <bool MERGE, bool X32>
+int launch_fwd(const void* x, const float* g, const float* b, bf16* y, float* y32, float* mean, float* rstd, int rows, int C,
                float eps, MergeMap mm, hipStream_t st) {
   const int need = cdiv(rows, 4 * rows_per_wave(C));
   const int grid = need < 4096 ? need : 4096;
-#define FWD(LPR, NV, ...) hipLaunchKernelGGL((ln_fwd_kernel<LPR, NV, MERGE>), dim3(grid), dim3(256), 0, st, __VA_ARGS__)
-  LN_DISPATCH(FWD, x, g, b, y, mean, rstd, rows, C, eps, mm);
+#define FWD(LPR, NV, ...) hipLaunchKernelGGL((ln_fwd_kernel<LPR, NV, MERGE, X32>), dim3(grid), dim3(256), 0, st, __VA_ARGS__)
+  LN_DISPATCH(FWD, x, g, b, y, y32, mean, rstd, rows, C, eps, mm);
 #undef FWD
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }
 
-template <bool MERGE>
-int launch_bwd(const bf16* dy, const bf16* x, const float* g, const float* mean, const float* rstd, const bf16* dres,
+template <bool MERGE, bool X32>
+int launch_bwd(const bf16* dy, const void* x, const float* g, const float* mean, const float* rstd, const bf16* dres,
                bf16* dx, float* dgamma, float* dbeta, float* ws, int grid, int rows, int C, MergeMap mm, hipStream_t st) {
-#define BWD(LPR, NV, ...) hipLaunchKernelGGL((ln_bwd_kernel<LPR, NV, MERGE>), dim3(grid), dim3(256), 0, st, __VA_ARGS__)
+#define BWD(LPR, NV, ...) hipLaunchKernelGGL((ln_bwd_kernel<LPR, NV, MERGE, X32>), dim3(grid), dim3(256), 0, st, __VA_ARGS__)
   LN_DISPATCH(BWD, dy, x, g, mean, rstd, dres, dx, ws, rows, C, mm);
 #undef BWD
   FIBER_CHECK_LAUNCH();
@@ -252,7 +279,17 @@ extern "C" int fiber_layernorm_fwd_bf16(const void* x, const float* gamma, const
                                         float* rstd, int rows, int C, float eps, hipStream_t stream) {
   if (rows <= 0) return FIBER_OK;
   if (C & 7) return FIBER_EINVAL;
-  return launch_fwd<false>((const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, rows, C, eps, MergeMap{0, 0, 0}, stream);
+  return launch_fwd<false, false>(x, gamma, beta, (bf16*)y, nullptr, mean, rstd, rows, C, eps, MergeMap{0, 0, 0}, stream);
+}
+
+// The same for the fp32 residual stream.  flags bit 0: x is fp32 [rows, C] (else bf16).  y32 (optional): fp32 copy of the output
+// next to the bf16 one (post-LN text stack: the LayerNorm output is the next residual, roberta.py:485,422).
+extern "C" int fiber_layernorm_fwd_stream(const void* x, const float* gamma, const float* beta, void* y, float* y32, float* mean,
+                                          float* rstd, int rows, int C, float eps, int flags, hipStream_t stream) {
+  if (rows <= 0) return FIBER_OK;
+  if (C & 7) return FIBER_EINVAL;
+  if (flags & 1) return launch_fwd<false, true>(x, gamma, beta, (bf16*)y, y32, mean, rstd, rows, C, eps, MergeMap{0, 0, 0}, stream);
+  return launch_fwd<false, false>(x, gamma, beta, (bf16*)y, y32, mean, rstd, rows, C, eps, MergeMap{0, 0, 0}, stream);
 }
 
 extern "C" int fiber_layernorm_bwd_bf16(const void* dy, const void* x, const float* gamma, const float* mean,
@@ -260,8 +297,21 @@ extern "C" int fiber_layernorm_bwd_bf16(const void* dy, const void* x, const flo
                                         float* workspace, int rows, int C, hipStream_t stream) {
   if (rows <= 0) return FIBER_OK;
   if (C & 7) return FIBER_EINVAL;
-  return launch_bwd<false>((const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, workspace,
-                           fiber_layernorm_bwd_grid(rows), rows, C, MergeMap{0, 0, 0}, stream);
+  return launch_bwd<false, false>((const bf16*)dy, x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, workspace,
+                                  fiber_layernorm_bwd_grid(rows), rows, C, MergeMap{0, 0, 0}, stream);
+}
+
+// Backward with the SAVED INPUT in fp32 (flags bit 0; the fp32 residual stream): gradients stay bf16 (dy, dres, dx).
+extern "C" int fiber_layernorm_bwd_stream(const void* dy, const void* x, const float* gamma, const float* mean,
+                                          const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                                          float* workspace, int rows, int C, int flags, hipStream_t stream) {
+  if (rows <= 0) return FIBER_OK;
+  if (C & 7) return FIBER_EINVAL;
+  if (flags & 1)
+    return launch_bwd<false, true>((const bf16*)dy, x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, workspace,
+                                   fiber_layernorm_bwd_grid(rows), rows, C, MergeMap{0, 0, 0}, stream);
+  return launch_bwd<false, false>((const bf16*)dy, x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, workspace,
+                                  fiber_layernorm_bwd_grid(rows), rows, C, MergeMap{0, 0, 0}, stream);
 }
 
 // PatchMerging front half: y[b,(i,j),:] = LN(concat(x[2i,2j], x[2i+1,2j], x[2i,2j+1], x[2i+1,2j+1])) over 4C.
@@ -269,8 +319,17 @@ extern "C" int fiber_layernorm_bwd_bf16(const void* dy, const void* x, const flo
 extern "C" int fiber_patch_merge_ln_fwd_bf16(const void* x, const float* gamma, const float* beta, void* y, float* mean,
                                              float* rstd, int B, int H, int W, int C, float eps, hipStream_t stream) {
   if ((C & 7) || (H & 1) || (W & 1)) return FIBER_EINVAL;
-  return launch_fwd<true>((const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, B * (H / 2) * (W / 2), 4 * C, eps,
-                          MergeMap{H, W, C}, stream);
+  return launch_fwd<true, false>(x, gamma, beta, (bf16*)y, nullptr, mean, rstd, B * (H / 2) * (W / 2), 4 * C, eps,
+                                 MergeMap{H, W, C}, stream);
+}
+
+// PatchMerging on the fp32 residual stream (flags bit 0: x is fp32 [B, H*W, C]); the output stays bf16 (it feeds the GEMM).
+extern "C" int fiber_patch_merge_ln_fwd_stream(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                               float* rstd, int B, int H, int W, int C, float eps, int flags, hipStream_t stream) {
+  if ((C & 7) || (H & 1) || (W & 1)) return FIBER_EINVAL;
+  const int rows = B * (H / 2) * (W / 2);
+  if (flags & 1) return launch_fwd<true, true>(x, gamma, beta, (bf16*)y, nullptr, mean, rstd, rows, 4 * C, eps, MergeMap{H, W, C}, stream);
+  return launch_fwd<true, false>(x, gamma, beta, (bf16*)y, nullptr, mean, rstd, rows, 4 * C, eps, MergeMap{H, W, C}, stream);
 }
 
 // Backward of the above: dy [B, H*W/4, 4C] -> dx [B, H*W, C] (every source element is written exactly once).
@@ -279,6 +338,18 @@ extern "C" int fiber_patch_merge_ln_bwd_bf16(const void* dy, const void* x, cons
                                              int B, int H, int W, int C, hipStream_t stream) {
   if ((C & 7) || (H & 1) || (W & 1)) return FIBER_EINVAL;
   const int rows = B * (H / 2) * (W / 2);
-  return launch_bwd<true>((const bf16*)dy, (const bf16*)x, gamma, mean, rstd, nullptr, (bf16*)dx, dgamma, dbeta, workspace,
-                          fiber_layernorm_bwd_grid(rows), rows, 4 * C, MergeMap{H, W, C}, stream);
+  return launch_bwd<true, false>((const bf16*)dy, x, gamma, mean, rstd, nullptr, (bf16*)dx, dgamma, dbeta, workspace,
+                                 fiber_layernorm_bwd_grid(rows), rows, 4 * C, MergeMap{H, W, C}, stream);
+}
+
+extern "C" int fiber_patch_merge_ln_bwd_stream(const void* dy, const void* x, const float* gamma, const float* mean,
+                                               const float* rstd, void* dx, float* dgamma, float* dbeta, float* workspace,
+                                               int B, int H, int W, int C, int flags, hipStream_t stream) {
+  if ((C & 7) || (H & 1) || (W & 1)) return FIBER_EINVAL;
+  const int rows = B * (H / 2) * (W / 2);
+  if (flags & 1)
+    return launch_bwd<true, true>((const bf16*)dy, x, gamma, mean, rstd, nullptr, (bf16*)dx, dgamma, dbeta, workspace,
+                                  fiber_layernorm_bwd_grid(rows), rows, 4 * C, MergeMap{H, W, C}, stream);
+  return launch_bwd<true, false>((const bf16*)dy, x, gamma, mean, rstd, nullptr, (bf16*)dx, dgamma, dbeta, workspace,
+                                 fiber_layernorm_bwd_grid(rows), rows, 4 * C, MergeMap{H, W, C}, stream);
 }

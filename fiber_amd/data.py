@@ -58,11 +58,12 @@ class DeviceImageTransform:
 
 def mlm_mask(ids, seed=None, mlm_probability=0.15, mask_id=50264, vocab=50265, special=(0, 2)):
     """ids int64 [B, S] (device) -> (text_ids_mlm, text_labels_mlm).  `special`: inclusive id range never masked (RoBERTa
-    <s> = 0, <pad> = 1, </s> = 2).  `seed`: 64-bit key of this batch (default: the next key of the path's RNG stream)."""
+    <s> = 0, <pad> = 1, </s> = 2).  `seed`: 64-bit key of this batch (default: the next key of the input pipeline's own stream,
+    ops.collate_seed(): by value and advancing per batch whether or not the training step is a captured hipGraph)."""
     ids = ids.contiguous()
     out, lab = torch.empty_like(ids), torch.empty_like(ids)
     if seed is None:
-        seed = ops.next_seed()
+        seed = ops.collate_seed()
     lib.call("fiber_mlm_mask_i64", lib.ptr(ids), lib.ptr(out), lib.ptr(lab), ids.numel(), int(seed) & (2 ** 64 - 1),
              int(mlm_probability * 2 ** 32), int(mask_id), int(vocab), int(special[0]), int(special[1]))
     return out, lab

@@ -19,6 +19,13 @@ SIGNATURES = {
     "fiber_gemm_tn_bf16": [P, P, P, P, P, I, I, I, I, I, P, I, F],
     "fiber_layernorm_fwd_bf16": [P, P, P, P, P, P, I, I, F],
     "fiber_layernorm_bwd_bf16": [P, P, P, P, P, P, P, P, P, P, I, I],
+    "fiber_layernorm_fwd_stream": [P, P, P, P, P, P, P, I, I, F, I],
+    "fiber_layernorm_bwd_stream": [P, P, P, P, P, P, P, P, P, P, I, I, I],
+    "fiber_patch_merge_ln_fwd_stream": [P, P, P, P, P, P, I, I, I, I, F, I],
+    "fiber_patch_merge_ln_bwd_stream": [P, P, P, P, P, P, P, P, P, I, I, I, I, I],
+    "fiber_stream_add": [P, I, P, P, P, P, L, F, U64, F, U64, P, P, P, L],
+    "fiber_stream_add_bwd": [P, P, P, P, L, F, U64, F, U64, P, P, P, P, L],
+    "fiber_cast_f32_bf16": [P, P, L],
     "fiber_patch_merge_ln_fwd_bf16": [P, P, P, P, P, P, I, I, I, I, F],
     "fiber_patch_merge_ln_bwd_bf16": [P, P, P, P, P, P, P, P, P, I, I, I, I],
     "fiber_window_attn_fwd_bf16": [P, P, P, P, I, I, I, I, I, I, I, I],

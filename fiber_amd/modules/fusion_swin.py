@@ -67,10 +67,7 @@ class WindowAttention(nn.Module):
         km = y_mask.reshape(B, S) if y_mask is not None else None
         yi = ops.mha(qi, kv[:, :C], kv[:, C:], km, B, self.num_heads, self.scale)
         yi = ops.linear(yi.view(B, L, C), self.proj_i2t.weight, self.proj_i2t.bias)
-        a = ops.scale_add(a, yi, self.alpha_i2t)
-        if rowscale is not None:
-            return ops.rowscale_add(shortcut, a, rowscale)
-        return ops.add(shortcut, a)
+        return ops.stream_add(shortcut, a, b=yi, alpha=self.alpha_i2t, rowscale=rowscale)
 
 
 class SwinTransformerBlock(nn.Module):

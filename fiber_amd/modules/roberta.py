@@ -38,9 +38,10 @@ class RobertaEmbeddings(nn.Module):
         self.register_buffer("position_ids", torch.arange(config.max_position_embeddings).expand((1, -1)))
 
     def forward(self, input_ids=None):
-        return ops.roberta_embed(input_ids, self.word_embeddings.weight, self.position_embeddings.weight,
-                                 self.token_type_embeddings.weight, self.LayerNorm.weight, self.LayerNorm.bias,
-                                 pad=self.padding_idx, eps=self.LayerNorm.eps, p_drop=self.dropout.p, training=self.training)
+        y = ops.roberta_embed(input_ids, self.word_embeddings.weight, self.position_embeddings.weight,
+                              self.token_type_embeddings.weight, self.LayerNorm.weight, self.LayerNorm.bias,
+                              pad=self.padding_idx, eps=self.LayerNorm.eps, p_drop=self.dropout.p, training=self.training)
+        return ops.start_stream(y)                          # the text residual stream begins (fp32 payload in fp32 mode)
 
 
 class RobertaSelfAttention(nn.Module):
@@ -85,8 +86,10 @@ class RobertaSelfOutput(nn.Module):
     def forward(self, hidden_states, residual=None):
         if residual is not None and not (self.training and self.dropout.p > 0):
             return ops.linear(hidden_states, self.dense.weight, self.dense.bias, residual=residual)
-        y = ops.dropout(ops.linear(hidden_states, self.dense.weight, self.dense.bias), self.dropout.p, self.training)
-        return y if residual is None else ops.add(y, residual)
+        y = ops.linear(hidden_states, self.dense.weight, self.dense.bias)
+        if residual is None:
+            return ops.dropout(y, self.dropout.p, self.training)
+        return ops.stream_add(residual, y, p_a=self.dropout.p, training=self.training)     # dropout + residual: one pass
 
 
 class RobertaAttention(nn.Module):
@@ -117,10 +120,13 @@ class RobertaOutput(nn.Module):
 
     def forward(self, hidden_states, input_tensor, last_norm=True):
         if self.training and self.dropout.p > 0:
-            h = ops.add(ops.dropout(ops.linear(hidden_states, self.dense.weight, self.dense.bias), self.dropout.p, True), input_tensor)
+            h = ops.stream_add(input_tensor, ops.linear(hidden_states, self.dense.weight, self.dense.bias), p_a=self.dropout.p)
         else:
             h = ops.linear(hidden_states, self.dense.weight, self.dense.bias, residual=input_tensor)
-        return ops.layernorm(h, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps) if last_norm else h
+        if not last_norm:
+            return h
+        # post-LN: this output is the next layer's residual -> it keeps an fp32 copy in fp32-stream mode
+        return ops.layernorm(h, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps, want_f32=ops.residual_fp32())
 
 
 class RobertaLayer(nn.Module):
@@ -140,9 +146,12 @@ class RobertaLayer(nn.Module):
         else:
             assert hasattr(self, "crossattention_t2i"), "layer built without cross-attention"
             a = self.attention(hidden_states, attention_mask)
-            c = self.crossattention_t2i(a, None, encoder_hidden_states)
-            a = ops.add(ops.scale_add(a, c, self.alpha_t2i), hidden_states)
-        a = ops.layernorm(a, ln.weight, ln.bias, ln.eps)
+            ca = self.crossattention_t2i
+            c = ca.self(a, None, encoder_hidden_states)
+            c = ops.linear(c, ca.output.dense.weight, ca.output.dense.bias)
+            # hidden + (a + alpha_t2i * dropout(c)) in one pass (roberta.py:474-485: RobertaSelfOutput's dropout, the gate, the residual)
+            a = ops.stream_add(hidden_states, a, b=c, alpha=self.alpha_t2i, p_b=ca.output.dropout.p, training=self.training)
+        a = ops.layernorm(a, ln.weight, ln.bias, ln.eps, want_f32=ops.residual_fp32())
         return (self.output(self.intermediate(a), a, last_norm=last_norm),)
 
 

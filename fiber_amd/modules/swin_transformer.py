@@ -56,7 +56,8 @@ class PatchEmbed(nn.Module):
 
     def forward(self, img):
         x = ops.patch_embed_proj(img, self.proj.weight, self.proj.bias)
-        return ops.layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        # the residual stream starts here: with config["residual_dtype"] = "fp32" the LayerNorm also emits its fp32 result
+        return ops.layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps, want_f32=ops.residual_fp32())
 
 
 class WindowAttention(nn.Module):
@@ -101,10 +102,10 @@ class WindowAttention(nn.Module):
         km = y_mask.reshape(B, S) if y_mask is not None else None
         yi = ops.mha(qi, kv[:, :C], kv[:, C:], km, B, self.num_heads, self.scale)
         yi = ops.linear(yi.view(B, L, C), self.proj_i2t.weight, self.proj_i2t.bias)
-        a = ops.scale_add(a, yi, self.alpha_i2t)
-        if rowscale is not None:
-            return ops.rowscale_add(shortcut, a, rowscale)
-        return a if shortcut is None else ops.add(shortcut, a)
+        if shortcut is None:
+            return ops.scale_add(a, yi, self.alpha_i2t)
+        # shortcut + DropPath(a + alpha_i2t * yi) in one pass (swin_transformer.py:259 and :390); keeps the stream's fp32 payload
+        return ops.stream_add(shortcut, a, b=yi, alpha=self.alpha_i2t, rowscale=rowscale)
 
 
 class SwinTransformerBlock(nn.Module):
@@ -151,7 +152,7 @@ class PatchMerging(nn.Module):
         B, L, C = x.shape
         assert L == H * W and H % 2 == 0 and W % 2 == 0
         z = ops.patch_merge_ln(x, self.norm.weight, self.norm.bias, H, W, self.norm.eps)
-        return ops.linear(z, self.reduction.weight)
+        return ops.start_stream(ops.linear(z, self.reduction.weight))      # a new stage's residual stream begins
 
 
 class BasicLayer(nn.Module):

@@ -157,13 +157,60 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# ---- fp32 residual stream ---------------------------------------------------------------------------------------------------
+# config["residual_dtype"] = "fp32" keeps the residual streams of both backbones (Swin: x = x + branch, reference
+# swin_transformer.py:388-391; RoBERTa: the LayerNorm inputs a + h / dense + input and the LayerNorm outputs that become the next
+# residual, roberta.py:485,417-423) in fp32 instead of rounding them to bf16 at every block.  A stream tensor then travels as a
+# PAIR: the bf16 tensor autograd sees (the "shadow": what GEMMs read, what gradients -- bf16 -- flow along) carrying the fp32
+# payload as the attribute `_f32`.  Ops that sit on the stream (layernorm_res / layernorm / patch_merge_ln read it; the proj / fc2 /
+# dense epilogues and stream_add write it) use the payload when it is there and fall back to the bf16 tensor when it is not (a
+# tensor that was cloned / sliced by a caller simply loses the extra precision).  Gradients stay bf16 either way.
+_RESIDUAL_FP32 = [os.environ.get("FIBER_RESIDUAL_DTYPE", "bf16").lower() in ("fp32", "float32")]
+
+
+def set_residual_dtype(dtype):
+    """"fp32" / torch.float32: new residual streams start in fp32 (see above); "bf16": the round-1/2 behaviour."""
+    _RESIDUAL_FP32[0] = dtype in ("fp32", "float32", torch.float32)
+
+
+def residual_fp32():
+    return _RESIDUAL_FP32[0]
+
+
+def f32_of(t):
+    """The fp32 payload of a stream tensor, or None."""
+    return getattr(t, "_f32", None) if t is not None else None
+
+
+def with_f32(t16, t32):
+    if t32 is not None:
+        t16._f32 = t32
+    return t16
+
+
+def start_stream(t16):
+    """A bf16 tensor that begins a residual stream (PatchMerging output, text embeddings): in fp32 mode attach its fp32 copy."""
+    if _RESIDUAL_FP32[0] and f32_of(t16) is None:
+        t16._f32 = t16.detach().float()
+    return t16
+
+
 def gemm_nt(x2, wb, bias=None, residual=None, act=0, want_pre=False, rowscale=None, rows_per_sample=0, aux=None,
-            want_colsum=False, out_fp32=False):
+            want_colsum=False, out_fp32=False, res32=None):
     """y = act(x2 @ wb^T + bias) + residual  on the HIP kernel.  x2 [M,K] bf16 (row stride may exceed K).
-    out_fp32 (plain / bias only): the result is stored in fp32."""
+    out_fp32 (plain / bias only): the result is stored in fp32.
+    res32 (fp32 [M, N], instead of `residual`): the fp32 residual-stream form -- returns (y16, y32): the sum in fp32 and its
+    bf16 shadow."""
     M, K = x2.shape
     N = wb.shape[0]
     assert x2.dtype == BF16 and wb.dtype == BF16 and x2.stride(1) == 1 and wb.stride(1) == 1
+    if res32 is not None:
+        assert res32.dtype == torch.float32 and res32.stride(1) == 1 and not act and residual is None and not want_colsum and not out_fp32
+        y16 = torch.empty((M, N), dtype=BF16, device=x2.device)
+        y32 = torch.empty((M, N), dtype=torch.float32, device=x2.device)
+        lib.call("fiber_gemm_nt_bf16", lib.ptr(x2), lib.ptr(wb), lib.ptr(bias), lib.ptr(res32), lib.ptr(y16), lib.ptr(y32),
+                 lib.ptr(rowscale), rows_per_sample, None, 0, None, M, N, K, x2.stride(0), wb.stride(0), N, res32.stride(0), 0x800)
+        return y16, y32
     y = torch.empty((M, N), dtype=torch.float32 if out_fp32 else BF16, device=x2.device)
     if out_fp32:
         assert not act and residual is None and not want_colsum
@@ -382,21 +429,31 @@ def _dgrad(dh, weight):
 
 
 class _Linear(torch.autograd.Function):
+    """Returns (y, y32): y32 is the fp32 payload of the output when `res32` (the fp32 payload of the residual) was given."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, act, rowscale, rs_value=None):
+    def forward(ctx, x, weight, bias, residual, act, rowscale, rs_value=None, res32=None):
         shp = x.shape
         x2 = _c(x).view(-1, shp[-1])
         wb = bf16_weight(weight)
-        r2 = _c(residual).view(-1, weight.shape[0]) if residual is not None else None
         need_pre = bool(act) and any(ctx.needs_input_grad[:3])
         rps = (x2.shape[0] // rowscale.numel()) if rowscale is not None else 0
-        y, pre = gemm_nt(x2, wb, bias, r2, act, need_pre, rowscale, rps)
+        oshp = (*shp[:-1], weight.shape[0])
+        if res32 is not None:
+            assert residual is not None and not act
+            y, y32 = gemm_nt(x2, wb, bias, None, 0, False, rowscale, rps, res32=_c(res32).view(-1, weight.shape[0]))
+            pre, y32 = None, y32.view(oshp)
+            ctx.mark_non_differentiable(y32)
+        else:
+            r2 = _c(residual).view(-1, weight.shape[0]) if residual is not None else None
+            y, pre = gemm_nt(x2, wb, bias, r2, act, need_pre, rowscale, rps)
+            y32 = None
         ctx.save_for_backward(x2, weight, pre, rowscale)
         ctx.act, ctx.has_bias, ctx.has_res, ctx.shp, ctx.rs_value = act, bias is not None, residual is not None, shp, rs_value
-        return y.view(*shp[:-1], weight.shape[0])
+        return y.view(oshp), y32
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dy32=None):
         x2, weight, pre, rowscale = ctx.saved_tensors
         dy2 = _c(dy).view(-1, weight.shape[0])
         dres = dy if ctx.has_res else None
@@ -426,7 +483,7 @@ class _Linear(torch.autograd.Function):
                     dw, db = dw
             elif need_db:
                 db = rowscale_colsum(dh, rowscale)[1]
-            return dx, dw, db, dres, None, None, None
+            return dx, dw, db, dres, None, None, None, None
         dx = _dgrad(dh, weight).view(ctx.shp) if ctx.needs_input_grad[0] else None
         if need_db and db is None and hint is not None and dh is dy2:
             db = hint                                  # produced by the kernel that wrote dy (window attention backward)
@@ -440,7 +497,7 @@ class _Linear(torch.autograd.Function):
             db = colsum(dh)
         if not need_db:
             db = None
-        return dx, dw, db, dres, None, None, None
+        return dx, dw, db, dres, None, None, None, None
 
 
 def linear(x, weight, bias=None, residual=None, act=None, rowscale=None, rowscale_value=None):
@@ -453,7 +510,8 @@ def linear(x, weight, bias=None, residual=None, act=None, rowscale=None, rowscal
             y = torch.nn.functional.gelu(y)
         assert rowscale is None
         return y + residual if residual is not None else y
-    return _Linear.apply(x, weight, bias, residual, 1 if act else 0, rowscale, rowscale_value)
+    y, y32 = _Linear.apply(x, weight, bias, residual, 1 if act else 0, rowscale, rowscale_value, f32_of(residual))
+    return with_f32(y, y32)
 
 
 class _MLP(torch.autograd.Function):
@@ -465,19 +523,26 @@ class _MLP(torch.autograd.Function):
     column-sum passes over the 4C-wide tensor disappear.  The remaining plain GEMMs (dX, dW1, dW2) use the library."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, residual, rowscale, rs_value=None):
+    def forward(ctx, x, w1, b1, w2, b2, residual, rowscale, rs_value=None, res32=None):
         shp = x.shape
         x2 = _c(x).view(-1, shp[-1])
-        r2 = _c(residual).view(-1, w2.shape[0]) if residual is not None else None
         g, h = gemm_nt(x2, bf16_weight(w1), b1, None, 1, True)
         rps = (x2.shape[0] // rowscale.numel()) if rowscale is not None else 0
-        y, _ = gemm_nt(g, bf16_weight(w2), b2, r2, 0, False, rowscale, rps)
+        oshp = (*shp[:-1], w2.shape[0])
+        if res32 is not None:                         # fp32 residual stream: (bf16 shadow, fp32 payload)
+            y, y32 = gemm_nt(g, bf16_weight(w2), b2, None, 0, False, rowscale, rps, res32=_c(res32).view(-1, w2.shape[0]))
+            y32 = y32.view(oshp)
+            ctx.mark_non_differentiable(y32)
+        else:
+            r2 = _c(residual).view(-1, w2.shape[0]) if residual is not None else None
+            y, _ = gemm_nt(g, bf16_weight(w2), b2, r2, 0, False, rowscale, rps)
+            y32 = None
         ctx.save_for_backward(x2, w1, w2, h, g, rowscale)
         ctx.has_res, ctx.shp, ctx.rs_value = residual is not None, shp, rs_value
-        return y.view(*shp[:-1], w2.shape[0])
+        return y.view(oshp), y32
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dy32=None):
         x2, w1, w2, h, g, rowscale = ctx.saved_tensors
         dy2 = _c(dy).view(-1, w2.shape[0])
         dres = dy if ctx.has_res else None
@@ -510,42 +575,78 @@ class _MLP(torch.autograd.Function):
             dw1, db1 = wgrad(dh, x2, want_bias=True)   # fc1 bias gradient = column sums of dH, from the same pass
         else:
             dw1 = wgrad(dh, x2)
-        return dx, dw1, db1, dw2, db2, dres, None, None
+        return dx, dw1, db1, dw2, db2, dres, None, None, None
 
 
 def mlp(x, w1, b1, w2, b2, residual=None, rowscale=None, rowscale_value=None):
-    return _MLP.apply(x, w1, b1, w2, b2, residual, rowscale, rowscale_value)
+    y, y32 = _MLP.apply(x, w1, b1, w2, b2, residual, rowscale, rowscale_value, f32_of(residual))
+    return with_f32(y, y32)
+
+
+def _ln_fwd(x2, x32, gamma, beta, eps, want_f32):
+    """LayerNorm rows of x2 (bf16) or of its fp32 payload x32 -> (y bf16, y32 or None, mean, rstd)."""
+    rows, C = x2.shape
+    y = torch.empty((rows, C), dtype=BF16, device=x2.device)
+    y32 = torch.empty((rows, C), dtype=torch.float32, device=x2.device) if want_f32 else None
+    mean = torch.empty(rows, dtype=torch.float32, device=x2.device)
+    rstd = torch.empty_like(mean)
+    if x32 is None and not want_f32:
+        lib.call("fiber_layernorm_fwd_bf16", lib.ptr(x2), lib.ptr(gamma), lib.ptr(beta), lib.ptr(y), lib.ptr(mean), lib.ptr(rstd), rows, C, eps)
+    else:
+        src = x32 if x32 is not None else x2
+        lib.call("fiber_layernorm_fwd_stream", lib.ptr(src), lib.ptr(gamma), lib.ptr(beta), lib.ptr(y), lib.ptr(y32), lib.ptr(mean),
+                 lib.ptr(rstd), rows, C, eps, 1 if x32 is not None else 0)
+    return y, y32, mean, rstd
+
+
+def _ln_bwd(dy2, xs, is32, gamma, mean, rstd, dr2):
+    """LayerNorm backward from the saved input xs (bf16, or fp32 when is32); dr2: residual-path gradient added into dx."""
+    rows, C = dy2.shape
+    dx = torch.empty((rows, C), dtype=BF16, device=dy2.device)
+    dg = torch.empty(C, dtype=torch.float32, device=dy2.device)
+    db = torch.empty_like(dg)
+    ws = torch.empty(lib.plain("fiber_layernorm_bwd_grid", rows) * 8 * C, dtype=torch.float32, device=dy2.device)
+    if is32:
+        lib.call("fiber_layernorm_bwd_stream", lib.ptr(dy2), lib.ptr(xs), lib.ptr(gamma), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dr2),
+                 lib.ptr(dx), lib.ptr(dg), lib.ptr(db), lib.ptr(ws), rows, C, 1)
+    else:
+        lib.call("fiber_layernorm_bwd_bf16", lib.ptr(dy2), lib.ptr(xs), lib.ptr(gamma), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dr2),
+                 lib.ptr(dx), lib.ptr(dg), lib.ptr(db), lib.ptr(ws), rows, C)
+    return dx, dg, db
 
 
 class _LayerNorm(torch.autograd.Function):
+    """(LN(x), fp32 copy of it or None).  x32: fp32 payload of x (the fp32 residual stream); want_f32: also return the output in
+    fp32 (post-LN text stack: the LayerNorm output is the next residual)."""
+
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, x32=None, want_f32=False):
         C = x.shape[-1]
         x2 = _c(x).view(-1, C)
-        rows = x2.shape[0]
-        y = torch.empty_like(x2)
-        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
-        rstd = torch.empty_like(mean)
-        lib.call("fiber_layernorm_fwd_bf16", lib.ptr(x2), lib.ptr(gamma), lib.ptr(beta), lib.ptr(y), lib.ptr(mean), lib.ptr(rstd), rows, C, eps)
-        ctx.save_for_backward(x2, gamma, mean, rstd)
-        return y.view(x.shape)
+        xs = _c(x32).view(-1, C) if x32 is not None else None
+        y, y32, mean, rstd = _ln_fwd(x2, xs, gamma, beta, eps, want_f32)
+        ctx.save_for_backward(xs if xs is not None else x2, gamma, mean, rstd)
+        ctx.is32 = xs is not None
+        if y32 is not None:
+            y32 = y32.view(x.shape)
+            ctx.mark_non_differentiable(y32)
+        return y.view(x.shape), y32
 
     @staticmethod
-    def backward(ctx, dy):
-        x2, gamma, mean, rstd = ctx.saved_tensors
-        rows, C = x2.shape
-        dy2 = _c(dy).view(rows, C)
-        dx = torch.empty_like(x2)
-        dg = torch.empty(C, dtype=torch.float32, device=dy.device)
-        db = torch.empty_like(dg)
-        ws = torch.empty(lib.plain("fiber_layernorm_bwd_grid", rows) * 8 * C, dtype=torch.float32, device=dy.device)
-        lib.call("fiber_layernorm_bwd_bf16", lib.ptr(dy2), lib.ptr(x2), lib.ptr(gamma), lib.ptr(mean), lib.ptr(rstd), None, lib.ptr(dx),
-                 lib.ptr(dg), lib.ptr(db), lib.ptr(ws), rows, C)
-        return dx.view(dy.shape), dg, db, None
+    def backward(ctx, dy, _dy32=None):
+        xs, gamma, mean, rstd = ctx.saved_tensors
+        dx, dg, db = _ln_bwd(_c(dy).view(xs.shape), xs, ctx.is32, gamma, mean, rstd, None)
+        return dx.view(dy.shape), dg, db, None, None, None
 
 
-def layernorm(x, gamma, beta, eps=1e-5):
-    return _LayerNorm.apply(x, gamma, beta, eps)
+def layernorm(x, gamma, beta, eps=1e-5, want_f32=None):
+    """LayerNorm over the last dim.  Reads the fp32 payload of a stream tensor when it has one.  want_f32 (default: follows the
+    input, i.e. on when x carries a payload and residual_fp32() -- the post-LN text stack) attaches the output's own payload."""
+    x32 = f32_of(x)
+    if want_f32 is None:
+        want_f32 = False
+    y, y32 = _LayerNorm.apply(x, gamma, beta, eps, x32, bool(want_f32))
+    return with_f32(y, y32)
 
 
 class _LayerNormRes(torch.autograd.Function):
@@ -553,70 +654,72 @@ class _LayerNormRes(torch.autograd.Function):
     added inside the LayerNorm backward kernel, so autograd never launches a separate activation-sized add."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, x32=None):
         C = x.shape[-1]
         x2 = _c(x).view(-1, C)
-        rows = x2.shape[0]
-        y = torch.empty_like(x2)
-        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
-        rstd = torch.empty_like(mean)
-        lib.call("fiber_layernorm_fwd_bf16", lib.ptr(x2), lib.ptr(gamma), lib.ptr(beta), lib.ptr(y), lib.ptr(mean), lib.ptr(rstd), rows, C, eps)
-        ctx.save_for_backward(x2, gamma, mean, rstd)
+        xs = _c(x32).view(-1, C) if x32 is not None else None
+        y, _, mean, rstd = _ln_fwd(x2, xs, gamma, beta, eps, False)
+        ctx.save_for_backward(xs if xs is not None else x2, gamma, mean, rstd)
+        ctx.is32 = xs is not None
         return y.view(x.shape), x2.view(x.shape)
 
     @staticmethod
     def backward(ctx, dy, dres):
-        x2, gamma, mean, rstd = ctx.saved_tensors
-        rows, C = x2.shape
+        xs, gamma, mean, rstd = ctx.saved_tensors
+        rows, C = xs.shape
         if dy is None:
-            return dres, None, None, None
-        dy2 = _c(dy).view(rows, C)
+            return dres, None, None, None, None
         dr2 = _c(dres).view(rows, C) if dres is not None else None
-        dx = torch.empty_like(x2)
-        dg = torch.empty(C, dtype=torch.float32, device=dy.device)
-        db = torch.empty_like(dg)
-        ws = torch.empty(lib.plain("fiber_layernorm_bwd_grid", rows) * 8 * C, dtype=torch.float32, device=dy.device)
-        lib.call("fiber_layernorm_bwd_bf16", lib.ptr(dy2), lib.ptr(x2), lib.ptr(gamma), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dr2),
-                 lib.ptr(dx), lib.ptr(dg), lib.ptr(db), lib.ptr(ws), rows, C)
-        return dx.view(dy.shape), dg, db, None
+        dx, dg, db = _ln_bwd(_c(dy).view(rows, C), xs, ctx.is32, gamma, mean, rstd, dr2)
+        return dx.view(dy.shape), dg, db, None, None
 
 
 def layernorm_res(x, gamma, beta, eps=1e-5):
-    """Returns (LN(x), x_for_residual)."""
-    return _LayerNormRes.apply(x, gamma, beta, eps)
+    """Returns (LN(x), x_for_residual); the residual keeps x's fp32 payload."""
+    x32 = f32_of(x)
+    y, r = _LayerNormRes.apply(x, gamma, beta, eps, x32)
+    return y, with_f32(r, x32)
 
 
 class _PatchMergeLN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, H, W, eps):
+    def forward(ctx, x, gamma, beta, H, W, eps, x32=None):
         B, L, C = x.shape
-        x = _c(x)
+        xs = _c(x32) if x32 is not None else _c(x)
         rows = B * (H // 2) * (W // 2)
         y = torch.empty((B, rows // B, 4 * C), dtype=BF16, device=x.device)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
-        lib.call("fiber_patch_merge_ln_fwd_bf16", lib.ptr(x), lib.ptr(gamma), lib.ptr(beta), lib.ptr(y), lib.ptr(mean), lib.ptr(rstd), B, H, W, C, eps)
-        ctx.save_for_backward(x, gamma, mean, rstd)
-        ctx.dims = (B, H, W, C)
+        if x32 is not None:
+            lib.call("fiber_patch_merge_ln_fwd_stream", lib.ptr(xs), lib.ptr(gamma), lib.ptr(beta), lib.ptr(y), lib.ptr(mean), lib.ptr(rstd),
+                     B, H, W, C, eps, 1)
+        else:
+            lib.call("fiber_patch_merge_ln_fwd_bf16", lib.ptr(xs), lib.ptr(gamma), lib.ptr(beta), lib.ptr(y), lib.ptr(mean), lib.ptr(rstd), B, H, W, C, eps)
+        ctx.save_for_backward(xs, gamma, mean, rstd)
+        ctx.dims, ctx.is32 = (B, H, W, C), x32 is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, gamma, mean, rstd = ctx.saved_tensors
+        xs, gamma, mean, rstd = ctx.saved_tensors
         B, H, W, C = ctx.dims
         rows = B * (H // 2) * (W // 2)
         dy = _c(dy)
-        dx = torch.empty_like(x)
+        dx = torch.empty(xs.shape, dtype=BF16, device=dy.device)
         dg = torch.empty(4 * C, dtype=torch.float32, device=dy.device)
         db = torch.empty_like(dg)
         ws = torch.empty(lib.plain("fiber_layernorm_bwd_grid", rows) * 8 * 4 * C, dtype=torch.float32, device=dy.device)
-        lib.call("fiber_patch_merge_ln_bwd_bf16", lib.ptr(dy), lib.ptr(x), lib.ptr(gamma), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dx),
-                 lib.ptr(dg), lib.ptr(db), lib.ptr(ws), B, H, W, C)
-        return dx, dg, db, None, None, None
+        if ctx.is32:
+            lib.call("fiber_patch_merge_ln_bwd_stream", lib.ptr(dy), lib.ptr(xs), lib.ptr(gamma), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dx),
+                     lib.ptr(dg), lib.ptr(db), lib.ptr(ws), B, H, W, C, 1)
+        else:
+            lib.call("fiber_patch_merge_ln_bwd_bf16", lib.ptr(dy), lib.ptr(xs), lib.ptr(gamma), lib.ptr(mean), lib.ptr(rstd), lib.ptr(dx),
+                     lib.ptr(dg), lib.ptr(db), lib.ptr(ws), B, H, W, C)
+        return dx, dg, db, None, None, None, None
 
 
 def patch_merge_ln(x, gamma, beta, H, W, eps=1e-5):
-    return _PatchMergeLN.apply(x, gamma, beta, H, W, eps)
+    return _PatchMergeLN.apply(x, gamma, beta, H, W, eps, f32_of(x))
 
 
 class _WindowAttn(torch.autograd.Function):
@@ -807,6 +910,64 @@ def add(a, b):
     return _Add.apply(a, b)
 
 
+class _StreamAdd(torch.autograd.Function):
+    """(out16, out32) = res + rowscale[sample] * (drop_a(a) + alpha * drop_b(b))  -- csrc/elementwise.hip stream_add_kernel."""
+
+    @staticmethod
+    def forward(ctx, res, a, b, alpha, rowscale, p_a, seed_a, p_b, seed_b, res32, want32):
+        a = _c(a)
+        b = _c(b) if b is not None else None
+        kind, rsrc = 0, None
+        if res32 is not None:
+            kind, rsrc = 2, _c(res32)
+        elif res is not None:
+            kind, rsrc = 1, _c(res)
+        out16 = torch.empty_like(a)
+        out32 = torch.empty(a.shape, dtype=torch.float32, device=a.device) if want32 else None
+        per = (a.numel() // rowscale.numel()) if rowscale is not None else 0
+        base = seed_base_ptr()
+        lib.call("fiber_stream_add", lib.ptr(rsrc), kind, lib.ptr(a), lib.ptr(b), lib.ptr(alpha), lib.ptr(rowscale), per, float(p_a), int(seed_a),
+                 float(p_b), int(seed_b), base, lib.ptr(out32), lib.ptr(out16), a.numel())
+        ctx.save_for_backward(b if (alpha is not None and b is not None) else None, alpha, rowscale)
+        ctx.cfg = (per, float(p_a), int(seed_a), float(p_b), int(seed_b), base, res is not None, b is not None)
+        if out32 is not None:
+            ctx.mark_non_differentiable(out32)
+        return out16, out32
+
+    @staticmethod
+    def backward(ctx, dy, _d32=None):
+        b, alpha, rowscale = ctx.saved_tensors
+        per, p_a, seed_a, p_b, seed_b, base, has_res, has_b = ctx.cfg
+        dy = _c(dy)
+        plain_a = rowscale is None and p_a == 0.0                       # d a = dy itself
+        da = dy if plain_a else torch.empty_like(dy)
+        db = torch.empty_like(dy) if has_b else None
+        dalpha = torch.zeros(1, dtype=torch.float32, device=dy.device) if (alpha is not None and has_b and ctx.needs_input_grad[3]) else None
+        if not plain_a or has_b:
+            lib.call("fiber_stream_add_bwd", lib.ptr(dy), lib.ptr(b), lib.ptr(alpha), lib.ptr(rowscale), per, p_a, seed_a, p_b, seed_b, base,
+                     None if plain_a else lib.ptr(da), lib.ptr(db), lib.ptr(dalpha), dy.numel())
+        return (dy if has_res else None), da, db, dalpha, None, None, None, None, None, None, None
+
+
+def stream_add(res, a, b=None, alpha=None, rowscale=None, p_a=0.0, p_b=0.0, training=True):
+    """res + rowscale * (dropout_pa(a) + alpha * dropout_pb(b)) in one pass.  `res` may be a stream pair (its fp32 payload is read
+    and the result is a pair again), a plain bf16 tensor, or None (with residual_fp32() a NEW stream starts when res is None
+    only if the caller attaches it).  Dropout keys are drawn here (one per active dropout, a before b)."""
+    p_a = float(p_a) if training else 0.0
+    p_b = float(p_b) if (training and b is not None) else 0.0
+    seed_a = next_seed() if p_a > 0 else 0
+    seed_b = next_seed() if p_b > 0 else 0
+    r32 = f32_of(res)
+    want32 = r32 is not None or (_RESIDUAL_FP32[0] and res is not None)
+    y, y32 = _StreamAdd.apply(res, a, b, alpha, rowscale, p_a, seed_a, p_b, seed_b, r32, want32)
+    return with_f32(y, y32)
+
+
+def stream_bf16(x):
+    """The bf16 tensor a GEMM may read for a stream tensor: the shadow itself (every producer on the stream writes one)."""
+    return x
+
+
 class _Dropout(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p, seed):
@@ -852,6 +1013,7 @@ def _write_base_dev():
 def manual_seed(seed):
     """Seed of the dropout / DropPath streams (lightning.seed_everything and the Trainer call this with config["seed"] + rank)."""
     _seed_state["seed"], _seed_state["ctr"], _seed_state["step"] = int(seed) & 0xFFFFFFFF, 0, None
+    _seed_state["collate_ctr"] = 0
     _write_base_dev()
 
 
@@ -888,6 +1050,16 @@ def next_seed():
     if _seed_state["base_dev"] is not None:
         return _seed_state["ctr"]
     return (_base_value() + _seed_state["ctr"]) & _M64
+
+
+def collate_seed():
+    """A fresh by-value 64-bit key for the input pipeline (MLM masking in data.device_collate).  The collate runs OUTSIDE the
+    training step (and outside a captured hipGraph), before set_rng_step() of the step that will consume the batch, so it has its
+    own stream: (seed, batch counter) in a key range no dropout site uses -- never the device-resident base, whose by-value part
+    restarts every step (the same tokens would be masked on every replay)."""
+    _seed_state["collate_ctr"] = _seed_state.get("collate_ctr", 0) + 1
+    hi = (_seed_state["seed"] ^ 0xC011A7E5) & 0xFFFFFFFF
+    return ((hi << 32) | (_seed_state["collate_ctr"] & 0xFFFFFFFF)) & _M64
 
 
 def dropout(x, p, training):

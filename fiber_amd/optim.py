@@ -50,7 +50,7 @@ class FiberAdamW(torch.optim.Optimizer):
         self._chunk = None
         self._tables = {}                       # group index -> cached device tables
         self.rebuilds = 0                       # how often a table had to be rebuilt (diagnostics)
-        self._hyper = None                      # graph mode: (device float [groups, 2], pinned host copy)
+        self._hyper = None                      # graph mode: device float [groups, 2] = {lr, bias-corrected step size}
 
     # ---- hipGraph support ---------------------------------------------------------------------------------------------
     # A captured step bakes every by-value kernel argument.  In graph mode the two arguments that change per step -- the
@@ -61,13 +61,17 @@ class FiberAdamW(torch.optim.Optimizer):
             raise lib.FiberHipError("FiberAdamW.enable_graph_mode: take one eager step first (device tables not built yet)")
         dev = next(p for g in self.param_groups for p in g["params"]).device
         n = len(self.param_groups)
-        self._hyper = (torch.zeros((n, 2), dtype=torch.float32, device=dev), torch.zeros((n, 2), dtype=torch.float32).pin_memory())
+        self._hyper = torch.zeros((n, 2), dtype=torch.float32, device=dev)
 
     def disable_graph_mode(self):
         self._hyper = None
 
     def prepare_replay(self):
-        dev_t, host_t = self._hyper
+        # The host runs ahead of the GPU (replays are asynchronous), so the upload must not read host memory that a LATER
+        # prepare_replay() may already have overwritten: a FRESH pageable host tensor per call -- the runtime stages a pageable
+        # source before copy_() returns (as for the pointer tables in step()), so step k's graph always sees step k's values.
+        dev_t = self._hyper
+        host_t = torch.zeros(tuple(dev_t.shape), dtype=torch.float32)
         for gi, group in enumerate(self.param_groups):
             tab = self._tables.get(gi)
             if tab is None:
@@ -161,7 +165,7 @@ class FiberAdamW(torch.optim.Optimizer):
                 hyper = None
             else:                                  # graph mode: prepare_replay() owns the counters and the device scalars
                 step = max(1, tab["states"][0]["step"])
-                hyper = self._hyper[0][gi].data_ptr()
+                hyper = self._hyper[gi].data_ptr()
             lib.call("fiber_adamw_multi_f32", lib.ptr(tab["table"]), lib.ptr(tab["numel"]), lib.ptr(tab["chunks"]), tab["n"],
                      float(group["lr"]), float(group["weight_decay"]), float(b1), float(b2), float(group["eps"]), int(step), hyper)
             ops.restamp_bf16_copies(plist, bump=not bumped)

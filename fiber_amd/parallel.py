@@ -41,9 +41,10 @@ def wrap_ddp(model, device=None, bucket_cap_mb=64, bf16_grads=None):
     rebuilds its buckets after the first iteration in the order the gradients actually became ready, i.e. reverse execution
     order of the interleaved image / text stacks (heads and Swin stage 3 / text layers 10-11 first, patch embedding last) --
     the definition order of `model.parameters()` only matters for step 0.
-    bf16_grads (default: on for nccl/RCCL, env FIBER_DDP_BF16=0/1 overrides): all-reduce the buckets in bf16
-    (`bf16_compress_hook`: 0.56 GB instead of 1.13 GB per step over xGMI) -- the sum is formed in bf16
-    on the wire and decompressed into the fp32 gradient views."""
+    bf16_grads (default OFF: the reference trains with an fp32 all-reduce; env FIBER_DDP_BF16=1 or the argument turn it on):
+    all-reduce the buckets in bf16 (`bf16_compress_hook`: 0.56 GB instead of 1.13 GB per step over xGMI)
+    -- the sum is then formed in bf16 on the wire and decompressed into the fp32 gradient views.  The fp32 ring moves
+    2*(7/8)*1.13 GB over one ~153 GB/s xGMI link = ~13 ms per step, hidden under a 320-ms backward at the bench batch."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return model
     ids = [device.index] if (device is not None and device.type == "cuda") else None
@@ -51,7 +52,7 @@ def wrap_ddp(model, device=None, bucket_cap_mb=64, bf16_grads=None):
                                                     gradient_as_bucket_view=True, bucket_cap_mb=bucket_cap_mb)
     if bf16_grads is None:
         env = os.environ.get("FIBER_DDP_BF16")
-        bf16_grads = (dist.get_backend() == "nccl") if env is None else env == "1"
+        bf16_grads = env == "1"
     from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
     inner = default_hooks.bf16_compress_hook if bf16_grads else default_hooks.allreduce_hook
     on_gpu = device is not None and device.type == "cuda"

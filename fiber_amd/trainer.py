@@ -32,6 +32,13 @@ class Trainer:
         self.resume_from_checkpoint = resume_from_checkpoint
         self.datamodule = datamodule
         self.seed = seed
+        # pl.Trainer semantics (run.py:69 passes config["val_check_interval"]): float in (0, 1] = fraction of the training
+        # epoch between validation runs, int = number of training batches between them
+        if isinstance(val_check_interval, float) and not (0.0 < val_check_interval <= 1.0):
+            raise ValueError(f"val_check_interval={val_check_interval}: a float must lie in (0, 1]")
+        if isinstance(val_check_interval, int) and not isinstance(val_check_interval, bool) and val_check_interval < 1:
+            raise ValueError(f"val_check_interval={val_check_interval}: an int must be >= 1")
+        self.val_check_interval = val_check_interval
         self.global_step = 0
         self.current_epoch = 0
         self.best_metric = None
@@ -55,7 +62,7 @@ class Trainer:
                     "best_metric": self.best_metric}, os.path.join(self.default_root_dir, name))
 
     def _resume(self, model, opt, sched, device):
-        ck = torch.load(self.resume_from_checkpoint, map_location=device, weights_only=False)
+        ck = torch.load(self.resume_from_checkpoint, map_location=device, weights_only=True)   # tensors / numbers / containers only
         model.load_state_dict(ck["state_dict"], strict=False)
         if ck.get("optimizer_states"):
             opt.load_state_dict(ck["optimizer_states"][0])      # FiberAdamW drops its cached device tables here
@@ -87,8 +94,27 @@ class Trainer:
         net = parallel.wrap_ddp(model, device)
         opt.zero_grad(set_to_none=True)
         micro, t0, last, step0 = 0, time.time(), None, self.global_step
+
+        def run_validation():
+            if val_dataloader is None:
+                return
+            metric = self.validate(model, val_dataloader, device=device)
+            if rank == 0 and metric is not None and (self.best_metric is None or metric > self.best_metric):
+                self.best_metric = metric                       # ModelCheckpoint(monitor="val/the_metric", mode="max", save_top_k=1)
+                self._save(model, opt, sched, "best.ckpt")
+            if rank == 0:
+                self._save(model, opt, sched, "last.ckpt")      # save_last=True
+
+        every = None                                            # validate every `every` training batches inside the epoch
+        vci = self.val_check_interval
+        if isinstance(vci, int) and not isinstance(vci, bool):
+            every = vci
+        elif vci < 1.0:
+            if not hasattr(train_dataloader, "__len__"):
+                raise ValueError("a fractional val_check_interval needs a training dataloader with a length")
+            every = max(1, int(len(train_dataloader) * vci))
         while not self._done() and (self.max_epochs is None or self.current_epoch < self.max_epochs):
-            seen = 0
+            seen, validated_at = 0, -1
             for batch_idx, batch in enumerate(train_dataloader):
                 seen += 1
                 batch = _to_device(batch, device)
@@ -120,18 +146,18 @@ class Trainer:
                               f"({(time.time() - t0) / max(1, self.global_step - step0):.3f} s/step)", flush=True)
                     if self._done():
                         break
+                if every is not None and seen % every == 0:
+                    run_validation()
+                    validated_at = seen
             if seen == 0:
                 raise ValueError("Trainer.fit: the training dataloader yielded no batch")
             if hasattr(model, "training_epoch_end"):
                 model.training_epoch_end([])
             self.current_epoch += 1
-            if val_dataloader is not None:
-                metric = self.validate(model, val_dataloader, device=device)
-                if rank == 0 and metric is not None and (self.best_metric is None or metric > self.best_metric):
-                    self.best_metric = metric                   # ModelCheckpoint(monitor="val/the_metric", mode="max", save_top_k=1)
-                    self._save(model, opt, sched, "best.ckpt")
-            if rank == 0:
-                self._save(model, opt, sched, "last.ckpt")      # save_last=True
+            if validated_at != seen:                            # the epoch-end check, unless an interval check just ran
+                run_validation()
+            if val_dataloader is None and rank == 0:
+                self._save(model, opt, sched, "last.ckpt")
         return last
 
     @torch.no_grad()

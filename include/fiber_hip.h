@@ -28,6 +28,10 @@ typedef struct ihipStream_t* fiber_stream_t;
 int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bias, const void* residual, void* Y, void* Ypre,
                        const float* rowscale, int rows_per_sample, const void* aux, int ldaux, float* colpart, int M, int N,
                        int K, int ldx, int ldw, int ldy, int ldr, int act, fiber_stream_t stream);
+/* act | 0x800 (act 0, residual required) = the fp32 RESIDUAL STREAM form of the residual epilogue (x = x + branch of
+ * swin_transformer.py:388-391, dense + input_tensor of roberta.py:417-423,485 -- the reference keeps these sums in fp32):
+ * `residual` is fp32 [M, ldr]; the sum is stored in fp32 at Ypre viewed as float [M, ldy] and, if Y is non-NULL, once more
+ * rounded to bf16 at Y (the copy GEMM consumers of the stream read). */
 int fiber_gemm_row_tile(int M, int N, int K);
 
 /* Weight (+bias) gradient of nn.Linear: dW[N,K] (fp32, contiguous) = dY[M,lddy]^T . X[M,ldx]; dbias (nullable, fp32[N]) =
@@ -51,12 +55,27 @@ int fiber_layernorm_bwd_bf16(const void* dy, const void* x, const float* gamma, 
                              const void* dres, void* dx, float* dgamma, float* dbeta, float* workspace, int rows, int C,
                              fiber_stream_t stream);
 
+/* The same on the fp32 residual stream.  flags bit 0: x is fp32 [rows, C] (the un-rounded x of swin_transformer.py:362,391 /
+ * the LayerNorm input of roberta.py:485,422).  y32 (nullable): the output once more in fp32 -- RoBERTa is post-LN, its LayerNorm
+ * output is the next residual.  Gradients (dy, dres, dx) stay bf16. */
+int fiber_layernorm_fwd_stream(const void* x, const float* gamma, const float* beta, void* y, float* y32, float* mean, float* rstd,
+                               int rows, int C, float eps, int flags, fiber_stream_t stream);
+int fiber_layernorm_bwd_stream(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                               const void* dres, void* dx, float* dgamma, float* dbeta, float* workspace, int rows, int C, int flags,
+                               fiber_stream_t stream);
+
 /* PatchMerging gather+concat+LayerNorm (swin_transformer.py:411-430): x [B,H*W,C] -> y [B,H*W/4,4C] */
 int fiber_patch_merge_ln_fwd_bf16(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int B,
                                   int H, int W, int C, float eps, fiber_stream_t stream);
 int fiber_patch_merge_ln_bwd_bf16(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                   void* dx, float* dgamma, float* dbeta, float* workspace, int B, int H, int W, int C,
                                   fiber_stream_t stream);
+/* flags bit 0: x is the fp32 residual stream [B,H*W,C]; y, dy, dx stay bf16 */
+int fiber_patch_merge_ln_fwd_stream(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int B,
+                                    int H, int W, int C, float eps, int flags, fiber_stream_t stream);
+int fiber_patch_merge_ln_bwd_stream(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                    void* dx, float* dgamma, float* dbeta, float* workspace, int B, int H, int W, int C, int flags,
+                                    fiber_stream_t stream);
 
 /* Swin (shifted) window attention in image-token order: roll + window_partition + WindowAttention self-attn core +
  * window_reverse + roll (swin_transformer.py:99-126, 195-219, 364-387, mask 327-350).  qkv [B*H*W,3C] -> o [B*H*W,C]. */
@@ -112,6 +131,21 @@ int fiber_dropout_bf16(const void* x, void* y, long n, float p, uint64_t seed, c
 int fiber_droppath_scale_f32(float* out, int n, float keep, uint64_t seed, const uint64_t* seed_base, fiber_stream_t stream);
 int fiber_rowscale_add_bf16(const void* r, const void* x, const float* scale, void* out, long n, long per_sample,
                             fiber_stream_t stream);
+/* Everything the reference does between a branch and its residual, in one pass:
+ *   out = res + rowscale[sample] * (drop_a(a) + alpha * drop_b(b))
+ * = swin_transformer.py:259 (x + alpha_i2t * y) followed by :390 (shortcut + drop_path(x)); roberta.py:339 / :420 (dense ->
+ * dropout -> + input_tensor) and :483-485 (alpha_t2i * cross + self, + hidden_states).  res_kind: 0 none, 1 bf16, 2 fp32 (the fp32
+ * residual stream); b, alpha, rowscale nullable; p_a / p_b dropout probabilities (0 = off) with keys seed_a / seed_b (+ *seed_base);
+ * out32 (fp32) and / or out16 (bf16), at least one.  n % 8 == 0; per_sample % 8 == 0 when rowscale is given. */
+int fiber_stream_add(const void* res, int res_kind, const void* a, const void* b, const float* alpha, const float* rowscale,
+                     long per_sample, float p_a, uint64_t seed_a, float p_b, uint64_t seed_b, const uint64_t* seed_base,
+                     float* out32, void* out16, long n, fiber_stream_t stream);
+/* branch gradients of the above: da, db (nullable), dalpha (nullable fp32 scalar, accumulated: zero it first; needs b) */
+int fiber_stream_add_bwd(const void* dy, const void* b, const float* alpha, const float* rowscale, long per_sample, float p_a,
+                         uint64_t seed_a, float p_b, uint64_t seed_b, const uint64_t* seed_base, void* da, void* db, float* dalpha,
+                         long n, fiber_stream_t stream);
+/* y (bf16) = x (fp32): the bf16 copy of an fp32 stream tensor for a GEMM that consumes it */
+int fiber_cast_f32_bf16(const float* x, void* y, long n, fiber_stream_t stream);
 /* y = scale[row / rows_per_sample] * x (DropPath backward, swin_transformer.py:390-391) and db = column sums of y (bias
  * gradient of the proj / fc2 linear) in one pass; workspace as for fiber_gelu_bwd_colsum_bf16 */
 int fiber_rowscale_colsum_bf16(const void* x, const float* scale, void* y, float* db, float* workspace, int M, int N,

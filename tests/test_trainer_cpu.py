@@ -253,3 +253,53 @@ def test_rng_stream_seeding_and_weak_weight_cache():
     del w
     gc.collect()
     assert len(ops._wcache) == n0
+
+
+def test_val_check_interval_int_and_fraction(tmp_path):
+    """val_check_interval is honoured the way pl.Trainer reads it (run.py passes config["val_check_interval"]):
+    an int = every N training batches, a float < 1 = that fraction of the epoch; 1.0 = once per epoch; bad values raise."""
+    import pytest
+    torch.manual_seed(0)
+    data = [{"x": torch.randn(8, 4), "y": torch.randn(8, 1)} for _ in range(6)]
+
+    class Counting(ToyVal):
+        def validation_epoch_end(self, outs):
+            self.val_runs = getattr(self, "val_runs", 0) + 1
+            super().validation_epoch_end(outs)
+
+    def runs(vci):
+        m = Counting(_cfg(optim_type="adamw", max_steps=12))
+        Trainer(max_steps=None, max_epochs=2, log_every_n_steps=0, val_check_interval=vci).fit(
+            m, data, val_dataloader=data[:2], device=torch.device("cpu"))
+        return m.val_runs
+
+    assert runs(1.0) == 2                      # once per epoch
+    assert runs(2) == 6                        # after batches 2, 4, 6 of each epoch (the one at 6 IS the epoch-end check)
+    assert runs(0.5) == 4                      # after batches 3 and 6
+    assert runs(4) == 4                        # after batch 4, plus the epoch-end check
+    for bad in (0.0, 1.5, 0):
+        with pytest.raises(ValueError):
+            Trainer(val_check_interval=bad)
+
+
+def test_collate_seed_advances_in_graph_rng_mode():
+    """the MLM-masking key of data.device_collate must not be the dropout stream's by-value counter (which restarts
+    every step and, in graph-RNG mode, IS the whole by-value key): consecutive batches get different keys in either mode, and
+    the keys are reproducible from the seed."""
+    from fiber_amd import ops
+    ops.manual_seed(11)
+    a = [ops.collate_seed() for _ in range(3)]
+    ops._seed_state["base_dev"] = torch.zeros((), dtype=torch.int64)          # what enable_graph_rng() installs (host tensor here)
+    try:
+        def new_step(i):                                                      # set_rng_step() minus the device write
+            ops._seed_state["step"], ops._seed_state["ctr"] = i, 0
+        new_step(0); k0 = ops.collate_seed()
+        new_step(1); k1 = ops.collate_seed()
+        new_step(1); k2 = ops.collate_seed()
+    finally:
+        ops._seed_state["base_dev"] = None
+    assert len({*a, k0, k1, k2}) == 6
+    ops.manual_seed(11)
+    assert a == [ops.collate_seed() for _ in range(3)]
+    ops.manual_seed(12)
+    assert ops.collate_seed() not in a
