@@ -45,6 +45,7 @@ class Sites:
     resid: bool = False
     attn: bool = False
     act_grad: bool = True
+    branch16: bool = False        # with an fp32 stream: the branch is rounded to bf16 BEFORE it is added (bf16 epilogue staging)
 
 
 class _RoundSTE(torch.autograd.Function):
@@ -73,6 +74,9 @@ def _r(x, flag):
 def _fp32_out():
     """The next linears feed a residual add whose epilogue works on the fp32 accumulator: no output rounding when the residual
     stream itself is fp32 (with a bf16 stream the SUM is rounded, by the `resid` site)."""
+    if _S.branch16:                                          # the branch goes through a bf16 staging slab first
+        yield
+        return
     _state["keep_out"] += 1
     try:
         yield
@@ -211,6 +215,8 @@ MODES = {
     "hip_bf16_stream": Sites(gemm_in=True, w=True, gemm_out=True, ln_out=True, resid=True, attn=True),
     # the same with an fp32 residual stream (Swin x, RoBERTa LN inputs / outputs on the residual path)
     "hip_fp32_stream": Sites(gemm_in=True, w=True, gemm_out=True, ln_out=False, resid=False, attn=True),
+    # fp32 stream, but every branch is rounded to bf16 before the add (what a bf16-staged GEMM epilogue does)
+    "hip_fp32_stream_bf16_branch": Sites(gemm_in=True, w=True, gemm_out=True, ln_out=False, resid=False, attn=True, branch16=True),
     # fp32 stream AND fp32 activation gradients (only the forward sites are bf16)
     "hip_fp32_stream_fp32_grads": Sites(gemm_in=True, w=True, gemm_out=True, ln_out=False, resid=False, attn=True, act_grad=False),
     # floor of "bf16 MFMA compute": only the GEMM operands are bf16, every stored tensor fp32

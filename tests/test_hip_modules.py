@@ -243,8 +243,10 @@ def test_fused_path(name, golden):
         mlm = objectives.compute_mlm(model, bd)["mlm_loss"]
         itm_out = objectives.compute_itm(model, bd, itm_labels=b["itm_labels"])
         itm = itm_out["itm_loss"]
-        assert abs(mlm.item() - float(gold["mlm_loss"])) < 2e-2, (mlm.item(), float(gold["mlm_loss"]))
-        assert abs(itm.item() - float(gold["itm_loss"])) < 2e-2, (itm.item(), float(gold["itm_loss"]))
+        # forward loss against the reference fixture: the bf16 path sits at 1.1e-3 mean / 4.1e-3 max over 16 batches of the two
+        # small configurations (tests/test_hip_stream.py), the reference-style autocast run at 1.3e-3 / 1.7e-3
+        assert abs(mlm.item() - float(gold["mlm_loss"])) < 6e-3, (mlm.item(), float(gold["mlm_loss"]))
+        assert abs(itm.item() - float(gold["itm_loss"])) < 6e-3, (itm.item(), float(gold["itm_loss"]))
         if pc["grads"]:
             (mlm + itm).backward()
             unused_gold = set(gold["unused_params"].tolist())
@@ -505,7 +507,7 @@ def test_loss_curve_tracks_oracle_over_optimizer_steps():
     assert gap < 2.5e-3 and dgap < 2.5e-3, (gap, dgap, got, want)
 
 
-def _loss_curve(cfg, size, batch, steps, nb, warm, tag):
+def _loss_curve(cfg, size, batch, steps, nb, warm, tag, residual_dtype="bf16"):
     """`steps` optimizer steps of MLM+ITM with the reference's hyper-parameter structure (6 parameter groups, lr x5 on heads /
     cross-modal, HF AdamW, linear warm-up + poly decay), dropout / DropPath 0 and a FIXED cycle of `nb` synthetic batches on both
     sides: HIP bf16 path vs the fp32 oracle from identical weights.  Returns the summary (also written to
@@ -521,7 +523,7 @@ def _loss_curve(cfg, size, batch, steps, nb, warm, tag):
     ref = detgen.fill_(R.FiberRef(cfg).train())
     hyper = dict(learning_rate=2e-5, lr_mult_head=5, lr_mult_cross_modal=5, warmup_steps=warm, max_steps=steps, weight_decay=0.01,
                  end_lr=0, decay_power=1)
-    model = FIBERTransformerSS(make_config(**cfg, **hyper)).train()
+    model = FIBERTransformerSS(make_config(**cfg, **hyper, residual_dtype=residual_dtype)).train()
     load_from_oracle(model, ref)
     for m_ in (ref, model):
         for n, p in m_.named_parameters():
@@ -566,9 +568,12 @@ def _loss_curve(cfg, size, batch, steps, nb, warm, tag):
     summary = {"steps": steps, "loss_first": want[0], "loss_last": want[-1], "gap_max": max(gaps), "gap_median": srt[len(srt) // 2],
                "gap_p90": srt[int(0.9 * (len(srt) - 1))], "steps_within_1e-3": sum(g_ <= 1e-3 for g_ in gaps),
                "hip": [round(v, 5) for v in got], "oracle": [round(v, 5) for v in want]}
+    summary["residual_dtype"] = residual_dtype
     print(json.dumps(summary))
     if os.path.isdir("gpurun_out"):
         json.dump(summary, open(f"gpurun_out/loss_curve_{tag}.json", "w"))
+    from fiber_amd import ops as _ops
+    _ops.set_residual_dtype("bf16")
     return summary
 
 
@@ -582,6 +587,19 @@ def test_loss_curve_swin_t_224_mlm_itm_50_steps():
     # steps within the north star's 1e-3, step 0 (no training dynamics: forward numerics only) 1.9e-3.  bf16 activations with
     # a 12-token MLM mean at batch 2 do not reach +-1e-3; before the fp32 label-logit correction (objectives._mlm_ce) the same
     # run read median 2.9e-3 / max 1.5e-2.  Bounds below = 2x the measured values.
+    assert summary["gap_max"] < 1.6e-2 and summary["gap_median"] < 4.5e-3, summary
+
+
+def test_loss_curve_swin_t_224_fp32_residual_stream():
+    """The same 50-step curve with config["residual_dtype"] = "fp32" (the round-2 review's item 1).  What the mode can and cannot
+    do was measured on the oracle first (oracle/precision_study.py, profiles/r03_precision_study_curve_swin_t.json, this very
+    curve, gap to the fp32 run: max / median): the reference-style autocast-bf16 run 1.35e-2 / 3.1e-3; every HIP storage site in
+    bf16 1.42e-2 / 3.2e-3; the same with an fp32 stream 1.64e-2 / 3.6e-3; bf16 GEMM OPERANDS ONLY (every stored tensor fp32) still
+    3.5e-3 / 7.4e-4 with 14 of 50 steps outside 1e-3.  The curve is a chaotic amplifier (loss 11.2 -> 1.4 in 50 steps on 5 cycled
+    batches of 2): +-1e-3 is below what bf16 MFMA operands alone allow, and the fp32 stream only buys the forward pass (step 0:
+    4.8e-3 -> 1.3e-3 in the study).  Held to the same regression bound as the bf16-stream curve."""
+    summary = _loss_curve(dict(cases.SWIN_T), 224, 2, 50, 5, 5, "swin_t_fp32_stream", residual_dtype="fp32")
+    assert summary["loss_last"] < summary["loss_first"] - 0.05
     assert summary["gap_max"] < 1.6e-2 and summary["gap_median"] < 4.5e-3, summary
 
 

@@ -147,8 +147,11 @@ def test_stream_add(ops, res_kind, with_b, rowscale, p_a, p_b):
     rhs = (a.detach().float() * a.grad.float()).sum().item()
     if with_b:
         rhs += (b.detach().float() * b.grad.float()).sum().item()
-    scale = max(abs(lhs), 1.0)
-    assert abs(lhs - rhs) / scale < 1.2e-2, (lhs, rhs)
+    # both sides are sums of N products of bf16-rounded factors (out / da / db are stored in bf16 unless the fp32 payload is
+    # compared): independent 2^-9 relative errors on N terms -> 3 sigma of the sum
+    n = branch.numel()
+    bound = 3 * 2.0 ** -9 * branch.norm().item() * dy.float().norm().item() / n ** 0.5
+    assert abs(lhs - rhs) < bound, (lhs, rhs, bound)
     if res is not None:
         assert torch.equal(res.grad, dy)
     if with_b:
@@ -164,7 +167,7 @@ def test_stream_add(ops, res_kind, with_b, rowscale, p_a, p_b):
         assert abs(alpha.grad.item() - want_dalpha) <= tol, (alpha.grad.item(), want_dalpha)
 
 
-def _run_path(case, residual_dtype):
+def _run_path(case, residual_dtype, n_batches=8):
     from fiber_amd import ops as O
     from fiber_amd.config import make_config
     from fiber_amd.modules import FIBERTransformerSS, fiber_utils, objectives
@@ -179,7 +182,7 @@ def _run_path(case, residual_dtype):
     model.to(DEV)
     c = ref.config
     losses = []
-    for seed in (1, 2, 3):
+    for seed in range(100, 100 + n_batches):
         b = detgen.synth_batch(B, c["image_size"], c["max_text_len"], c["vocab_size"], seed=seed, min_len=min(8, c["max_text_len"]))
         bd = {k: (v.to(DEV) if isinstance(v, torch.Tensor) else [t.to(DEV) for t in v] if isinstance(v, list) and isinstance(v[0], torch.Tensor) else v)
               for k, v in b.items()}
@@ -202,5 +205,8 @@ def test_fused_path_forward_gap_fp32_stream(case):
     g32 = [abs(a - b) for a, b in l32]
     g16 = [abs(a - b) for a, b in l16]
     print(f"{case}: forward gap fp32 stream {['%.2e' % g for g in g32]}  bf16 stream {['%.2e' % g for g in g16]}")
-    assert max(g32) < 3e-3, (g32, l32)
-    assert sum(g32) <= sum(g16) + 1e-3, "the fp32 stream must not be further from the oracle than the bf16 stream"
+    # measured (8 batches): path_tiny fp32 stream mean 2.9e-4 / max 5.9e-4, bf16 stream 8.7e-4 / 4.1e-3; path_swin_t fp32 stream
+    # 8.8e-4 / 1.8e-3, bf16 stream 1.09e-3 / 1.9e-3 -- at Swin-T width the bf16 GEMM operands (study floor 6e-4 / 1.3e-3) dominate
+    assert max(g32) < 3e-3 and sum(g32) / len(g32) < 1.5e-3, (g32, l32)
+    assert max(g16) < 6e-3 and sum(g16) / len(g16) < 2.5e-3, (g16, l16)
+    assert sum(g32) <= sum(g16) + 2e-3, "the fp32 stream must not be further from the oracle than the bf16 stream"
