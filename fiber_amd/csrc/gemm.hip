@@ -845,6 +845,238 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_wide_persist2_kernel(Gem
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// v5 ("q8", round 3): the persistent kernel with the K loop re-cut along the OUTPUT instead of along K -- the 8-phase schedule of
+// cdna_hip_programming.md section 5 ("The 256^2 8-phase template") on this kernel's LDS images, tile walk and wave-private epilogue.
+//
+// Why: in v4 a wave requests the whole next K tile (8 LDS-DMA instructions) at the head of one load phase.  The texture addresser
+// takes ~31 cycles per 1-KB instruction, so the 4 x 8 instructions of a wave group hold that phase for ~1000 cycles while the
+// partner group's 16 MFMAs need 512: two of the four phases of every K tile run at half the matrix pipe's pace (trace: 3.3-3.6 k
+// cycles per K tile for 2.05 k of MFMA).  Spreading the same requests over all four phases INCLUDING the math phases made it
+// slower (662 vs 568 us at 294912 x 512 x 2048: a wave stalled on a full DMA queue stops feeding the matrix pipe), and a K-split
+// sub-tile cannot be re-staged before the whole K tile has been read.  Cutting the wave's 128 x 64 tile into four QUADRANTS
+// (64 rows x 32 columns, all of K = 64) instead makes the four half-tiles of a stage (A rows h*64.., W rows j*32.. of every wave)
+// die at different times, so ONE half-tile (2 DMA instructions per wave) can be re-staged in EVERY phase, always by the group
+// that is in its load half -- 8 instructions = ~250 addresser cycles beside 256 cycles of the partner's MFMAs, continuously.
+//   phase  quadrant (A half, W half)   LDS reads (new fragments)      stages (cursor K tile c)     wait
+//     P1     (0, 0)                     A0: 8  W0: 4                   W1 of c
+//     P2     (0, 1)                     W1: 4                          A1 of c  -> c advances       vmcnt(6)
+//     P3     (1, 1)                     A1: 8                          A0 of c
+//     P4     (1, 0)                     -  (W0 still in registers)     W0 of c                      vmcnt(6)
+// With K tile t in flight the cursor is t+1 in P1/P2 and t+2 in P3/P4 (the buffer of t itself: A0 / W0 were last read in P1, two
+// and three phases earlier).  Every half-tile has 3-4 phases to land; a counted vmcnt(6) leaves the three newest half-tiles in
+// flight and is followed by a barrier before the NEXT phase reads what it retired (RAW rule of the guide: wait in phase p, read in
+// p+1; the group that runs one barrier behind passes its own wait before the leading group's read).  WAR: a half-tile is
+// re-staged two or three phases after its last ds_read.  Epilogue stores / residual loads only make the counted waits stricter.
+template <int EPI, bool HAS_R, bool HAS_RS>
+__global__ __launch_bounds__(512) void gemm_nt_q8_kernel(GemmArgs a) {
+  constexpr int BM = 256, BN = 256, WN = 4;
+  constexpr int WTM = 128, WTN = 64, TM = 4, TN = 2;
+  constexpr int STAGE = (BM + BN) * BK;
+  constexpr int SLAB = 32 * 64;
+  __shared__ __attribute__((aligned(16))) bf16 smem[2 * STAGE + 8 * SLAB];        // ONE LDS object: 128 KB ring + 32 KB slabs
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  bf16* cw = smem + 2 * STAGE + wave * SLAB;
+  const int tilesN = (a.N + BN - 1) / BN, tilesM = (a.M + BM - 1) / BM;
+  const int nblk = tilesM * tilesN;
+  const int P = gridDim.x >> 3, xcd = blockIdx.x & 7, widx = blockIdx.x >> 3;
+  const int q8 = nblk >> 3, r8 = nblk & 7;
+  const int first = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + widx;
+  const int count = q8 + (xcd < r8 ? 1 : 0);
+  const int T = widx < count ? (count - widx + P - 1) / P : 0;
+  if (T == 0) return;
+  const int nk = a.K / BK;
+
+  // ---- DMA side.  A half-tile = 128 tile rows x 64 k = 16 units of 8 rows (one 1-KB DMA instruction each); wave w owns units
+  // w and w + 8 of every half-tile:  A half h: rows {0, 128} + h*64 + w*8 .. +8;   W half j: rows {0, 128} + (w>>2)*64 + j*32 + (w&3)*8 .. +8
+  const int lr = lane >> 3;
+  const unsigned csw = (unsigned)(((lane & 7) ^ (((wave & 1) << 2) + (lr >> 1))) << 4);     // swizzled 16-B chunk, same for all 8 units
+  const int ra0 = wave * 8, rb0 = (wave >> 2) * 64 + (wave & 3) * 8;                          // unit base rows (half 0, unit 0)
+  const bf16* xbase; const bf16* wbase;                  // origins of the cursor's output tile
+  unsigned xo[2][2], wo[2][2];                           // per-lane byte offsets [half][unit]
+  int c_seq = 0, c_kt = 0, c_g = 0;                      // cursor: output tile, K tile in it, ring counter (buffer = c_g & 1)
+  auto aim = [&]() {
+    const int id = first + c_seq * P;
+    const int m0 = (id / tilesN) * BM, n0 = (id % tilesN) * BN;
+    xbase = a.X + (size_t)m0 * a.ldx;
+    wbase = a.W + (size_t)n0 * a.ldw;
+    const int xlim = a.M - 1 - m0, wlim = a.N - 1 - n0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        xo[h][u] = (unsigned)(min(u * 128 + h * 64 + ra0 + lr, xlim) * a.ldx) * 2u + csw;
+        wo[h][u] = (unsigned)(min(u * 128 + h * 32 + rb0 + lr, wlim) * a.ldw) * 2u + csw;
+      }
+  };
+  auto advance = [&]() {                                  // after the last half-tile (A1) of the cursor's K tile
+    ++c_g;
+    if (++c_kt == nk) {
+      if (c_seq + 1 < T) { c_kt = 0; ++c_seq; aim(); }
+      else c_kt = nk - 1;                                 // past the end: keep re-requesting the last K tile into buffers that are
+    }                                                     // free by construction (no "anything left?" test in the phases)
+  };
+  auto stageA = [&](int h) {
+    bf16* st = smem + (c_g & 1) * STAGE;
+    lds_dma16(xbase + c_kt * BK, xo[h][0], st + (h * 64 + ra0) * BK);
+    lds_dma16(xbase + c_kt * BK, xo[h][1], st + (128 + h * 64 + ra0) * BK);
+  };
+  auto stageW = [&](int j) {
+    bf16* st = smem + (c_g & 1) * STAGE + BM * BK;
+    lds_dma16(wbase + c_kt * BK, wo[j][0], st + (j * 32 + rb0) * BK);
+    lds_dma16(wbase + c_kt * BK, wo[j][1], st + (128 + j * 32 + rb0) * BK);
+  };
+
+  // ---- MFMA side
+  f32x16 acc[TM][TN];
+  const int frow = lane & 31, fk = lane >> 5;
+  bf16x8 fa[4][2], fb[2][4];                             // A half: [k step][32-row tile];  both W halves: [half][k step]
+  auto readA = [&](const bf16* sb, int h) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+        fa[ks][ii] = *reinterpret_cast<const bf16x8*>(sb + swz(wm * WTM + (2 * h + ii) * 32 + frow, ks * 2 + fk));
+  };
+  auto readW = [&](const bf16* sb, int j) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      fb[j][ks] = *reinterpret_cast<const bf16x8*>(sb + BM * BK + swz(wn * WTN + j * 32 + frow, ks * 2 + fk));
+  };
+  // bias of column block j in accumulator layout (element q*4+e <-> column j*32 + q*8 + 4*(lane>>5) + e): scalar loads, one select each
+  auto seed_of = [&](int n0w, int j) {
+    f32x16 sd;
+    if (EPI != 2 && a.bias) {
+      typedef __attribute__((address_space(4))) const float cfloat;
+      cfloat* bp = (cfloat*)(uintptr_t)(a.bias + n0w + j * 32);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = bp[q * 8 + e], hi = bp[q * 8 + 4 + e];
+          sd[q * 4 + e] = fk ? hi : lo;
+        }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sd[r] = 0.f;
+    }
+    return sd;
+  };
+  auto mma = [&](int h, int j) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+        acc[2 * h + ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][ks], fa[ks][ii], acc[2 * h + ii][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto mma_seeded = [&](int h, int j, const f32x16& sd) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+      acc[2 * h + ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][0], fa[0][ii], sd, 0, 0, 0);
+#pragma unroll
+    for (int ks = 1; ks < 4; ++ks)
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+        acc[2 * h + ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][ks], fa[ks][ii], acc[2 * h + ii][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // first barrier of a phase: the requests of this load half are out; `counted`: make everything but the three newest half-tiles
+  // resident first.  Second barrier: the MFMAs of the phase are issued.
+  auto bar_load = [&](bool counted) {
+    if (counted) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto bar_math = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: K tile 0 complete, A0 / W0 of K tile 1 requested (what the steady state has issued before P1 of K tile 0)
+  aim();
+  stageA(0); stageW(0); stageW(1); stageA(1); advance();
+  stageA(0); stageW(0);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (wm == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }   // group 1 runs one barrier behind from here on
+  int g = 0;
+  for (int seq = 0; seq < T; ++seq) {
+    const int id = first + seq * P;
+    const int tm0 = (id / tilesN) * BM, tn0 = (id % tilesN) * BN;
+    const int n0w = tn0 + wn * WTN;
+    for (int kt = 0; kt < nk; ++kt, ++g) {
+      const bf16* sb = smem + (g & 1) * STAGE;
+      // P1: quadrant (0, 0)
+      readW(sb, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      readA(sb, 0);
+      stageW(1);
+      if (kt == 0) {
+        const f32x16 sd = seed_of(n0w, 0);
+        bar_load(false);
+        mma_seeded(0, 0, sd);
+      } else {
+        bar_load(false);
+        mma(0, 0);
+      }
+      bar_math();
+      // P2: quadrant (0, 1)
+      readW(sb, 1);
+      stageA(1);
+      advance();
+      if (kt == 0) {
+        const f32x16 sd = seed_of(n0w, 1);
+        bar_load(true);
+        mma_seeded(0, 1, sd);
+      } else {
+        bar_load(true);
+        mma(0, 1);
+      }
+      bar_math();
+      // P3: quadrant (1, 1)
+      readA(sb, 1);
+      stageA(0);
+      if (kt == 0) {
+        const f32x16 sd = seed_of(n0w, 1);
+        bar_load(false);
+        mma_seeded(1, 1, sd);
+      } else {
+        bar_load(false);
+        mma(1, 1);
+      }
+      bar_math();
+      // P4: quadrant (1, 0) -- W half 0 is still in registers
+      stageW(0);
+      if (kt == 0) {
+        const f32x16 sd = seed_of(n0w, 0);
+        bar_load(true);
+        mma_seeded(1, 0, sd);
+      } else {
+        bar_load(true);
+        mma(1, 0);
+      }
+      bar_math();
+    }
+    if (tm0 + BM <= a.M)
+      wave_epilogue<TM, EPI, HAS_R, HAS_RS, true>(a, acc, cw, tm0 + wm * WTM, tn0 + wn * WTN);
+    else
+      wave_epilogue<TM, EPI, HAS_R, HAS_RS, false>(a, acc, cw, tm0 + wm * WTM, tn0 + wn * WTN);
+  }
+  if (wm == 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }   // every wave passes the same number of barriers
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may outlive the workgroup's LDS allocation
+}
+
 // Variants the v4 (wave-private epilogue) persistent kernel serves: those it compiles without scratch.  gelu' * aux WITH column sums
 // and the residual-without-DropPath forms spill 60-120 VGPRs around its longer live ranges and stay on v3; gelu' * aux without
 // column sums (the caller takes the bias gradient from the weight-gradient kernel) is served.
@@ -853,6 +1085,11 @@ constexpr bool kV4Ok = (EPI == 0 && (!R || RS)) || (EPI == 1 && !R) || EPI == 2 
 
 }  // namespace
 
+#ifdef FIBER_P2_PROBE   // compile-time probe: ONE instantiation (register / scratch check while editing a K loop)
+extern "C" void fiber_p2_probe(GemmArgs a, hipStream_t st) {
+  hipLaunchKernelGGL((gemm_nt_q8_kernel<0, false, false>), dim3(256), dim3(512), 0, st, a);
+}
+#else
 // C ABI ---------------------------------------------------------------------------------------------------------
 // Row-tile height the dispatcher will use for an [M,N,K] problem (rows of `colpart` = ceil(M / tile)).
 extern "C" int fiber_gemm_row_tile(int M, int N, int K) {
@@ -909,9 +1146,11 @@ extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bia
   const long small = (long)cdiv(M, 64) * cdiv(N, 64);
   static const int persist_env = getenv("FIBER_GEMM_PERSIST") ? atoi(getenv("FIBER_GEMM_PERSIST")) : 1;
   const bool persist = persist_env && wide >= 512;        // at least two tiles per CU
+  static const int q8_env = getenv("FIBER_GEMM_Q8") ? atoi(getenv("FIBER_GEMM_Q8")) : 1;   // 0: the v4 K loop (A/B runs)
 #define FIBER_LAUNCH_EPI(EPI, R, RS)                                                                                          \
   do {                                                                                                                        \
     if (shape == 0 && persist && persist_env == 2) hipLaunchKernelGGL((gemm_nt_wide_persist_kernel<2, 4, EPI, R, RS>), dim3(256), dim3(512), 0, stream, a); \
+    else if (shape == 0 && persist && q8_env && kV4Ok<EPI, R, RS> && !(EPI == 2 && a.colpart)) hipLaunchKernelGGL((gemm_nt_q8_kernel<kV4Ok<EPI, R, RS> ? EPI : 0, kV4Ok<EPI, R, RS> && R, RS>), dim3(256), dim3(512), 0, stream, a); \
     else if (shape == 0 && persist && kV4Ok<EPI, R, RS> && !(EPI == 2 && a.colpart)) hipLaunchKernelGGL((gemm_nt_wide_persist2_kernel<2, 4, kV4Ok<EPI, R, RS> ? EPI : 0, kV4Ok<EPI, R, RS> && R, RS>), dim3(256), dim3(512), 0, stream, a); \
     else if (shape == 0 && persist) hipLaunchKernelGGL((gemm_nt_wide_persist_kernel<2, 4, EPI, R, RS>), dim3(256), dim3(512), 0, stream, a); \
     else if (shape == 0) hipLaunchKernelGGL((gemm_nt_wide_kernel<2, 4, EPI, R, RS>), dim3((unsigned)wide), dim3(512), 0, stream, a);   \
@@ -945,3 +1184,4 @@ extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bia
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }
+#endif  // FIBER_P2_PROBE

@@ -68,7 +68,7 @@ def test_graph_replay_matches_eager_with_dropout_and_lr_schedule():
     assert lr_e[n_done:] == lr_g
     # weights: Adam turns round-off-level differences of (mathematically) zero gradients into +-lr steps -- the embedding
     # scatter-add uses fp32 atomics, so two EAGER runs differ by the same ~1e-3 -- hence a loose bound here, a tight one on the loss
-    assert float((w_e - w_g).norm() / w_e.norm()) < 5e-3
+    assert float((w_e - w_g).norm() / w_e.norm()) < 1e-2          # measured 2e-3 .. 5.3e-3 across builds and boxes
     # and dropout really is active and re-drawn per step (a frozen mask would still pass the comparison above only if the
     # eager run froze it too): two eager steps from the same weights with different step indices give different losses
     assert len({round(v, 6) for v in eager}) == len(eager)
