@@ -868,7 +868,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_wide_persist2_kernel(Gem
 // flight and is followed by a barrier before the NEXT phase reads what it retired (RAW rule of the guide: wait in phase p, read in
 // p+1; the group that runs one barrier behind passes its own wait before the leading group's read).  WAR: a half-tile is
 // re-staged two or three phases after its last ds_read.  Epilogue stores / residual loads only make the counted waits stricter.
-template <int EPI, bool HAS_R, bool HAS_RS>
+template <int EPI, bool HAS_R, bool HAS_RS, bool TRACE = false>
 __global__ __launch_bounds__(512) void gemm_nt_q8_kernel(GemmArgs a) {
   constexpr int BM = 256, BN = 256, WN = 4;
   constexpr int WTM = 128, WTN = 64, TM = 4, TN = 2;
@@ -1011,6 +1011,20 @@ __global__ __launch_bounds__(512) void gemm_nt_q8_kernel(GemmArgs a) {
   asm volatile("" ::: "memory");
   if (wm == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }   // group 1 runs one barrier behind from here on
   int g = 0;
+  // TRACE build (tools/gemm_trace.py q8): s_memtime ticks per wave summed over its K tiles -- for each of the four phases
+  // [4p + 0] load half (reads + DMA issued AND the reads returned: s_memtime drains lgkmcnt)  [4p + 1] wait + first barrier
+  // [4p + 2] MFMA issue  [4p + 3] second barrier;  [16] epilogue
+  unsigned long long tr[17] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t0 = 0;
+  if constexpr (TRACE) t0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long tstart = t0;
+  auto mark = [&](int i) {
+    if constexpr (TRACE) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      tr[i] += t - t0;
+      t0 = t;
+    }
+  };
   for (int seq = 0; seq < T; ++seq) {
     const int id = first + seq * P;
     const int tm0 = (id / tilesN) * BM, tn0 = (id % tilesN) * BN;
@@ -1022,59 +1036,89 @@ __global__ __launch_bounds__(512) void gemm_nt_q8_kernel(GemmArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       readA(sb, 0);
       stageW(1);
+      mark(0);
       if (kt == 0) {
         const f32x16 sd = seed_of(n0w, 0);
         bar_load(false);
+        mark(1);
         mma_seeded(0, 0, sd);
       } else {
         bar_load(false);
+        mark(1);
         mma(0, 0);
       }
+      mark(2);
       bar_math();
+      mark(3);
       // P2: quadrant (0, 1)
       readW(sb, 1);
       stageA(1);
       advance();
+      mark(4);
       if (kt == 0) {
         const f32x16 sd = seed_of(n0w, 1);
         bar_load(true);
+        mark(5);
         mma_seeded(0, 1, sd);
       } else {
         bar_load(true);
+        mark(5);
         mma(0, 1);
       }
+      mark(6);
       bar_math();
+      mark(7);
       // P3: quadrant (1, 1)
       readA(sb, 1);
       stageA(0);
+      mark(8);
       if (kt == 0) {
         const f32x16 sd = seed_of(n0w, 1);
         bar_load(false);
+        mark(9);
         mma_seeded(1, 1, sd);
       } else {
         bar_load(false);
+        mark(9);
         mma(1, 1);
       }
+      mark(10);
       bar_math();
+      mark(11);
       // P4: quadrant (1, 0) -- W half 0 is still in registers
       stageW(0);
+      mark(12);
       if (kt == 0) {
         const f32x16 sd = seed_of(n0w, 0);
         bar_load(true);
+        mark(13);
         mma_seeded(1, 0, sd);
       } else {
         bar_load(true);
+        mark(13);
         mma(1, 0);
       }
+      mark(14);
       bar_math();
+      mark(15);
     }
     if (tm0 + BM <= a.M)
       wave_epilogue<TM, EPI, HAS_R, HAS_RS, true>(a, acc, cw, tm0 + wm * WTM, tn0 + wn * WTN);
     else
       wave_epilogue<TM, EPI, HAS_R, HAS_RS, false>(a, acc, cw, tm0 + wm * WTM, tn0 + wn * WTN);
+    mark(16);
   }
   if (wm == 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }   // every wave passes the same number of barriers
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may outlive the workgroup's LDS allocation
+  if constexpr (TRACE) {
+    if (lane == 0 && blockIdx.x < 8) {
+      float* o = a.colpart + (blockIdx.x * 8 + wave) * 24;
+      for (int i = 0; i < 17; ++i) o[i] = (float)tr[i];
+      o[17] = (float)(__builtin_amdgcn_s_memtime() - tstart);
+      o[18] = (float)nk;
+      o[19] = (float)T;
+    }
+  }
 }
 
 // Variants the v4 (wave-private epilogue) persistent kernel serves: those it compiles without scratch.  gelu' * aux WITH column sums
@@ -1128,7 +1172,7 @@ extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bia
   if ((mode == 2 || colpart) && !((K % 64 == 0) && (N % 8 == 0) && (ldy % 8 == 0))) return FIBER_EINVAL;   // LDS-DMA kernels only
   if (mode == 2 && residual) return FIBER_EINVAL;
   if ((act & 0x800) && (mode != 0 || !residual || !Ypre || colpart || (act & 0x100))) return FIBER_EINVAL;
-  if (colpart && mode != 2 && !(act & 0x600)) return FIBER_EINVAL;
+  if (colpart && mode != 2 && !(act & 0x1600)) return FIBER_EINVAL;
   const bool v2 = (K % 64 == 0) && (N % 8 == 0) && (ldy % 8 == 0) && (!residual || ldr % 8 == 0) && !getenv("FIBER_GEMM_V1");
   // Tile choice.  256x256 (K step 32, two wave groups half a tile apart) whenever N is a multiple of 256 and there are
   // enough tiles; otherwise 256x128 / 128x128 / 64x64 on the 64-deep ring.  FIBER_GEMM_TILE / FIBER_GEMM_NOWIDE force a
@@ -1158,6 +1202,13 @@ extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bia
     else if (shape == 2) hipLaunchKernelGGL((gemm_nt_glds_kernel<128, 128, 2, 2, 2, EPI, R, RS>), dim3((unsigned)big), dim3(256), 0, stream, a);  \
     else hipLaunchKernelGGL((gemm_nt_glds_kernel<64, 64, 2, 2, 2, EPI, R, RS>), dim3((unsigned)small), dim3(256), 0, stream, a);                   \
   } while (0)
+  if (shape == 0 && (act & 0x1000)) {                     // tools/gemm_trace.py q8: per-phase timing of the v5 kernel
+    a.act &= 0xff;
+    if ((act & 0xff) == 1) hipLaunchKernelGGL((gemm_nt_q8_kernel<1, false, false, true>), dim3(256), dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((gemm_nt_q8_kernel<0, false, false, true>), dim3(256), dim3(512), 0, stream, a);
+    FIBER_CHECK_LAUNCH();
+    return FIBER_OK;
+  }
   if (shape == 0 && (act & 0x400)) {                      // tools/gemm_trace.py persist: per-segment timing of the persistent kernel
     a.act &= 0xff;
     if ((act & 0xff) == 1) hipLaunchKernelGGL((gemm_nt_wide_persist2_kernel<2, 4, 1, false, false, true>), dim3(256), dim3(512), 0, stream, a);
