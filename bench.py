@@ -144,36 +144,95 @@ def cpu_baseline(budget_s=80.0, batch=2):
     return dict(base, value=round(batch / b, 4), cores=t)
 
 
+def _dominant_from_profile(B):
+    """The (entry point, shape) with the largest share of the step in the committed per-shape profile of this bench
+    (profiles/r03_shape_breakdown.json, written by tools/shape_breakdown.py at the bench batch); None when the file is missing or
+    was taken at another batch."""
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r03_shape_breakdown.json")))
+    except (OSError, ValueError):
+        return None
+    if prof.get("batch") != B:
+        return None
+    rows = [r for r in prof["rows"] if "kind" in r]
+    return (rows[0], prof["single_stream_step_ms"]) if rows else None
+
+
 def time_dominant_kernel(B, device):
-    """Live HIP-event timing of the dominant hand-written kernel: the MFMA GEMM at the Swin stage-2 MLP fc1 shape
-    (M = B*576, N = 2048, K = 512, bias + GELU epilogue) -- 18 of the 24 Swin blocks run it."""
+    """Live HIP-event timing of the dominant hand-written kernel.  WHICH kernel that is comes from the committed per-shape
+    profile (largest ms per step over all (entry point, shape) pairs); without a profile for this batch it falls back to the
+    stage-2 MLP fc1 GEMM (bias + GELU + pre-activation store).  Reports the achieved fraction of BOTH rooflines (algorithmic
+    bytes / time against HBM, algorithmic FLOPs / time against dense bf16 MFMA); `bound` names the tighter one, i.e. the resource
+    whose floor is higher for this shape."""
     from fiber_amd import ops
-    M, N, K = 2 * B * 576, 2048, 512            # one fused 2B-sample pass
-    x = torch.randn(M, K, device=device).to(torch.bfloat16)
-    w = (torch.randn(N, K, device=device) * K ** -0.5).to(torch.bfloat16)
-    bias = torch.randn(N, device=device)
+    dom = _dominant_from_profile(B)
+    if dom is None:
+        row = {"entry": "fiber_gemm_nt_bf16", "kind": "NT gelu+pre", "shape": [2 * B * 576, 2048, 512], "ms_per_step": None}
+        step_ms = None
+    else:
+        row, step_ms = dom
+    M, N, K = row["shape"]
+    kind = row["kind"]
+    bf = torch.bfloat16
+    rs = torch.ones(M // 576 if M % 576 == 0 else 1, device=device)
+    rps = M // rs.numel()
+    if row["entry"] == "fiber_gemm_tn_bf16":
+        dy = torch.randn(M, N, device=device).to(bf)
+        x = torch.randn(M, K, device=device).to(bf)
+        fn = lambda: ops.wgrad(dy, x, want_bias=True)
+        alg_bytes = 2 * M * (N + K) + 4 * N * K
+        name = "gemm_tn_kernel<256,64,2,true> + tn_fold_kernel (weight + bias gradient)"
+    else:
+        x = torch.randn(M, K, device=device).to(bf)
+        w = (torch.randn(N, K, device=device) * K ** -0.5).to(bf)
+        bias = torch.randn(N, device=device)
+        alg_bytes = 2 * (M * K + N * K + M * N)
+        if kind.startswith("NT gelu'"):
+            aux = torch.randn(M, N, device=device).to(bf)
+            dp = "droppath" in kind
+            fn = lambda: ops.gemm_nt(x, w, None, None, 2, False, rs if dp else None, rps if dp else 0, aux=aux)
+            alg_bytes += 2 * M * N
+            name = "gemm_nt_q8_kernel<2,...> ((dY.W2^T) * gelu'(H) fused MLP backward)"
+        elif kind == "NT gelu+pre":
+            fn = lambda: ops.gemm_nt(x, w, bias, None, 1, True)
+            alg_bytes += 2 * M * N
+            name = "gemm_nt_q8_kernel<1,false,false> (fc1: bias + GELU + pre-activation store)"
+        elif kind.startswith("NT residual"):
+            r = torch.randn(M, N, device=device).to(bf)
+            dp = "droppath" in kind
+            fn = lambda: ops.gemm_nt(x, w, bias, r, 0, False, rs if dp else None, rps if dp else 0)
+            alg_bytes += 2 * M * N
+            name = "gemm_nt_q8_kernel<0,true,...> (bias + DropPath scale + residual)"
+        else:
+            fn = lambda: ops.gemm_nt(x, w, bias)
+            name = "gemm_nt_q8_kernel<0,false,false> (plain / bias)"
     for _ in range(5):
-        ops.gemm_nt(x, w, bias, None, 1, True)
+        fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 50
     e0.record()
     for _ in range(reps):
-        ops.gemm_nt(x, w, bias, None, 1, True)
+        fn()
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
-    tf = 2.0 * M * N * K / (us * 1e-6) / 1e12
-    alg_bytes = 2 * (M * K + N * K + 2 * M * N)          # X, W in; Y and the saved pre-activation out
-    # 618.5 GFLOP over 2.72 GB = 227 flop/B, BELOW the machine balance (2500 TFLOP/s / 8 TB/s = 312 flop/B): with its two
-    # output streams this kernel is HBM-bound by construction (floor 340 us at 8 TB/s vs 247 us of MFMA time), so its
-    # roofline is stated against HBM bandwidth; the MFMA fraction is given beside it.
+    flops = 2.0 * M * N * K
+    tf = flops / (us * 1e-6) / 1e12
     gbps = alg_bytes / us / 1e3
-    out = {"kernel": "gemm_nt_wide_persist2_kernel<2,4,1,false,false> (stage-2 fc1: bias + GELU + pre-activation store)", "shape": [M, N, K], "us": round(us, 2),
-           "bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
-           "algorithmic_bytes": alg_bytes, "mfma_TFLOPs": round(tf, 1), "mfma_frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None}
-    try:   # HBM bytes per launch from the committed PMC pass (profiles/, collected with rocprofv3 --pmc on this same shape)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_kernels.json")))["gemm"]
-        if pmc["algorithmic_bytes_per_launch"] == alg_bytes:      # same shape as the PMC pass (tools/pmc_gemm.py at the bench batch)
+    # which roofline bounds this shape: the one with the higher floor (time at peak)
+    hbm_floor_us, mfma_floor_us = alg_bytes / PEAK_HBM_GBPS / 1e3, flops / PEAK_BF16_TFLOPS / 1e6
+    bound = "hbm" if hbm_floor_us >= mfma_floor_us else "mfma"
+    out = {"kernel": name, "entry": row["entry"], "kind": kind, "shape": [M, N, K], "us": round(us, 2),
+           "share_of_step": (round(row["ms_per_step"] / step_ms, 4) if step_ms else None),
+           "selected_from": "profiles/r03_shape_breakdown.json (largest ms per step)" if dom else "default (no profile at this batch)",
+           "bound": bound, "flop_per_byte": round(flops / alg_bytes, 1),
+           "achieved": round(gbps if bound == "hbm" else tf, 1), "peak": PEAK_HBM_GBPS if bound == "hbm" else PEAK_BF16_TFLOPS,
+           "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round((gbps / PEAK_HBM_GBPS) if bound == "hbm" else (tf / PEAK_BF16_TFLOPS), 4),
+           "hbm_GBps": round(gbps, 1), "hbm_frac": round(gbps / PEAK_HBM_GBPS, 4), "mfma_TFLOPs": round(tf, 1),
+           "mfma_frac": round(tf / PEAK_BF16_TFLOPS, 4), "algorithmic_bytes": alg_bytes, "traffic": None}
+    try:   # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs on this shape)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_kernels.json")))["dominant"]
+        if pmc["algorithmic_bytes_per_launch"] == alg_bytes and pmc.get("shape") == [M, N, K]:
             out["traffic"] = int(pmc["traffic_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         pass
@@ -344,12 +403,13 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": task["workload"], "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "dropout": "reference defaults (text 0.1, DropPath linspace 0..0.1)",
+                       "residual_dtype": "fp32" if ops.residual_fp32() else "bf16",
                        "launch": "hipGraph replay of the captured step" if use_graph else "eager (one launch per kernel)"},
             "loss": round(lossv, 4),
             "step_ms": {"p10": round(pct(0.1), 3), "median": round(pct(0.5), 3), "p90": round(pct(0.9), 3),
                         "per_rank_mean": [round(x, 3) for x in per_rank_ms], "allreduce_exposed": exposed_allreduce_ms,
-                        "grad_allreduce": ("bf16 buckets (bf16_compress_hook), 64 MB, reverse execution order after step 0"
-                                           if world > 1 else None)},
+                        "grad_allreduce": (("bf16 buckets (bf16_compress_hook)" if os.environ.get("FIBER_DDP_BF16") == "1" else "fp32 buckets")
+                                           + ", 64 MB, reverse execution order after step 0" if world > 1 else None)},
             "roofline": {"bound": "mfma", "achieved": round(tf_per_gpu, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tf_per_gpu / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "basis": f"{task['flop'] / 1e9:.1f} GFLOP algorithmic per image per step (BASELINE.md section 3 / SURVEY.md "

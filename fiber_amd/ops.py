@@ -358,7 +358,21 @@ def cross_entropy(logits, labels, ignore_index=-100):
     return _CrossEntropy.apply(logits, labels, ignore_index)
 
 
+# Call sites of the library GEMM (file names), recorded when a test switches it on: the library is allowed for the caller-side heads
+#  and the ITC similarity matrices only -- tests/test_hip_modules.py::test_library_gemm_only_from_heads.
+lib_gemm_sites = None
+
+
+def _note_lib_site(depth=2):
+    if lib_gemm_sites is not None:
+        import sys
+        f = sys._getframe(depth)
+        lib_gemm_sites[os.path.basename(f.f_code.co_filename) + ":" + f.f_code.co_name] = lib_gemm_sites.get(
+            os.path.basename(f.f_code.co_filename) + ":" + f.f_code.co_name, 0) + 1
+
+
 def lib_linear(x, w, b=None):
+    _note_lib_site()
     return _LibLinear.apply(x, w, b)
 
 
@@ -504,8 +518,9 @@ def linear(x, weight, bias=None, residual=None, act=None, rowscale=None, rowscal
     """nn.Linear with fused bias / exact GELU / residual, forward and both backward GEMMs on the hand-written kernels.
     A library GEMM is used only for shapes the tile kernels do not cover (N % 8 != 0, e.g. the 2-way ITM head, or K % 8 != 0)."""
     N, K = weight.shape
-    if (N % 8) or (K % 8):
-        y = torch.nn.functional.linear(x, weight.to(BF16), bias.to(BF16) if bias is not None else None)
+    if (N % 8) or (K % 8):                                 # no backbone linear has such a shape; odd test / head shapes only
+        _note_lib_site()
+        y = _LibLinear.apply(x, weight.to(BF16), bias.to(BF16) if bias is not None else None)
         if act:
             y = torch.nn.functional.gelu(y)
         assert rowscale is None
@@ -519,8 +534,9 @@ class _MLP(torch.autograd.Function):
 
     Forward: two MFMA GEMMs (bias+GELU epilogue saving the pre-activation; bias+DropPath scale+residual epilogue).
     Backward: dH = (dY . W2) * gelu'(H) is ONE hand-written GEMM whose epilogue applies the GELU derivative to the saved
-    pre-activation and emits the fc1 bias gradient (column sums) -- dG never exists in HBM and the separate gelu_bwd and
-    column-sum passes over the 4C-wide tensor disappear.  The remaining plain GEMMs (dX, dW1, dW2) use the library."""
+    pre-activation (and the DropPath factor of the branch) -- dG never exists in HBM and the separate gelu_bwd pass over the
+    4C-wide tensor disappears.  dX = dH . W1 runs on the same NT kernel family (transposed working copy of W1), dW1 / dW2 and
+    both bias gradients on the TN kernel (csrc/gemm_tn.hip); no library GEMM is involved."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, residual, rowscale, rs_value=None, res32=None):

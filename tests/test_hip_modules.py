@@ -609,3 +609,33 @@ def test_loss_curve_fiber_base_384_mlm_itm_8_steps():
     384^2 are what bounds the length).  Bound = 2x the measured values (profiles/r02_loss_curve_fiber_base.json)."""
     summary = _loss_curve(dict(cases.SWIN_B), 384, 2, 8, 2, 2, "fiber_base")
     assert summary["gap_max"] < 2.5e-2 and summary["gap_median"] < 1.0e-2, summary
+
+
+def test_library_gemm_only_from_heads():
+    """The library GEMM (hipBLASLt through torch) is allowed for the caller-side heads (vocabulary decoder, 2-way
+    ITM classifier, VQA classifier) and the ITC similarity matrices -- nothing inside the two backbones may reach it, neither through
+    ops.lib_linear nor through the odd-shape fallback of ops.linear.  One MLM + ITM + ITC training step and one VQA step of the tiny
+    configurations with every call site recorded."""
+    from fiber_amd import ops
+    from fiber_amd.config import make_config
+    from fiber_amd.modules import FIBERTransformerSS, fiber_utils
+    sites = {}
+    ops.lib_gemm_sites = sites
+    try:
+        for case in (cases.ITC_CASES["itc_tiny"], cases.VQA_CASES["vqa_tiny576"]):
+            cfg = dict(case["config"])
+            model = FIBERTransformerSS(make_config(**cfg)).train()
+            detgen.fill_(model)
+            model.to(DEV)
+            fiber_utils.set_task(model)
+            c = model.config
+            b = detgen.synth_batch(case["B"], c["image_size"], c["max_text_len"], c["vocab_size"], seed=3, min_len=6)
+            if c["loss_names"].get("vqa", 0) > 0:
+                b.update(detgen.synth_vqa(case["B"], c["vqav2_label_size"], seed=3))
+            loss = model.training_step(_to_dev(b), 0)
+            loss.backward()
+    finally:
+        ops.lib_gemm_sites = None
+    assert sites, "the heads should have used the library GEMM"
+    allowed = ("heads.py:", "objectives.py:")
+    assert all(k.startswith(allowed) for k in sites), sites
