@@ -62,18 +62,21 @@ class RobertaSelfAttention(nn.Module):
 
     def forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None):
         B, S, _ = hidden_states.shape
-        q = ops.linear(hidden_states, self.query.weight, self.query.bias).view(B * S, self.all_head_size)
-        if encoder_hidden_states is not None:
-            src, mask = encoder_hidden_states, None                          # roberta.py:276: cross-attn mask is None
-        else:
-            src, mask = hidden_states, attention_mask
-        Lk = src.shape[1]
-        k = ops.linear(src, self.key.weight, self.key.bias).view(B * Lk, self.all_head_size)
-        v = ops.linear(src, self.value.weight, self.value.bias).view(B * Lk, self.all_head_size)
+        C, scale = self.all_head_size, 1.0 / math.sqrt(self.attention_head_size)
         p = self.dropout.p if self.training else 0.0
-        o = ops.mha(q, k, v, mask, B, self.num_attention_heads, 1.0 / math.sqrt(self.attention_head_size), p,
-                    ops.next_seed() if p > 0 else 0)
-        return o.view(B, S, self.all_head_size)
+        seed = ops.next_seed() if p > 0 else 0
+        if encoder_hidden_states is None:
+            # q, k, v of one input as ONE GEMM (three nn.Linear modules in the state dict, roberta.py:231-241)
+            qkv = ops.linear_packed(hidden_states, [(self.query.weight, self.query.bias), (self.key.weight, self.key.bias),
+                                                    (self.value.weight, self.value.bias)])
+            o = ops.mha_qkv_packed(qkv.view(B * S, 3 * C), attention_mask, B, self.num_attention_heads, scale, p, seed)
+        else:
+            # t2i: keys / values from the image tokens as one GEMM; roberta.py:276: the cross-attention mask is None
+            q = ops.linear(hidden_states, self.query.weight, self.query.bias).view(B * S, C)
+            Lk = encoder_hidden_states.shape[1]
+            kv = ops.linear_packed(encoder_hidden_states, [(self.key.weight, self.key.bias), (self.value.weight, self.value.bias)])
+            o = ops.mha_kv_packed(q, kv.view(B * Lk, 2 * C), None, B, self.num_attention_heads, scale, p, seed)
+        return o.view(B, S, C)
 
 
 class RobertaSelfOutput(nn.Module):

@@ -59,7 +59,11 @@ def bf16_weight(w):
     hit = _cache_get(key, w)
     if hit is not None and hit[0] == _stamp(w):
         return hit[1]
-    wb = w.detach().to(BF16).contiguous()
+    if hit is not None and hit[1].shape == w.shape and hit[1].device == w.device:
+        wb = hit[1]
+        wb.copy_(w.detach())                             # same storage: views into packed buffers / optimizer tables stay valid
+    else:
+        wb = w.detach().to(BF16).contiguous()
     _cache_put(key, _stamp(w), wb, w)
     return wb
 
@@ -105,6 +109,14 @@ def refresh_transposed_copies():
         if (wt.shape[0] % 8) or (wt.shape[1] % 8):
             continue
         by_dev.setdefault(wt.device, []).append((key, w, plain[1], wt, ref))
+    for pk in list(_packs.values()):                      # packed projections (linear_packed): ONE descriptor per pack
+        ws = [r() for r in pk["refs"]]
+        if any(w is None for w in ws) or not pk["plain"].is_cuda:
+            continue
+        hits = [_cache_get(id(w), w) for w in ws]
+        if any(h is None or h[0] != _stamp(w) for h, w in zip(hits, ws)) or not _pack_views_ok(pk, ws):
+            continue                                         # some member stale: the lazy path (_pack_get) refreshes
+        by_dev.setdefault(pk["plain"].device, []).append((None, pk, pk["plain"], pk["t"], None))
     for dev, items in by_dev.items():
         members = tuple((p.data_ptr(), t.data_ptr()) for _, _, p, t, _ in items)
         ent = _t_table.get(dev)
@@ -120,7 +132,10 @@ def refresh_transposed_copies():
         with torch.cuda.device(dev):
             lib.call("fiber_transpose_multi_bf16", lib.ptr(ent[1]), len(items), ent[2])
         for key, w, _, wt, ref in items:
-            _wcache[key] = (_stamp(w), wt, ref)
+            if key is None:
+                w["t_stamp"] = tuple(_stamp(r()) for r in w["refs"])     # a pack: its transposed copy is current
+            else:
+                _wcache[key] = (_stamp(w), wt, ref)
 
 
 def bf16_copy_if_cached(w):
@@ -147,6 +162,7 @@ def cast_bf16(w):
 
 def clear_weight_cache():
     _wcache.clear()
+    _packs.clear()
 
 
 def _rows(x):
@@ -841,6 +857,111 @@ def linear_qkv_head_major(x, weight, bias, heads):
     return _LinearQKVHeadMajor.apply(x, weight, bias, heads)
 
 
+# ---- packed projections ---------------------------------------------------------------------------------------------------------
+# q / k / v of RobertaSelfAttention (roberta.py:256-290) and key / value of the t2i cross-attention are separate nn.Linear modules
+# (separate state-dict keys) applied to the SAME input.  Here they run as ONE GEMM: the bf16 working copies of the member weights
+# are row slices of one [sum N, K] buffer (registered in the weight cache as the members' own working copies, so the fused
+# optimizer kernel rewrites the packed buffer in place), its transposed copy is one entry of the multi-tensor transpose, and the
+# member BIASES (fp32 parameters) are re-pointed at slices of one fp32 buffer (same values, same Parameter objects, shared
+# storage) -- no per-step gather of either.  One forward GEMM, one dgrad, one wgrad (+ fold) instead of three each, and no
+# autograd fan-in adds of the three input gradients.
+_packs = {}
+
+
+def _pack_views_ok(pk, ws):
+    off = 0
+    for w, n in zip(ws, pk["Ns"]):
+        hit = _cache_get(id(w), w)
+        if hit is None or hit[1].data_ptr() != pk["plain"].data_ptr() + off * pk["K"] * 2:
+            return False
+        off += n
+    return True
+
+
+def _pack_get(weights, biases):
+    key = tuple(id(w) for w in weights)
+    pk = _packs.get(key)
+    dev = weights[0].device
+    if pk is None or pk["plain"].device != dev or any(r() is not w for r, w in zip(pk["refs"], weights)):
+        Ns, K = [w.shape[0] for w in weights], weights[0].shape[1]
+        pk = {"plain": torch.empty((sum(Ns), K), dtype=BF16, device=dev), "t": torch.empty((K, sum(Ns)), dtype=BF16, device=dev),
+              "refs": [weakref.ref(w, lambda _r, k=key: _packs.pop(k, None)) for w in weights], "Ns": Ns, "K": K, "t_stamp": None,
+              "bias": None}
+        _packs[key] = pk
+        _t_registry_version[0] += 1
+    if not _pack_views_ok(pk, weights):                     # (re-)register the members' working copies as views of the pack
+        off = 0
+        for w, n in zip(weights, pk["Ns"]):
+            view = pk["plain"][off:off + n]
+            view.copy_(w.detach())
+            _cache_put(id(w), _stamp(w), view, w)
+            off += n
+        pk["t_stamp"] = None
+    else:
+        for w in weights:                                   # stale member (parameter changed outside the fused optimizer)
+            if _cache_get(id(w), w)[0] != _stamp(w):
+                bf16_weight(w)                              # in-place refresh of the view
+                pk["t_stamp"] = None
+    stamps = tuple(_stamp(w) for w in weights)
+    if pk["t_stamp"] != stamps:
+        pk["t"].copy_(pk["plain"].t())
+        pk["t_stamp"] = stamps
+    if biases[0] is not None:
+        bp, off, ok = pk["bias"], 0, pk["bias"] is not None
+        for b, n in zip(biases, pk["Ns"]):
+            ok = ok and b.data_ptr() == bp.data_ptr() + off * 4
+            off += n
+        if not ok:                                          # first use / the parameters moved (model.to, load with assign)
+            with torch.no_grad():
+                bp = torch.cat([b.detach().float().reshape(-1) for b in biases])
+                off = 0
+                for b, n in zip(biases, pk["Ns"]):
+                    b.data = bp[off:off + n]                # same values, shared storage: optimizer updates land in the pack
+                    off += n
+            pk["bias"] = bp
+    return pk
+
+
+class _LinearPacked(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, n, *wb):
+        weights, biases = wb[0::2], wb[1::2]
+        pk = _pack_get(weights, biases)
+        shp = x.shape
+        x2 = _c(x).view(-1, shp[-1])
+        y, _ = gemm_nt(x2, pk["plain"], pk["bias"])
+        ctx.save_for_backward(x2)
+        ctx.pk, ctx.shp, ctx.has_bias = pk, shp, biases[0] is not None
+        return y.view(*shp[:-1], pk["plain"].shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2,) = ctx.saved_tensors
+        pk = ctx.pk
+        dy2 = _c(dy).view(-1, pk["plain"].shape[0])
+        _take_colsum(dy2)
+        dx = gemm_nt(dy2, pk["t"])[0].view(ctx.shp) if ctx.needs_input_grad[0] else None
+        out = wgrad(dy2, x2, want_bias=ctx.has_bias)
+        dw, db = out if ctx.has_bias else (out, None)
+        grads, off = [], 0
+        for n in pk["Ns"]:
+            grads += [dw[off:off + n], db[off:off + n] if db is not None else None]
+            off += n
+        return (dx, None, *grads)
+
+
+def linear_packed(x, linears):
+    """[x W0^T + b0 | x W1^T + b1 | ...] for nn.Linear-like (weight, bias) pairs that share the input: one GEMM (see above).
+    Falls back to separate GEMMs + cat for shapes the tile kernels do not cover."""
+    weights = [w for w, _ in linears]
+    biases = [b for _, b in linears]
+    K = weights[0].shape[1]
+    if any(w.shape[1] != K or w.shape[0] % 8 for w in weights) or K % 8 or any((b is None) != (biases[0] is None) for b in biases):
+        return torch.cat([linear(x, w, b) for w, b in linears], dim=-1)
+    flat = [t for pair in zip(weights, biases) for t in pair]
+    return _LinearPacked.apply(x, len(weights), *flat)
+
+
 def _ld(t):
     assert t.dim() == 2 and t.stride(1) == 1
     return t.stride(0)
@@ -880,6 +1001,66 @@ def mha(q, k, v, kmask, B, heads, scale, p_drop=0.0, seed=0):
     if kmask is not None:
         kmask = _c(kmask.view(B, -1).float())
     return _MHA.apply(q, k, v, kmask, B, heads, float(scale), float(p_drop), int(seed))
+
+
+class _MHAPacked(torch.autograd.Function):
+    """mha() on packed projections: mode 0: `a` = [q | k | v] ([B*L, 3*heads*D], self-attention), mode 1: `a` = q, `b` = [k | v].
+    The backward kernel writes dq / dk / dv straight into the column blocks of ONE packed gradient per input, so the projection's
+    backward is one dgrad + one wgrad and autograd never assembles slices."""
+
+    @staticmethod
+    def forward(ctx, a, b, kmask, mode, B, heads, scale, p_drop, seed):
+        a = _c(a)
+        b = _c(b) if b is not None else None
+        if mode == 0:
+            C = a.shape[1] // 3
+            q, k, v = a[:, :C], a[:, C:2 * C], a[:, 2 * C:]
+        else:
+            C = a.shape[1]
+            q, k, v = a, b[:, :C], b[:, C:]
+        D = C // heads
+        Lq, Lk = q.shape[0] // B, k.shape[0] // B
+        o = torch.empty((q.shape[0], C), dtype=BF16, device=a.device)
+        lse = torch.empty((q.shape[0], heads), dtype=torch.float32, device=a.device)
+        base = seed_base_ptr()
+        lib.call("fiber_mha_fwd_bf16", lib.ptr(q), lib.ptr(k), lib.ptr(v), lib.ptr(kmask), lib.ptr(o), lib.ptr(lse), B, heads, Lq, Lk, D,
+                 _ld(q), _ld(k), _ld(v), _ld(o), scale, p_drop, seed, base)
+        ctx.save_for_backward(a, b, kmask, o, lse)
+        ctx.cfg = (mode, B, heads, Lq, Lk, D, C, scale, p_drop, seed, base)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        a, b, kmask, o, lse = ctx.saved_tensors
+        mode, B, heads, Lq, Lk, D, C, scale, p_drop, seed, base = ctx.cfg
+        do = _c(do)
+        da = torch.empty_like(a)
+        db = torch.empty_like(b) if b is not None else None
+        if mode == 0:
+            q, k, v = a[:, :C], a[:, C:2 * C], a[:, 2 * C:]
+            dq, dk, dv = da[:, :C], da[:, C:2 * C], da[:, 2 * C:]
+        else:
+            q, k, v = a, b[:, :C], b[:, C:]
+            dq, dk, dv = da, db[:, :C], db[:, C:]
+        delta = torch.empty((q.shape[0], heads), dtype=torch.float32, device=a.device)
+        lib.call("fiber_mha_bwd_bf16", lib.ptr(q), lib.ptr(k), lib.ptr(v), lib.ptr(kmask), lib.ptr(o), lib.ptr(do), lib.ptr(lse),
+                 lib.ptr(dq), lib.ptr(dk), lib.ptr(dv), lib.ptr(delta), B, heads, Lq, Lk, D, _ld(q), _ld(k), _ld(v), _ld(o), _ld(do),
+                 _ld(dq), _ld(dk), _ld(dv), scale, p_drop, seed, base)
+        return da, db, None, None, None, None, None, None, None
+
+
+def mha_qkv_packed(qkv, kmask, B, heads, scale, p_drop=0.0, seed=0):
+    """Self-attention on a packed projection qkv [B*L, 3*heads*D] = [q | k | v] (linear_packed)."""
+    if kmask is not None:
+        kmask = _c(kmask.view(B, -1).float())
+    return _MHAPacked.apply(qkv, None, kmask, 0, B, heads, float(scale), float(p_drop), int(seed))
+
+
+def mha_kv_packed(q, kv, kmask, B, heads, scale, p_drop=0.0, seed=0):
+    """Cross-attention with the key / value projections packed: q [B*Lq, heads*D], kv [B*Lk, 2*heads*D] = [k | v]."""
+    if kmask is not None:
+        kmask = _c(kmask.view(B, -1).float())
+    return _MHAPacked.apply(q, kv, kmask, 1, B, heads, float(scale), float(p_drop), int(seed))
 
 
 class _ScaleAdd(torch.autograd.Function):
