@@ -1189,7 +1189,8 @@ extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bia
   else shape = v2 ? 3 : 5;
   const long small = (long)cdiv(M, 64) * cdiv(N, 64);
   static const int persist_env = getenv("FIBER_GEMM_PERSIST") ? atoi(getenv("FIBER_GEMM_PERSIST")) : 1;
-  const bool persist = persist_env && wide >= 512;        // at least two tiles per CU
+  static const int persist_min = getenv("FIBER_GEMM_PERSIST_MIN") ? atoi(getenv("FIBER_GEMM_PERSIST_MIN")) : 200;
+  const bool persist = persist_env && wide >= persist_min;   // (q8 wins from one tile per CU on: 240 tiles 31.5 -> 28.1 us, 97.5 -> 85.1 us at K = 3072)
   static const int q8_env = getenv("FIBER_GEMM_Q8") ? atoi(getenv("FIBER_GEMM_Q8")) : 1;   // 0: the v4 K loop (A/B runs)
 #define FIBER_LAUNCH_EPI(EPI, R, RS)                                                                                          \
   do {                                                                                                                        \
