@@ -558,7 +558,8 @@ class _MLP(torch.autograd.Function):
     def forward(ctx, x, w1, b1, w2, b2, residual, rowscale, rs_value=None, res32=None):
         shp = x.shape
         x2 = _c(x).view(-1, shp[-1])
-        g, h = gemm_nt(x2, bf16_weight(w1), b1, None, 1, True)
+        need_bwd = any(ctx.needs_input_grad[:5])            # inference (no_grad / frozen): the pre-activation copy is not stored
+        g, h = gemm_nt(x2, bf16_weight(w1), b1, None, 1, need_bwd)
         rps = (x2.shape[0] // rowscale.numel()) if rowscale is not None else 0
         oshp = (*shp[:-1], w2.shape[0])
         if res32 is not None:                         # fp32 residual stream: (bf16 shadow, fp32 payload)
@@ -569,7 +570,8 @@ class _MLP(torch.autograd.Function):
             r2 = _c(residual).view(-1, w2.shape[0]) if residual is not None else None
             y, _ = gemm_nt(g, bf16_weight(w2), b2, r2, 0, False, rowscale, rps)
             y32 = None
-        ctx.save_for_backward(x2, w1, w2, h, g, rowscale)
+        if need_bwd:
+            ctx.save_for_backward(x2, w1, w2, h, g, rowscale)
         ctx.has_res, ctx.shp, ctx.rs_value = residual is not None, shp, rs_value
         return y.view(oshp), y32
 
