@@ -868,6 +868,7 @@ def linear_qkv_head_major(x, weight, bias, heads):
 # storage) -- no per-step gather of either.  One forward GEMM, one dgrad, one wgrad (+ fold) instead of three each, and no
 # autograd fan-in adds of the three input gradients.
 _packs = {}
+_NO_PACK = os.environ.get("FIBER_NO_PACK", "0") == "1"      # A/B and debugging: separate GEMMs + cat
 
 
 def _pack_views_ok(pk, ws):
@@ -918,6 +919,10 @@ def _pack_get(weights, biases):
                 bp = torch.cat([b.detach().float().reshape(-1) for b in biases])
                 off = 0
                 for b, n in zip(biases, pk["Ns"]):
+                    if b.is_cuda:
+                        # the cat above may still be QUEUED on this (second) stream when the old storage -- allocated on the default
+                        # stream -- is dropped here: without this the other stream's next allocation reuses and overwrites it first
+                        b.data.record_stream(torch.cuda.current_stream(b.device))
                     b.data = bp[off:off + n]                # same values, shared storage: optimizer updates land in the pack
                     off += n
             pk["bias"] = bp
@@ -958,7 +963,8 @@ def linear_packed(x, linears):
     weights = [w for w, _ in linears]
     biases = [b for _, b in linears]
     K = weights[0].shape[1]
-    if any(w.shape[1] != K or w.shape[0] % 8 for w in weights) or K % 8 or any((b is None) != (biases[0] is None) for b in biases):
+    if (_NO_PACK or any(w.shape[1] != K or w.shape[0] % 8 for w in weights) or K % 8
+            or any((b is None) != (biases[0] is None) for b in biases)):
         return torch.cat([linear(x, w, b) for w, b in linears], dim=-1)
     flat = [t for pair in zip(weights, biases) for t in pair]
     return _LinearPacked.apply(x, len(weights), *flat)

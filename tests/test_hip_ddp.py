@@ -112,7 +112,7 @@ def _worker_no_sync(rank, world, port, out):
     loss_of(net(micro[1])).backward()
     for mb in micro:
         loss_of(local(mb)).backward()
-    worst, worst_name = 0.0, None
+    worst, worst_name, errs = 0.0, None, []
     for (n, p), (_, q) in zip(model.named_parameters(), local.named_parameters()):
         if p.grad is None:
             assert q.grad is None, n
@@ -124,10 +124,11 @@ def _worker_no_sync(rank, world, port, out):
         # (key biases of softmax attention have mathematically ZERO gradients -- what the kernels produce for them is rounding noise of
         # the order 1e-6 whose value depends on the summation order, hence an absolute floor next to the relative measure)
         err = float((got - ref).norm() / max(float(ref.norm()), 1e-4))
+        errs.append((round(err, 5), n, round(float(ref.norm()), 6)))
         if err > worst:
             worst, worst_name = err, n
     if rank == 0:
-        torch.save({"worst": worst, "param": worst_name}, out)
+        torch.save({"worst": worst, "param": worst_name, "top": sorted(errs, reverse=True)[:8]}, out)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -639,3 +639,38 @@ def test_library_gemm_only_from_heads():
     assert sites, "the heads should have used the library GEMM"
     allowed = ("heads.py:", "objectives.py:")
     assert all(k.startswith(allowed) for k in sites), sites
+
+
+def test_packed_biases_survive_a_lagging_second_stream():
+    """The first two-stream forward re-points the q/k/v biases at slices of one packed buffer, from inside the SECOND stream;
+    the buffer is filled by a kernel that may still be queued when the old bias storage (allocated on the default stream) is
+    dropped.  With the GPU lagging behind the host (a long sleep kernel ahead of the step) the default stream's next
+    allocations used to recycle that storage before the fill had read it: garbage biases in text layers 6..11 from then on
+    (invisible with zero-initialised biases on an idle GPU; found by the 2-process DDP test).  Values must survive exactly."""
+    from fiber_amd import lib, ops, parallel
+    from fiber_amd.config import make_config
+    from fiber_amd.modules import FIBERTransformerSS, fiber_utils
+    lib.load()
+    ops.clear_weight_cache()
+    torch.manual_seed(0)
+    model = FIBERTransformerSS(make_config(**cases.TINY))
+    detgen.fill_(model)                                     # NON-zero biases
+    parallel.freeze_unused(model, model.unused_parameter_names())
+    model.to(DEV).eval()
+    fiber_utils.set_task(model)
+    before = {n: p.detach().clone() for n, p in model.named_parameters() if n.endswith(".bias")}
+    b = detgen.synth_batch(4, 96, 12, 1000, seed=40, min_len=6)
+    bd = {k: (v.to(DEV) if isinstance(v, torch.Tensor) else [t.to(DEV) for t in v] if isinstance(v, list) and isinstance(v[0], torch.Tensor) else v)
+          for k, v in b.items()}
+    bd["itm_labels_override"] = bd["itm_labels"]
+    torch.cuda.synchronize()
+    torch.cuda._sleep(int(2e9))                             # ~1 s of GPU time: the host enqueues the whole forward behind it
+    out = model(bd)
+    torch.cuda.synchronize()
+    assert getattr(model, "_side_stream", None) is not None, "the two-stream path did not run"
+    moved = 0
+    for n, p in model.named_parameters():
+        if n in before:
+            assert torch.equal(p.detach(), before[n]), n
+            moved += int(p.data_ptr() != before[n].data_ptr())
+    assert moved > 0 and all(torch.isfinite(v).all() for k, v in out.items() if "loss" in k)

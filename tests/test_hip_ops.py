@@ -633,3 +633,74 @@ def test_transposed_weight_copies_refreshed_in_one_launch():
             assert hit[1].data_ptr() == p0
             assert torch.equal(hit[1], w.detach().to(BF).t().contiguous())
             assert torch.equal(ops_mod.bf16_weight(w), w.detach().to(BF))
+
+
+@pytest.mark.parametrize("B,S,L,hid,kvdim", [(3, 40, 144, 768, 1024), (2, 12, 36, 64, 128)])
+def test_packed_projections_and_packed_mha(ops, B, S, L, hid, kvdim):
+    """ops.linear_packed + ops.mha_qkv_packed / mha_kv_packed (q | k | v of RobertaSelfAttention and key | value of t2i as ONE GEMM,
+    the attention backward writing one packed gradient) against three separate nn.Linear + softmax attention in fp32: outputs,
+    input gradients and every member's weight / bias gradient; the members' Parameters keep their identity (biases are re-pointed
+    at slices of one buffer, values unchanged) and a parameter update through the members is seen by the next call."""
+    heads = hid // 64 if hid >= 64 * 2 else 1
+    D = hid // heads
+    torch.manual_seed(0)
+    lin = {n: torch.nn.Linear(hid if n in "qkv" else kvdim, hid) for n in ("q", "k", "v", "ck", "cv")}
+    for m in lin.values():
+        m.to(DEV)
+        m.weight.data.mul_(2.0)
+        m.bias.data.normal_(0, 0.1)
+    b0 = {n: m.bias.detach().clone() for n, m in lin.items()}
+    x = bf(rnd(B, S, hid)).requires_grad_(True)
+    img = bf(rnd(B, L, kvdim, seed=1)).requires_grad_(True)
+    mask = torch.zeros(B, S)
+    mask[1:, S - 3:] = -10000.0
+    scale = D ** -0.5
+
+    def ours():
+        qkv = ops.linear_packed(x, [(lin["q"].weight, lin["q"].bias), (lin["k"].weight, lin["k"].bias), (lin["v"].weight, lin["v"].bias)])
+        o1 = ops.mha_qkv_packed(qkv.view(B * S, 3 * hid), mask.to(DEV), B, heads, scale)
+        q2 = ops.linear(o1.view(B, S, hid), lin["q"].weight, lin["q"].bias).view(B * S, hid)
+        kv = ops.linear_packed(img, [(lin["ck"].weight, lin["ck"].bias), (lin["cv"].weight, lin["cv"].bias)])
+        return ops.mha_kv_packed(q2, kv.view(B * L, 2 * hid), None, B, heads, scale).view(B, S, hid)
+
+    def ref(xr, ir, P):
+        def attn(q, k, v, m):
+            q = q.view(B, -1, heads, D).transpose(1, 2); k = k.view(B, -1, heads, D).transpose(1, 2); v = v.view(B, -1, heads, D).transpose(1, 2)
+            a = q @ k.transpose(-1, -2) * scale
+            if m is not None:
+                a = a + m[:, None, None, :]
+            return (a.softmax(-1) @ v).transpose(1, 2).reshape(B, -1, hid)
+        f = lambda n, t: F.linear(t, P[n + ".w"], P[n + ".b"])
+        o1 = attn(f("q", xr), f("k", xr), f("v", xr), mask.to(DEV)).to(BF).float()
+        return attn(f("q", o1), f("ck", ir), f("cv", ir), None)
+
+    out = ours()
+    for n, m in lin.items():
+        assert torch.equal(m.bias.detach(), b0[n]), "re-pointing the biases must not change their values"
+    g = bf(rnd(B, S, hid, seed=5))
+    out.backward(g)
+    P = {}
+    for n, m in lin.items():
+        P[n + ".w"] = m.weight.detach().to(BF).float().requires_grad_(True)
+        P[n + ".b"] = m.bias.detach().clone().requires_grad_(True)
+    xr, ir = x.detach().float().requires_grad_(True), img.detach().float().requires_grad_(True)
+    outr = ref(xr, ir, P)
+    outr.backward(g.float())
+    assert_close("out", out, outr, 1.2e-2)
+    assert_close("dx", x.grad, xr.grad, 3e-2)
+    assert_close("dimg", img.grad, ir.grad, 3e-2)
+    for n, m in lin.items():
+        assert_close(f"dW {n}", m.weight.grad, P[n + ".w"].grad, 3e-2)
+        if n in ("k", "ck"):                               # key biases: mathematically zero gradients (softmax shift invariance)
+            assert float(m.bias.grad.abs().max()) < 2e-2 * float(lin["v"].bias.grad.abs().max() + 1e-6) + 1e-3
+        else:
+            assert_close(f"db {n}", m.bias.grad, P[n + ".b"].grad, 3e-2)
+    # an update through the member Parameters (what any optimizer does) must reach the packed copies
+    with torch.no_grad():
+        lin["k"].weight.add_(0.05)
+        lin["v"].bias.add_(0.5)
+    out2 = ours()
+    P["k.w"] = lin["k"].weight.detach().to(BF).float()
+    P["v.b"] = lin["v"].bias.detach().clone()
+    assert_close("out after update", out2, ref(x.detach().float(), img.detach().float(), {k: v.detach() for k, v in P.items()}), 1.2e-2)
+    assert rel_l2(out2, out) > 1e-3
