@@ -1130,8 +1130,11 @@ constexpr bool kV4Ok = (EPI == 0 && (!R || RS)) || (EPI == 1 && !R) || EPI == 2 
 }  // namespace
 
 #ifdef FIBER_P2_PROBE   // compile-time probe: ONE instantiation (register / scratch check while editing a K loop)
+#ifndef FIBER_P2_PROBE_EPI
+#define FIBER_P2_PROBE_EPI 0
+#endif
 extern "C" void fiber_p2_probe(GemmArgs a, hipStream_t st) {
-  hipLaunchKernelGGL((gemm_nt_q8_kernel<0, false, false>), dim3(256), dim3(512), 0, st, a);
+  hipLaunchKernelGGL((gemm_nt_q8_kernel<FIBER_P2_PROBE_EPI, false, false>), dim3(256), dim3(512), 0, st, a);
 }
 #else
 // C ABI ---------------------------------------------------------------------------------------------------------

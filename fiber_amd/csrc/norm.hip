@@ -32,9 +32,12 @@ __device__ __forceinline__ float group_sum(float v) {
 
 // LPR lanes cooperate on one row (64/LPR rows per wave, so narrow rows such as C=128 still use all 64 lanes);
 // NV 16-byte vectors per lane (NV > 1 only when LPR == 64).
+// U: row groups a wave has IN FLIGHT per iteration.  All U loads are issued before the first reduction: with one row per wave
+// and iteration (1 KB outstanding, then a 12-shuffle dependent chain, then the store) the kernels sat at 2.4 TB/s -- the guide's
+// streaming regime needs >= 32 KB of loads in flight per CU ALL the time, not only while every wave happens to be loading.
 // X32: x is the fp32 residual stream (ops.py "stream pair": fp32 payload + bf16 shadow) instead of a bf16 tensor;  y32 (optional):
 // the output is ALSO stored in fp32 -- RoBERTa is post-LN, its LayerNorm output is the next residual (roberta.py:485,422).
-template <int LPR, int NV, bool MERGE, bool X32>
+template <int LPR, int NV, bool MERGE, bool X32, int U>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ xv, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16* __restrict__ y,
                                                      float* __restrict__ y32, float* __restrict__ mean,
@@ -52,53 +55,84 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ xv
 #pragma unroll
     for (int e = 0; e < 8; ++e) { g[i][e] = vi < nvec ? gamma[vi * 8 + e] : 0.f; b[i][e] = vi < nvec ? beta[vi * 8 + e] : 0.f; }
   }
-  for (int row0 = (blockIdx.x * 4 + wave) * RPW; row0 < rows; row0 += gridDim.x * 4 * RPW) {
-    const int row = row0 + sub;
-    const bool rok = row < rows;
-    float v[NV][8];
-    float s = 0.f;
+  for (int base = (blockIdx.x * 4 + wave) * (U * RPW); base < rows; base += gridDim.x * 4 * (U * RPW)) {
+    float v[U][NV][8];
+    bf16x8 raw[U][NV];
+    // ---- every load of the U row groups first
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int vi = gl + i * LPR;
-      if (rok && vi < nvec) {
-        const size_t off = MERGE ? mm.src(row, vi * 8) : (size_t)row * C + vi * 8;
-        if constexpr (X32) {
-          const float4 t0 = *reinterpret_cast<const float4*>(xf + off), t1 = *reinterpret_cast<const float4*>(xf + off + 4);
-          v[i][0] = t0.x; v[i][1] = t0.y; v[i][2] = t0.z; v[i][3] = t0.w; v[i][4] = t1.x; v[i][5] = t1.y; v[i][6] = t1.z; v[i][7] = t1.w;
+    for (int u = 0; u < U; ++u) {
+      const int row = base + u * RPW + sub;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) s += v[i][e];
+      for (int i = 0; i < NV; ++i) {
+        const int vi = gl + i * LPR;
+        if (row < rows && vi < nvec) {
+          const size_t off = MERGE ? mm.src(row, vi * 8) : (size_t)row * C + vi * 8;
+          if constexpr (X32) {
+            const float4 t0 = *reinterpret_cast<const float4*>(xf + off), t1 = *reinterpret_cast<const float4*>(xf + off + 4);
+            v[u][i][0] = t0.x; v[u][i][1] = t0.y; v[u][i][2] = t0.z; v[u][i][3] = t0.w;
+            v[u][i][4] = t1.x; v[u][i][5] = t1.y; v[u][i][6] = t1.z; v[u][i][7] = t1.w;
+          } else {
+            raw[u][i] = *reinterpret_cast<const bf16x8*>(x + off);
+          }
         } else {
-          const bf16x8 t = *reinterpret_cast<const bf16x8*>(x + off);
+          if constexpr (X32) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { v[i][e] = bf2f(t[e]); s += v[i][e]; }
+            for (int e = 0; e < 8; ++e) v[u][i][e] = 0.f;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) raw[u][i][e] = (bf16)0.f;
+          }
         }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
       }
     }
-    const float mu = group_sum<LPR>(s) / C;
-    float q = 0.f;
+    // ---- statistics of all U groups (independent shuffle chains interleave)
+    float mu[U], rs[U];
 #pragma unroll
-    for (int i = 0; i < NV; ++i)
-      if (gl + i * LPR < nvec)
+    for (int u = 0; u < U; ++u) {
+      float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mu; q += d * d; }
-    const float rs = rsqrtf(group_sum<LPR>(q) / C + eps);
-    if (rok && gl == 0) { mean[row] = mu; rstd[row] = rs; }
+      for (int i = 0; i < NV; ++i)
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int vi = gl + i * LPR;
-      if (rok && vi < nvec) {
-        bf16x8 o;
-        float of[8];
+        for (int e = 0; e < 8; ++e) {
+          if constexpr (!X32) v[u][i][e] = bf2f(raw[u][i][e]);
+          s += v[u][i][e];
+        }
+      mu[u] = s;
+    }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { of[e] = (v[i][e] - mu) * rs * g[i][e] + b[i][e]; o[e] = f2bf(of[e]); }
-        *reinterpret_cast<bf16x8*>(y + (size_t)row * C + vi * 8) = o;
-        if (y32) {
-          float* yp = y32 + (size_t)row * C + vi * 8;
-          *reinterpret_cast<float4*>(yp) = float4{of[0], of[1], of[2], of[3]};
-          *reinterpret_cast<float4*>(yp + 4) = float4{of[4], of[5], of[6], of[7]};
+    for (int u = 0; u < U; ++u) mu[u] = group_sum<LPR>(mu[u]) / C;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (gl + i * LPR < nvec)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float d = v[u][i][e] - mu[u]; q += d * d; }
+      rs[u] = q;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) rs[u] = rsqrtf(group_sum<LPR>(rs[u]) / C + eps);
+    // ---- normalise + store
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int row = base + u * RPW + sub;
+      const bool rok = row < rows;
+      if (rok && gl == 0) { mean[row] = mu[u]; rstd[row] = rs[u]; }
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int vi = gl + i * LPR;
+        if (rok && vi < nvec) {
+          bf16x8 o;
+          float of[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { of[e] = (v[u][i][e] - mu[u]) * rs[u] * g[i][e] + b[i][e]; o[e] = f2bf(of[e]); }
+          *reinterpret_cast<bf16x8*>(y + (size_t)row * C + vi * 8) = o;
+          if (y32) {
+            float* yp = y32 + (size_t)row * C + vi * 8;
+            *reinterpret_cast<float4*>(yp) = float4{of[0], of[1], of[2], of[3]};
+            *reinterpret_cast<float4*>(yp + 4) = float4{of[4], of[5], of[6], of[7]};
+          }
         }
       }
     }
@@ -106,7 +140,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ xv
 }
 
 // dx = rstd * (dy*g - mean_c(dy*g) - xhat * mean_c(dy*g*xhat)); one fp32 partial row of dgamma/dbeta per wave.
-template <int LPR, int NV, bool MERGE, bool X32>
+template <int LPR, int NV, bool MERGE, bool X32, int U>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const void* __restrict__ xv,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const bf16* __restrict__ dres,
@@ -130,59 +164,80 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ag[i][e] = 0.f; ab[i][e] = 0.f; g[i][e] = vi < nvec ? gamma[vi * 8 + e] : 0.f; }
   }
-  for (int row0 = (blockIdx.x * 4 + wave) * RPW; row0 < rows; row0 += gridDim.x * 4 * RPW) {
-    const int row = row0 + sub;
-    const bool rok = row < rows;
-    const float mu = rok ? mean[row] : 0.f, rs = rok ? rstd[row] : 0.f;
-    float xh[NV][8], dg[NV][8];
-    float s1 = 0.f, s2 = 0.f;
+  for (int base = (blockIdx.x * 4 + wave) * (U * RPW); base < rows; base += gridDim.x * 4 * (U * RPW)) {
+    float xh[U][NV][8], dg[U][NV][8];
+    bf16x8 rx[U][NV], rd[U][NV], rr[U][NV];
+    float mu[U], rs[U];
+    // ---- every load of the U row groups first (x, dy, the residual-path gradient, the saved statistics)
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int vi = gl + i * LPR;
-      if (rok && vi < nvec) {
-        const size_t off = MERGE ? mm.src(row, vi * 8) : (size_t)row * C + vi * 8;
-        float xv8[8];
-        if constexpr (X32) {
-          const float4 t0 = *reinterpret_cast<const float4*>(xf + off), t1 = *reinterpret_cast<const float4*>(xf + off + 4);
-          xv8[0] = t0.x; xv8[1] = t0.y; xv8[2] = t0.z; xv8[3] = t0.w; xv8[4] = t1.x; xv8[5] = t1.y; xv8[6] = t1.z; xv8[7] = t1.w;
+    for (int u = 0; u < U; ++u) {
+      const int row = base + u * RPW + sub;
+      const bool rok = row < rows;
+      mu[u] = rok ? mean[row] : 0.f;
+      rs[u] = rok ? rstd[row] : 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int vi = gl + i * LPR;
+        if (rok && vi < nvec) {
+          const size_t off = MERGE ? mm.src(row, vi * 8) : (size_t)row * C + vi * 8;
+          if constexpr (X32) {
+            const float4 t0 = *reinterpret_cast<const float4*>(xf + off), t1 = *reinterpret_cast<const float4*>(xf + off + 4);
+            xh[u][i][0] = t0.x; xh[u][i][1] = t0.y; xh[u][i][2] = t0.z; xh[u][i][3] = t0.w;
+            xh[u][i][4] = t1.x; xh[u][i][5] = t1.y; xh[u][i][6] = t1.z; xh[u][i][7] = t1.w;
+          } else {
+            rx[u][i] = *reinterpret_cast<const bf16x8*>(x + off);
+          }
+          rd[u][i] = *reinterpret_cast<const bf16x8*>(dy + (size_t)row * C + vi * 8);
+          if (dres) rr[u][i] = *reinterpret_cast<const bf16x8*>(dres + off);
         } else {
-          const bf16x8 tx = *reinterpret_cast<const bf16x8*>(x + off);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) xv8[e] = bf2f(tx[e]);
+          for (int e = 0; e < 8; ++e) {
+            rd[u][i][e] = (bf16)0.f;
+            if constexpr (X32) xh[u][i][e] = mu[u]; else rx[u][i][e] = (bf16)0.f;     // mu = 0 here: xhat = 0
+          }
         }
-        const bf16x8 td = *reinterpret_cast<const bf16x8*>(dy + (size_t)row * C + vi * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float d = bf2f(td[e]);
-          xh[i][e] = (xv8[e] - mu) * rs;
-          dg[i][e] = d * g[i][e];
-          s1 += dg[i][e];
-          s2 += dg[i][e] * xh[i][e];
-          ag[i][e] += d * xh[i][e];
-          ab[i][e] += d;
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { xh[i][e] = 0.f; dg[i][e] = 0.f; }
       }
     }
-    s1 = group_sum<LPR>(s1) / C;
-    s2 = group_sum<LPR>(s2) / C;
+    // ---- per-row sums of all U groups, then the (independent) shuffle chains
+    float s1[U], s2[U];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int vi = gl + i * LPR;
-      if (rok && vi < nvec) {
-        const size_t off = MERGE ? mm.src(row, vi * 8) : (size_t)row * C + vi * 8;
-        bf16x8 o;
-        if (dres) {                                      // fused residual-path gradient: dx = LN'(dy) + dres
-          const bf16x8 rr = *reinterpret_cast<const bf16x8*>(dres + off);
+    for (int u = 0; u < U; ++u) {
+      s1[u] = 0.f; s2[u] = 0.f;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = f2bf(rs * (dg[i][e] - s1 - xh[i][e] * s2) + bf2f(rr[e]));
-        } else {
+      for (int i = 0; i < NV; ++i)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = f2bf(rs * (dg[i][e] - s1 - xh[i][e] * s2));
+        for (int e = 0; e < 8; ++e) {
+          const float d = bf2f(rd[u][i][e]);
+          const float xv1 = X32 ? xh[u][i][e] : bf2f(rx[u][i][e]);
+          xh[u][i][e] = (xv1 - mu[u]) * rs[u];
+          dg[u][i][e] = d * g[i][e];
+          s1[u] += dg[u][i][e];
+          s2[u] += dg[u][i][e] * xh[u][i][e];
+          ag[i][e] += d * xh[u][i][e];
+          ab[i][e] += d;
         }
-        *reinterpret_cast<bf16x8*>(dx + off) = o;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) { s1[u] = group_sum<LPR>(s1[u]) / C; s2[u] = group_sum<LPR>(s2[u]) / C; }
+    // ---- dx
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int row = base + u * RPW + sub;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int vi = gl + i * LPR;
+        if (row < rows && vi < nvec) {
+          const size_t off = MERGE ? mm.src(row, vi * 8) : (size_t)row * C + vi * 8;
+          bf16x8 o;
+          if (dres) {                                      // fused residual-path gradient: dx = LN'(dy) + dres
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(rs[u] * (dg[u][i][e] - s1[u] - xh[u][i][e] * s2[u]) + bf2f(rr[u][i][e]));
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(rs[u] * (dg[u][i][e] - s1[u] - xh[u][i][e] * s2[u]));
+          }
+          *reinterpret_cast<bf16x8*>(dx + off) = o;
+        }
       }
     }
   }
@@ -228,28 +283,40 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
   }
 }
 
-#define LN_DISPATCH(KERNEL, ...)                                                             \
+// row groups in flight per wave, forward / backward (A/B builds: -DLN_UF=1 -DLN_UB=1 is the one-row-at-a-time form)
+#ifndef LN_UF
+#define LN_UF 4
+#endif
+#ifndef LN_UB
+#define LN_UB 2
+#endif
+#define LN_DISPATCH(KERNEL, LN_U, ...)                                                             \
   do {                                                                                      \
     const int nvec = C >> 3;                                                                \
-    if (nvec <= 8) KERNEL(8, 1, __VA_ARGS__);                                               \
-    else if (nvec <= 16) KERNEL(16, 1, __VA_ARGS__);                                        \
-    else if (nvec <= 32) KERNEL(32, 1, __VA_ARGS__);                                        \
-    else if (nvec <= 64) KERNEL(64, 1, __VA_ARGS__);                                        \
-    else if (nvec <= 128) KERNEL(64, 2, __VA_ARGS__);                                       \
-    else if (nvec <= 256) KERNEL(64, 4, __VA_ARGS__);                                       \
-    else if (nvec <= 512) KERNEL(64, 8, __VA_ARGS__);                                       \
+    if (nvec <= 8) KERNEL(8, 1, LN_U, __VA_ARGS__);                                         \
+    else if (nvec <= 16) KERNEL(16, 1, LN_U, __VA_ARGS__);                                  \
+    else if (nvec <= 32) KERNEL(32, 1, LN_U, __VA_ARGS__);                                  \
+    else if (nvec <= 64) KERNEL(64, 1, LN_U, __VA_ARGS__);                                  \
+    else if (nvec <= 128) KERNEL(64, 2, (LN_U > 1 ? 2 : 1), __VA_ARGS__);                   \
+    else if (nvec <= 256) KERNEL(64, 4, 1, __VA_ARGS__);                                    \
+    else if (nvec <= 512) KERNEL(64, 8, 1, __VA_ARGS__);                                    \
     else return FIBER_EINVAL;                                                               \
   } while (0)
 
-inline int rows_per_wave(int C) { const int nvec = C >> 3; return nvec <= 8 ? 8 : nvec <= 16 ? 4 : nvec <= 32 ? 2 : 1; }
+// rows one wave takes per iteration (row groups in flight x rows per group)
+inline int rows_per_wave(int C) {
+  const int nvec = C >> 3;
+  const int u = nvec <= 64 ? LN_UF : nvec <= 128 ? (LN_UF > 1 ? 2 : 1) : 1;
+  return u * (nvec <= 8 ? 8 : nvec <= 16 ? 4 : nvec <= 32 ? 2 : 1);
+}
 
 template <bool MERGE, bool X32>
 int launch_fwd(const void* x, const float* g, const float* b, bf16* y, float* y32, float* mean, float* rstd, int rows, int C,
                float eps, MergeMap mm, hipStream_t st) {
   const int need = cdiv(rows, 4 * rows_per_wave(C));
   const int grid = need < 4096 ? need : 4096;
-#define FWD(LPR, NV, ...) hipLaunchKernelGGL((ln_fwd_kernel<LPR, NV, MERGE, X32>), dim3(grid), dim3(256), 0, st, __VA_ARGS__)
-  LN_DISPATCH(FWD, x, g, b, y, y32, mean, rstd, rows, C, eps, mm);
+#define FWD(LPR, NV, UU, ...) hipLaunchKernelGGL((ln_fwd_kernel<LPR, NV, MERGE, X32, UU>), dim3(grid), dim3(256), 0, st, __VA_ARGS__)
+  LN_DISPATCH(FWD, LN_UF, x, g, b, y, y32, mean, rstd, rows, C, eps, mm);
 #undef FWD
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
@@ -258,8 +325,8 @@ int launch_fwd(const void* x, const float* g, const float* b, bf16* y, float* y3
 template <bool MERGE, bool X32>
 int launch_bwd(const bf16* dy, const void* x, const float* g, const float* mean, const float* rstd, const bf16* dres,
                bf16* dx, float* dgamma, float* dbeta, float* ws, int grid, int rows, int C, MergeMap mm, hipStream_t st) {
-#define BWD(LPR, NV, ...) hipLaunchKernelGGL((ln_bwd_kernel<LPR, NV, MERGE, X32>), dim3(grid), dim3(256), 0, st, __VA_ARGS__)
-  LN_DISPATCH(BWD, dy, x, g, mean, rstd, dres, dx, ws, rows, C, mm, dgamma, dbeta);
+#define BWD(LPR, NV, UU, ...) hipLaunchKernelGGL((ln_bwd_kernel<LPR, NV, MERGE, X32, UU>), dim3(grid), dim3(256), 0, st, __VA_ARGS__)
+  LN_DISPATCH(BWD, LN_UB, dy, x, g, mean, rstd, dres, dx, ws, rows, C, mm, dgamma, dbeta);
 #undef BWD
   FIBER_CHECK_LAUNCH();
   const int nrows = grid * 4, ysplit = nrows >= 64 ? 32 : 1;

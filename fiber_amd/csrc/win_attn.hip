@@ -816,6 +816,247 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dkv_kernel(WinP
   }
 }
 
+// ================================================================ backward, ONE pass (12x12 windows) ============
+// The two-pass backward evaluates the softmax backward twice (S, P, dP, dS once per pass: the kernels are VALU-issue bound, so
+// that is the cost) and reads q, k, v, dO twice.  Here each (window, head) is visited once:
+//   phase 1 (wave = key strip, the dK/dV pass's formulation: S[query][key] with the query on registers, the key on lanes):
+//           dK, dV of the strip complete in registers; dS is ALSO what dbias accumulates (registers, over the windows of the run)
+//           and is written -- transposed, bf16 -- into an LDS image DSt[key][query] (one ds_write_b64 per query tile);
+//   phase 2 (wave = query strip, after one barrier): dQ^T = K^T . dS^T, ten MFMAs per window whose B operand is read back from
+//           DSt with ds_read_b64_tr_b16 (the same fragment trr_frag() builds for K^T: both operands see the same key order).
+// delta = rowsum(dO . O) is formed while staging (the four lanes that stage a row hold its four chunks of dO and O).
+// LDS: tables 4.7 KB + Q, dO, K images (160 rows: tile 9 stays zero) 46 KB + DSt 144 x 352 B = 50.7 KB + column-sum slots 55 KB.
+// Row stride of DSt: 88 dwords = 24 mod 64, the stride class the transposed read is conflict-free for (see RS above).
+constexpr int DSS = 176;
+__device__ __forceinline__ bf16x8 trr_frag_lohi(const bf16* lo_img, int lo_stride, const bf16* hi_img, int hi_stride, int g, int l) {
+  const bf16* a = lo_img + (g * 4 + (l >> 2)) * lo_stride + (l & 3) * 4;
+  const bf16* b = hi_img + (g * 4 + (l >> 2)) * hi_stride + (l & 3) * 4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi[e]; }
+  return __builtin_bit_cast(bf16x8, o);
+}
+
+// SHIFT: compile-time copy for shifted blocks -- every window then runs the masked body (interior windows carry one label: the
+// mask term is 0), so the kernel has ONE window body (two copies behind a branch cost 4-6 registers more than the cap allows).
+template <bool SHIFT>
+__global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
+  constexpr int MT = 9, MAXN = 160, NTH = 576;           // 12x12 windows: 9 strips of 16, images padded to 10 tiles
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nb = (2 * p.ws - 1) * (2 * p.ws - 1);
+  Smem S = carve<10>(smem, nb, 0);
+  bf16* Qs = S.a0; bf16* dOs = Qs + MAXN * RS; bf16* Ks = dOs + MAXN * RS; bf16* DSt = Ks + MAXN * RS;
+  // dbias accumulators of query tiles 0 .. NL-1: private LDS slots [tile][thread] (read + add + write per window, conflict-free);
+  // tiles NL .. 8 stay in registers.  All nine in registers put the kernel 17-36 registers over its 168-register cap (scratch
+  // traffic: shifted stage-2 backward 1820 us against 1330 without spills).
+  constexpr int NL = 5;
+  f32x4* db_lds = reinterpret_cast<f32x4*>(DSt + 144 * DSS);
+  // column sums of dQ | dK | dV (the qkv bias gradient): reduced over the 16 key / query lanes in registers (the kernel is not
+  // VALU-bound), then one f32x4 per (wave, lane group, piece) in LDS: [wave][gq][6]
+  f32x4* cs_small = db_lds + NL * NTH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int gq = lane >> 4, lq = lane & 15;
+  const int h = blockIdx.y, C = p.C, ld = 3 * C;
+  const int qo = p.hmajor ? h * 96 : h * 32, ko = p.hmajor ? h * 96 + 32 : C + h * 32, vo = p.hmajor ? h * 96 + 64 : 2 * C + h * 32;
+  setup<10>(p, S, h, nb, 0, 1.4426950408889634f, -INFINITY);
+  {                                                      // zero the three images once: rows 144..159 (tile 9) are never staged
+    uint32_t* z = reinterpret_cast<uint32_t*>(Qs);
+    for (int t = tid; t < 3 * MAXN * RS / 2; t += NTH) z[t] = 0u;
+  }
+  for (int t = tid; t < NL * NTH + 9 * 4 * 6; t += NTH) db_lds[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // staging chunk of this thread: row sr of the window, 16-byte piece sc (576 threads = 144 rows x 4 pieces exactly)
+  const int sr = tid >> 2, sc = tid & 3;
+  const int spr = sr / p.ws, spc = sr - spr * p.ws;
+  const int j = wave * 16 + lq;                          // this lane's key (phase 1) = this lane's query (phase 2)
+  const int kpr = j / p.ws, kpc = j - kpr * p.ws;
+  const int kconst = (p.ws - 1) * (2 * p.ws - 1) + p.ws - 1 - (kpr * (2 * p.ws - 1) + kpc);
+  const float scale = 0.17677669529663687f;
+  const int g0 = blockIdx.x * p.gpb, g1 = min(p.G, g0 + p.gpb);
+  if (g0 >= g1) return;
+  __syncthreads();
+  // Bias of (query tile qt, rows gq*4 .. +3) for this lane's key: the four queries lie in one window row (12 = 3 x 4), so their
+  // table entries are CONSECUTIVE: btab[koff[qt*16 + gq*4] + kconst + 0..3] -- five ds_read_b32 per tile instead of
+  // 36 registers held for the whole run (this kernel also carries the dbias accumulators; the register cap is 168 at 9 waves).
+  f32x4 dbacc[MT - NL];
+#pragma unroll
+  for (int qt = 0; qt < MT - NL; ++qt) dbacc[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4* db_mine = db_lds + tid;
+  // sum over the 16 lanes of a lane group (a DPP row) as four v_add_f32 with DPP operands: quad butterflies, then the mirrored
+  // half row and the mirrored row (ds_bpermute shuffles here cost the kernel 15 %: 96 LDS-crossbar operations per window and wave)
+  auto lane16_sum = [&](f32x4 v) -> f32x4 {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float x = v[e];
+      x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+      x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+      x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, true));   // row_half_mirror
+      x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, true));   // row_mirror
+      v[e] = x;
+    }
+    return v;
+  };
+  f32x4* cs_mine = cs_small + (wave * 4 + gq) * 6;
+  auto bias_tile = [&](int qt) -> f32x4 {                 // (the tile's base offset is re-read as well: nine more registers do not exist)
+    const float* b = S.btab + S.koff[qt * 16 + gq * 4] + kconst;
+    return f32x4{b[0], b[1], b[2], b[3]};
+  };
+  Geo geo;
+  geo.set(p, g0);
+  bf16x8 qr, dr, kr, orr, vn;
+  float lser = 0.f;
+  unsigned kpix = geo.pix(p, kpr, kpc);
+  size_t kimg = geo.img(p);
+  auto prefetch = [&]() {
+    const bf16* base = p.qkv + kimg * ld;
+    const unsigned st = geo.pix(p, spr, spc);
+    qr = *reinterpret_cast<const bf16x8*>(at(base, st * ld + qo + sc * 8));
+    kr = *reinterpret_cast<const bf16x8*>(at(base, st * ld + ko + sc * 8));
+    dr = *reinterpret_cast<const bf16x8*>(at(p.dout + kimg * C, st * C + h * 32 + sc * 8));
+    orr = *reinterpret_cast<const bf16x8*>(at(static_cast<const bf16*>(p.o) + kimg * C, st * C + h * 32 + sc * 8));
+    if (sc == 0) lser = *at(p.lse + kimg * p.heads, st * p.heads + h);
+    vn = *reinterpret_cast<const bf16x8*>(at(base, kpix * ld + vo + gq * 8));
+  };
+  prefetch();
+  for (int g = g0; g < g1; ++g) {
+    __syncthreads();                                     // phase 2 of the previous window is done with the images and DSt
+    *reinterpret_cast<bf16x8*>(Qs + sr * RS + sc * 8) = qr;
+    *reinterpret_cast<bf16x8*>(dOs + sr * RS + sc * 8) = dr;
+    *reinterpret_cast<bf16x8*>(Ks + sr * RS + sc * 8) = kr;
+    {
+      typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+      float dpart = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; e += 2)
+        dpart = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, bf16x2{dr[e], dr[e + 1]}), __builtin_bit_cast(bf16x2_t, bf16x2{orr[e], orr[e + 1]}), dpart, false);
+      dpart += __shfl_xor(dpart, 1);
+      dpart += __shfl_xor(dpart, 2);
+      // seeds of the S and dP accumulators: (q.k - lse/scale) * scale*log2e + bias = log2 p, and dP - delta come out of the MFMAs
+      if (sc == 0) { S.lse[sr] = lser * -5.656854249492381f; S.dlt[sr] = -dpart; }
+    }
+    float* kregf = reinterpret_cast<float*>(S.kreg);     // shift-region labels as floats
+    float kregf_own = 0.f;
+    if constexpr (SHIFT) {
+      if (tid < p.N) kregf[tid] = (float)geo.reg(p, tid / p.ws, tid % p.ws);
+      kregf_own = (float)geo.reg(p, kpr, kpc);
+    }
+    const bf16x8 vf = vn;
+    const unsigned opix = kpix;
+    const size_t oimg = kimg;
+    __syncthreads();
+    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + j * RS + gq * 8);   // this lane's key row out of the staged image
+    if (g + 1 < g1) {
+      geo.next(p);
+      kpix = geo.pix(p, kpr, kpc);
+      kimg = geo.img(p);
+      prefetch();
+    }
+    // ---- phase 1: this wave's key strip against every query tile
+    f32x4 dkacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 dvacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    bf16* dsrow = DSt + j * DSS + gq * 4;                // DSt[key j][query tile * 16 + gq * 4 .. + 3]
+    // One query tile per step; the dK / dV MFMAs are the K = 16 form (the operand is the tile's own 16 queries), so a step holds one
+    // tile's temporaries instead of a pair's -- this kernel also carries 36 dbias accumulators under a 168-register cap.
+    {
+      constexpr bool BORDER = SHIFT;
+#pragma unroll
+      for (int qi = 0; qi < MT; ++qi) {
+        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + (qi * 16 + lq) * RS + gq * 8);
+        const bf16x8 df = *reinterpret_cast<const bf16x8*>(dOs + (qi * 16 + lq) * RS + gq * 8);
+        f32x4 sa = *reinterpret_cast<const f32x4*>(S.lse + qi * 16 + gq * 4);
+        f32x4 sdp = *reinterpret_cast<const f32x4*>(S.dlt + qi * 16 + gq * 4);
+        f32x4 qg;
+        if constexpr (BORDER) qg = *reinterpret_cast<const f32x4*>(kregf + qi * 16 + gq * 4);
+        const f32x4 bq = bias_tile(qi);
+        s16x4 qt[2], dt_[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {                   // Q^T / dO^T of this tile: [d = dt*16 + lq][queries gq*4 .. +3]
+          const int off = (qi * 16 + gq * 4 + (lq >> 2)) * RS + dt * 16 + (lq & 3) * 4;
+          qt[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Qs + off));
+          dt_[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(dOs + off));
+        }
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, sa, 0, 0, 0);        // S[query][key] - lse/scale
+        sdp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf, sdp, 0, 0, 0);      // dP[query][key] - delta
+        f32x4 sv = fma4(sa, scale * 1.4426950408889634f, bq);
+        if constexpr (BORDER) sv = region_mask(sv, qg, kregf_own, -144.26950408889634f);
+        const f32x4 pr = exp2x4(sv);
+        const f32x4 ds = pr * sdp;
+        if (qi < NL) db_mine[qi * NTH] += ds; else dbacc[qi - NL] += ds;
+        bf16x4 dsb, pb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { dsb[r] = f2bf(ds[r]); pb[r] = f2bf(pr[r]); }
+        *reinterpret_cast<bf16x4*>(dsrow + qi * 16) = dsb;
+        const s16x4 dsv = __builtin_bit_cast(s16x4, dsb), pv = __builtin_bit_cast(s16x4, pb);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qt[dt], dsv, dkacc[dt], 0, 0, 0);
+          dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dt_[dt], pv, dvacc[dt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);                 // no loads of later tiles hoisted over this one (register cap)
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      bf16x4 ok, ov;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ok[r] = f2bf(dkacc[dt][r] * scale); ov[r] = f2bf(dvacc[dt][r]); }
+      *reinterpret_cast<bf16x4*>(at(p.dqkv + oimg * ld, opix * ld + ko + dt * 16 + gq * 4)) = ok;
+      *reinterpret_cast<bf16x4*>(at(p.dqkv + oimg * ld, opix * ld + vo + dt * 16 + gq * 4)) = ov;
+    }
+    if (p.colsum_part) {
+      const f32x4 s0 = lane16_sum(dkacc[0] * scale), s1 = lane16_sum(dkacc[1] * scale), s2 = lane16_sum(dvacc[0]), s3 = lane16_sum(dvacc[1]);
+      if (lq == 0) { cs_mine[2] += s0; cs_mine[3] += s1; cs_mine[4] += s2; cs_mine[5] += s3; }
+    }
+    __syncthreads();                                     // DSt complete
+    // ---- phase 2: dQ^T[d][query] of this wave's query strip = sum over keys K^T[d][key] dS^T[key][query]
+    f32x4 dqacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int t2 = 0; t2 < 5; ++t2) {
+      // key tiles 2 t2 and 2 t2 + 1; tile 9 does not exist in DSt: its half of the fragment is read from the zero rows of the K image
+      const bf16* lo = DSt + (2 * t2 * 16) * DSS + wave * 16;
+      const bf16x8 dsb = t2 < 4 ? trr_frag_lohi(lo, DSS, lo + 16 * DSS, DSS, gq, lq)
+                                : trr_frag_lohi(lo, DSS, Ks + 144 * RS, RS, gq, lq);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const bf16x8 kt_ = trr_frag(Ks, dt * 16, 2 * t2, gq, lq);
+        dqacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_, dsb, dqacc[dt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      bf16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = f2bf(dqacc[dt][r] * scale);
+      *reinterpret_cast<bf16x4*>(at(p.dqkv + oimg * ld, opix * ld + qo + dt * 16 + gq * 4)) = o;
+    }
+    if (p.colsum_part) {
+      const f32x4 s0 = lane16_sum(dqacc[0] * scale), s1 = lane16_sum(dqacc[1] * scale);
+      if (lq == 0) { cs_mine[0] += s0; cs_mine[1] += s1; }
+    }
+  }
+  {                                                      // dbias_part[z, h, i, j]: this lane holds column j, rows qt*16 + gq*4 + r
+    float* dst = p.dbias_part + ((size_t)blockIdx.x * p.heads + h) * p.N * p.N + j;
+#pragma unroll
+    for (int qt = 0; qt < MT; ++qt) {
+      const f32x4 v = qt < NL ? db_mine[qt * NTH] : dbacc[qt < NL ? 0 : qt - NL];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(size_t)(qt * 16 + gq * 4 + r) * p.N] = v[r];
+    }
+  }
+  if (p.colsum_part) {                                   // channel c of group grp (q | k | v): piece grp*2 + (c >> 4), lane group (c >> 2) & 3, element c & 3
+    __syncthreads();
+    if (tid < 96) {
+      const int grp = tid >> 5, c = tid & 31;
+      float sum = 0.f;
+      for (int w = 0; w < 9; ++w) sum += cs_small[(w * 4 + ((c >> 2) & 3)) * 6 + grp * 2 + (c >> 4)][c & 3];
+      const int chan0 = grp == 0 ? qo : grp == 1 ? ko : vo;
+      p.colsum_part[(size_t)blockIdx.x * 3 * C + chan0 + c] = sum;
+    }
+  }
+}
+
 // dtable[rel_index(i,j), h] += sum_z part[z, h, i, j]
 __global__ __launch_bounds__(256) void win_dbias_scatter_kernel(const float* __restrict__ part, float* __restrict__ dtable,
                                                                 int nz, int H, int ws) {
@@ -842,6 +1083,8 @@ void ensure_attrs() {
   hipFuncSetAttribute((const void*)win_fwd_kernel<3, 0, 21, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   hipFuncSetAttribute((const void*)win_bwd_dq_kernel<3, 0, 21, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   hipFuncSetAttribute((const void*)win_bwd_dkv_kernel<3, 0, 21, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)win_bwd_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)win_bwd_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   attrs_set = true;
 }
 
@@ -938,6 +1181,18 @@ int fiber_win_bwd_launch(const void* qkv, const float* bias_table, const void* o
   const size_t nth = big_window(p.N) ? 448 : 640;        // launch bounds = slot stride of the column-sum slots
   const size_t csq = colsum_ws ? nth * 2 * 16 : 0, cskv = colsum_ws ? nth * 4 * 16 : 0;
   if ((colsum_ws == nullptr) != (dqkv_colsum == nullptr)) return FIBER_EINVAL;
+  static const int fused = getenv("FIBER_WIN_FUSED") ? atoi(getenv("FIBER_WIN_FUSED")) : 1;   // 0: the two-pass backward (A/B runs)
+  if (fused && p.N == 144 && sg == 1) {                  // 12x12 windows: one pass (delta_ws stays unused)
+    const size_t bytes = (size_t)(4 * 160 + ((nb + 3) & ~3)) * 4 + (size_t)3 * 160 * RS * 2 + (size_t)144 * DSS * 2 + (size_t)(5 * 576 + 9 * 4 * 6) * 16;
+    if (shift > 0) hipLaunchKernelGGL(win_bwd_fused_kernel<true>, dim3(gz, heads, 1), dim3(576), bytes, st, p);
+    else hipLaunchKernelGGL(win_bwd_fused_kernel<false>, dim3(gz, heads, 1), dim3(576), bytes, st, p);
+    FIBER_CHECK_LAUNCH();
+    if (hipMemsetAsync(dbias_table, 0, (size_t)nb * heads * sizeof(float), st) != hipSuccess) return FIBER_ELAUNCH;
+    hipLaunchKernelGGL(win_dbias_scatter_kernel, dim3(p.N, heads), dim3(256), 0, st, dbias_ws, dbias_table, gz, heads, ws);
+    FIBER_CHECK_LAUNCH();
+    if (colsum_ws) return fiber_fold_rows_f32(colsum_ws, dqkv_colsum, gz, 3 * C, st);
+    return FIBER_OK;
+  }
   if (big_window(p.N)) hipLaunchKernelGGL((win_bwd_dq_kernel<3, 0, 21, false>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2) + csq, st, p);
   else if (p.N == 144 && (ntc_mask() & 2)) hipLaunchKernelGGL((win_bwd_dq_kernel<1, 9>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2) + slab + csq, st, p);
   else hipLaunchKernelGGL((win_bwd_dq_kernel<1, 0>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2) + slab + csq, st, p);

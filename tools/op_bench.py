@@ -72,11 +72,12 @@ def main():
             qkv = torch.randn(B, L, 3 * C, device=dev).to(BF).requires_grad_(True)
             tab = (torch.randn(529, heads, device=dev) * 0.5).requires_grad_(True)
             do = torch.randn(B, L, C, device=dev).to(BF)
+            hm = os.environ.get("OPB_HEAD_MAJOR", "1") == "1"       # the layout the model uses (ops.linear_qkv_head_major)
             for shift in (0, 6 if H > 12 else 0):
-                o = ops.window_attention(qkv, tab, B, H, H, heads, 12, shift)
-                t_f = timeit(lambda: ops.window_attention(qkv, tab, B, H, H, heads, 12, shift))
+                o = ops.window_attention(qkv, tab, B, H, H, heads, 12, shift, head_major=hm)
+                t_f = timeit(lambda: ops.window_attention(qkv, tab, B, H, H, heads, 12, shift, head_major=hm))
                 def bw():
-                    o = ops.window_attention(qkv, tab, B, H, H, heads, 12, shift)
+                    o = ops.window_attention(qkv, tab, B, H, H, heads, 12, shift, head_major=hm)
                     o.backward(do)
                 t_fb = timeit(bw, reps=10)
                 fl = 4.0 * B * L * 144 * C
