@@ -283,21 +283,23 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
   }
 }
 
-// row groups in flight per wave, forward / backward (A/B builds: -DLN_UF=1 -DLN_UB=1 is the one-row-at-a-time form)
+// row groups in flight per wave, forward / backward (A/B builds: -DLN_UF=1 -DLN_UB=1 is the one-row-at-a-time form).  tools/ln_bench.py,
+// 256 images: C = 128 forward 264 -> 230 us (4.6 -> 5.3 TB/s), backward + dres 495 -> 466; C = 512 forward 68.7 -> 62.9; rows of two
+// vectors per lane (C = 768 / 1024): forward two groups (30.6 -> 18.2 us at 10240 x 768), backward one (two measured 12 % slower)
 #ifndef LN_UF
 #define LN_UF 4
 #endif
 #ifndef LN_UB
-#define LN_UB 2
+#define LN_UB 4
 #endif
-#define LN_DISPATCH(KERNEL, LN_U, ...)                                                             \
+#define LN_DISPATCH(KERNEL, LN_U, LN_U2, ...)                                                             \
   do {                                                                                      \
     const int nvec = C >> 3;                                                                \
     if (nvec <= 8) KERNEL(8, 1, LN_U, __VA_ARGS__);                                         \
     else if (nvec <= 16) KERNEL(16, 1, LN_U, __VA_ARGS__);                                  \
     else if (nvec <= 32) KERNEL(32, 1, LN_U, __VA_ARGS__);                                  \
     else if (nvec <= 64) KERNEL(64, 1, LN_U, __VA_ARGS__);                                  \
-    else if (nvec <= 128) KERNEL(64, 2, (LN_U > 1 ? 2 : 1), __VA_ARGS__);                   \
+    else if (nvec <= 128) KERNEL(64, 2, LN_U2, __VA_ARGS__);                                \
     else if (nvec <= 256) KERNEL(64, 4, 1, __VA_ARGS__);                                    \
     else if (nvec <= 512) KERNEL(64, 8, 1, __VA_ARGS__);                                    \
     else return FIBER_EINVAL;                                                               \
@@ -316,7 +318,7 @@ int launch_fwd(const void* x, const float* g, const float* b, bf16* y, float* y3
   const int need = cdiv(rows, 4 * rows_per_wave(C));
   const int grid = need < 4096 ? need : 4096;
 #define FWD(LPR, NV, UU, ...) hipLaunchKernelGGL((ln_fwd_kernel<LPR, NV, MERGE, X32, UU>), dim3(grid), dim3(256), 0, st, __VA_ARGS__)
-  LN_DISPATCH(FWD, LN_UF, x, g, b, y, y32, mean, rstd, rows, C, eps, mm);
+  LN_DISPATCH(FWD, LN_UF, (LN_UF > 1 ? 2 : 1), x, g, b, y, y32, mean, rstd, rows, C, eps, mm);
 #undef FWD
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
@@ -326,7 +328,7 @@ template <bool MERGE, bool X32>
 int launch_bwd(const bf16* dy, const void* x, const float* g, const float* mean, const float* rstd, const bf16* dres,
                bf16* dx, float* dgamma, float* dbeta, float* ws, int grid, int rows, int C, MergeMap mm, hipStream_t st) {
 #define BWD(LPR, NV, UU, ...) hipLaunchKernelGGL((ln_bwd_kernel<LPR, NV, MERGE, X32, UU>), dim3(grid), dim3(256), 0, st, __VA_ARGS__)
-  LN_DISPATCH(BWD, LN_UB, dy, x, g, mean, rstd, dres, dx, ws, rows, C, mm, dgamma, dbeta);
+  LN_DISPATCH(BWD, LN_UB, 1, dy, x, g, mean, rstd, dres, dx, ws, rows, C, mm, dgamma, dbeta);
 #undef BWD
   FIBER_CHECK_LAUNCH();
   const int nrows = grid * 4, ysplit = nrows >= 64 ? 32 : 1;
