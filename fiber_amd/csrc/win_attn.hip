@@ -961,8 +961,9 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
     // tile's temporaries instead of a pair's -- this kernel also carries 36 dbias accumulators under a 168-register cap.
     {
       constexpr bool BORDER = SHIFT;
-#pragma unroll
-      for (int qi = 0; qi < MT; ++qi) {
+      bf16x4 ds_prev, p_prev;
+      auto tile = [&](auto qi_t) {
+        constexpr int qi = decltype(qi_t)::value;
         const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + (qi * 16 + lq) * RS + gq * 8);
         const bf16x8 df = *reinterpret_cast<const bf16x8*>(dOs + (qi * 16 + lq) * RS + gq * 8);
         f32x4 sa = *reinterpret_cast<const f32x4*>(S.lse + qi * 16 + gq * 4);
@@ -970,12 +971,21 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
         f32x4 qg;
         if constexpr (BORDER) qg = *reinterpret_cast<const f32x4*>(kregf + qi * 16 + gq * 4);
         const f32x4 bq = bias_tile(qi);
+        // dK / dV: query tiles are consumed in PAIRS by K = 32 MFMAs (the K = 16 form has half the rate per pass: 1.7 k of SIMD 0's
+        // 10 k cycles per window); the odd tile of a pair brings both tiles' transposed operands, the last tile (8) runs alone
+        constexpr bool PAIR_END = (qi & 1) == 1, ALONE = qi == MT - 1;
+        bf16x8 qt2[2], dt2[2];
         s16x4 qt[2], dt_[2];
+        if constexpr (PAIR_END) {
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {                   // Q^T / dO^T of this tile: [d = dt*16 + lq][queries gq*4 .. +3]
-          const int off = (qi * 16 + gq * 4 + (lq >> 2)) * RS + dt * 16 + (lq & 3) * 4;
-          qt[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Qs + off));
-          dt_[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(dOs + off));
+          for (int dt = 0; dt < 2; ++dt) { qt2[dt] = trr_frag(Qs, dt * 16, qi - 1, gq, lq); dt2[dt] = trr_frag(dOs, dt * 16, qi - 1, gq, lq); }
+        } else if constexpr (ALONE) {
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {                 // Q^T / dO^T of this tile: [d = dt*16 + lq][queries gq*4 .. +3]
+            const int off = (qi * 16 + gq * 4 + (lq >> 2)) * RS + dt * 16 + (lq & 3) * 4;
+            qt[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Qs + off));
+            dt_[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(dOs + off));
+          }
         }
         sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, sa, 0, 0, 0);        // S[query][key] - lse/scale
         sdp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf, sdp, 0, 0, 0);      // dP[query][key] - delta
@@ -988,14 +998,30 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { dsb[r] = f2bf(ds[r]); pb[r] = f2bf(pr[r]); }
         *reinterpret_cast<bf16x4*>(dsrow + qi * 16) = dsb;
-        const s16x4 dsv = __builtin_bit_cast(s16x4, dsb), pv = __builtin_bit_cast(s16x4, pb);
+        if constexpr (PAIR_END) {
+          bf16x8 dsf, pf;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qt[dt], dsv, dkacc[dt], 0, 0, 0);
-          dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dt_[dt], pv, dvacc[dt], 0, 0, 0);
+          for (int r = 0; r < 4; ++r) { dsf[r] = ds_prev[r]; dsf[4 + r] = dsb[r]; pf[r] = p_prev[r]; pf[4 + r] = pb[r]; }
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt2[dt], dsf, dkacc[dt], 0, 0, 0);
+            dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dt2[dt], pf, dvacc[dt], 0, 0, 0);
+          }
+        } else if constexpr (ALONE) {
+          const s16x4 dsv = __builtin_bit_cast(s16x4, dsb), pv = __builtin_bit_cast(s16x4, pb);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qt[dt], dsv, dkacc[dt], 0, 0, 0);
+            dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dt_[dt], pv, dvacc[dt], 0, 0, 0);
+          }
+        } else {
+          ds_prev = dsb; p_prev = pb;
         }
         __builtin_amdgcn_sched_barrier(0);                 // no loads of later tiles hoisted over this one (register cap)
-      }
+      };
+      tile(std::integral_constant<int, 0>{}); tile(std::integral_constant<int, 1>{}); tile(std::integral_constant<int, 2>{});
+      tile(std::integral_constant<int, 3>{}); tile(std::integral_constant<int, 4>{}); tile(std::integral_constant<int, 5>{});
+      tile(std::integral_constant<int, 6>{}); tile(std::integral_constant<int, 7>{}); tile(std::integral_constant<int, 8>{});
     }
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
