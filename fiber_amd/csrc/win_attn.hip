@@ -920,8 +920,22 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
     vn = *reinterpret_cast<const bf16x8*>(at(base, kpix * ld + vo + gq * 8));
   };
   prefetch();
+  // TRACE build (-DFIBER_WIN_TRACE, tools/win_trace.py): s_memtime ticks per segment and wave, summed over the windows of the run, written
+  // into the delta workspace (unused by this kernel)
+#ifdef FIBER_WIN_TRACE
+  unsigned long long tr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#define WIN_MARK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tr[i] += t_ - t0; t0 = t_; } while (0)
+#else
+#define WIN_MARK(i) do { } while (0)
+#endif
   for (int g = g0; g < g1; ++g) {
     __syncthreads();                                     // phase 2 of the previous window is done with the images and DSt
+    WIN_MARK(0);
+#ifdef FIBER_WIN_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    WIN_MARK(1);
     *reinterpret_cast<bf16x8*>(Qs + sr * RS + sc * 8) = qr;
     *reinterpret_cast<bf16x8*>(dOs + sr * RS + sc * 8) = dr;
     *reinterpret_cast<bf16x8*>(Ks + sr * RS + sc * 8) = kr;
@@ -945,7 +959,9 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
     const bf16x8 vf = vn;
     const unsigned opix = kpix;
     const size_t oimg = kimg;
+    WIN_MARK(2);
     __syncthreads();
+    WIN_MARK(3);
     const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + j * RS + gq * 8);   // this lane's key row out of the staged image
     if (g + 1 < g1) {
       geo.next(p);
@@ -953,6 +969,7 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
       kimg = geo.img(p);
       prefetch();
     }
+    WIN_MARK(7);
     // ---- phase 1: this wave's key strip against every query tile
     f32x4 dkacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     f32x4 dvacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -1023,6 +1040,7 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
       tile(std::integral_constant<int, 3>{}); tile(std::integral_constant<int, 4>{}); tile(std::integral_constant<int, 5>{});
       tile(std::integral_constant<int, 6>{}); tile(std::integral_constant<int, 7>{}); tile(std::integral_constant<int, 8>{});
     }
+    WIN_MARK(8);
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
       bf16x4 ok, ov;
@@ -1035,7 +1053,9 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
       const f32x4 s0 = lane16_sum(dkacc[0] * scale), s1 = lane16_sum(dkacc[1] * scale), s2 = lane16_sum(dvacc[0]), s3 = lane16_sum(dvacc[1]);
       if (lq == 0) { cs_mine[2] += s0; cs_mine[3] += s1; cs_mine[4] += s2; cs_mine[5] += s3; }
     }
+    WIN_MARK(4);
     __syncthreads();                                     // DSt complete
+    WIN_MARK(5);
     // ---- phase 2: dQ^T[d][query] of this wave's query strip = sum over keys K^T[d][key] dS^T[key][query]
     f32x4 dqacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -1061,7 +1081,16 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
       const f32x4 s0 = lane16_sum(dqacc[0] * scale), s1 = lane16_sum(dqacc[1] * scale);
       if (lq == 0) { cs_mine[0] += s0; cs_mine[1] += s1; }
     }
+    WIN_MARK(6);
   }
+#ifdef FIBER_WIN_TRACE
+  if (lane == 0 && blockIdx.x < 4 && h == 0) {
+    float* o = p.delta + (blockIdx.x * 9 + wave) * 12;
+    for (int i = 0; i < 12; ++i) o[i] = (float)tr[i];
+    if (wave == 0) p.delta[1000 + blockIdx.x] = (float)(g1 - g0);
+  }
+#endif
+#undef WIN_MARK
   {                                                      // dbias_part[z, h, i, j]: this lane holds column j, rows qt*16 + gq*4 + r
     float* dst = p.dbias_part + ((size_t)blockIdx.x * p.heads + h) * p.N * p.N + j;
 #pragma unroll

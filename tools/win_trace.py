@@ -1,5 +1,9 @@
-"""Per-segment cycle trace of the one-pass window-attention backward (TRACE build of csrc/win_attn.hip in tools/bin; the kernel
-writes its s_memtime sums into the otherwise unused delta workspace).   FIBER_HIP_LIB=tools/bin/libfiber_hip_wtrace.so python tools/win_trace.py"""
+"""Per-segment cycle trace of the one-pass window-attention backward (the kernel writes its s_memtime sums into the otherwise unused
+delta workspace).  Build the TRACE library next to the product one and point the loader at it:
+    cd fiber_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DFIBER_WIN_TRACE -c win_attn.hip -o /tmp/win_trace.o && \
+      hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/bin/libfiber_hip_wtrace.so gemm.o gemm_tn.o input.o dcn.o norm.o attn.o \
+      /tmp/win_trace.o elementwise.o embed.o optim.o loss.o
+    FIBER_HIP_LIB=tools/bin/libfiber_hip_wtrace.so python tools/win_trace.py [shift]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
