@@ -963,12 +963,17 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
     __syncthreads();
     WIN_MARK(3);
     const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + j * RS + gq * 8);   // this lane's key row out of the staged image
-    if (g + 1 < g1) {
+    // The next window's loads are requested from INSIDE phase 1, a third of the waves at tile 0, 3 and 6: all nine waves requesting
+    // right behind the barrier stalled each other for 0.5-2 k ticks on the address path (tools/win_trace.py) with nobody computing;
+    // the data is needed a whole phase later either way (it used to land ~9 k ticks early).
+    const int pf_tile = (wave % 3) * 3;
+    const bool pf_more = g + 1 < g1;
+    auto prefetch_next = [&]() {
       geo.next(p);
       kpix = geo.pix(p, kpr, kpc);
       kimg = geo.img(p);
       prefetch();
-    }
+    };
     WIN_MARK(7);
     // ---- phase 1: this wave's key strip against every query tile
     f32x4 dkacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -981,6 +986,7 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
       bf16x4 ds_prev, p_prev;
       auto tile = [&](auto qi_t) {
         constexpr int qi = decltype(qi_t)::value;
+        if constexpr (qi % 3 == 0) { if (pf_more && pf_tile == qi) prefetch_next(); }
         const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + (qi * 16 + lq) * RS + gq * 8);
         const bf16x8 df = *reinterpret_cast<const bf16x8*>(dOs + (qi * 16 + lq) * RS + gq * 8);
         f32x4 sa = *reinterpret_cast<const f32x4*>(S.lse + qi * 16 + gq * 4);
