@@ -36,6 +36,10 @@ constexpr int RS = 48;
 // per-tile register arrays and the image height, the extra tile being all zeros)
 #define WIN_DIMS(MTT) constexpr int MT = (MTT), MTP = ((MTT) + 1) & ~1, MAXN = MTP * 16; (void)MT; (void)MTP; (void)MAXN
 
+#ifdef FIBER_WIN_TRACE
+__device__ float g_win_trace[256];
+#endif
+
 struct WinP {
   const bf16* qkv; bf16* o; const bf16* dout; bf16* dqkv;
   float* lse; float* delta;   // delta: written by the dQ pass, read by the dK/dV pass
@@ -287,8 +291,20 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
     qn = *reinterpret_cast<const bf16x8*>(at(base, qpix * ld + qo + gq * 8));
   };
   prefetch();
+#ifdef FIBER_WIN_TRACE      // tools/win_trace.py fwd: s_memtime ticks per segment and wave into g_win_trace
+  unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#define FWD_MARK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tr[i] += t_ - t0; t0 = t_; } while (0)
+#else
+#define FWD_MARK(i) do { } while (0)
+#endif
   for (int g = g0; g < g1; ++g) {
     __syncthreads();                                  // previous window's LDS reads done (also covers setup)
+    FWD_MARK(0);
+#ifdef FIBER_WIN_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    FWD_MARK(1);
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
       if (sval[c]) {
@@ -304,13 +320,16 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
     const bf16x8 qf = qn;
     const unsigned opix = qpix;
     const size_t oimg = qimg;
+    FWD_MARK(2);
     __syncthreads();
+    FWD_MARK(3);
     if (g + 1 < g1) {                                  // prefetch next window while this one computes
       geo.next(p);
       qpix = geo.pix(p, qpr, qpc);
       qimg = geo.img(p);
       prefetch();
     }
+    FWD_MARK(4);
     // Only windows on the wrapped border pay for the region mask (one wave-uniform branch, swin_transformer.py:327-350);
     // padded key tiles carry bias = -inf so exp2 gives exact zeros without per-element selects.
     f32x4 s[MTP];
@@ -390,6 +409,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
         }
       }
     }
+    FWD_MARK(5);
     if (qval) {
       const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
@@ -401,7 +421,16 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
       }
       if (gq == 0) *at(p.lse + oimg * p.heads, opix * p.heads + h) = mx * scale + __logf(sum);
     }
+    FWD_MARK(6);
   }
+#ifdef FIBER_WIN_TRACE
+  if (lane == 0 && blockIdx.x < 2 && h == 0 && blockIdx.z == 0) {
+    float* o = g_win_trace + (blockIdx.x * 10 + wave) * 8;
+    for (int i = 0; i < 8; ++i) o[i] = (float)tr[i];
+    if (wave == 0) g_win_trace[200 + blockIdx.x] = (float)(g1 - g0);
+  }
+#endif
+#undef FWD_MARK
 }
 
 // ================================================================ backward pass A: dQ + dbias =================
@@ -1195,6 +1224,11 @@ WinP make(const void* qkv, int B, int Hres, int Wres, int C, int heads, int ws, 
   return p;
 }
 
+#ifdef FIBER_WIN_TRACE
+}  // namespace
+extern "C" int fiber_win_trace_read(float* host256) { return (int)hipMemcpyFromSymbol(host256, HIP_SYMBOL(g_win_trace), 256 * sizeof(float)); }
+namespace {
+#endif
 }  // namespace
 
 // Used by attn.hip's C entry points when the window fits the specialised path (head_dim 32, N <= 160).

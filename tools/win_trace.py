@@ -3,7 +3,8 @@ delta workspace).  Build the TRACE library next to the product one and point the
     cd fiber_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DFIBER_WIN_TRACE -c win_attn.hip -o /tmp/win_trace.o && \
       hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/bin/libfiber_hip_wtrace.so gemm.o gemm_tn.o input.o dcn.o norm.o attn.o \
       /tmp/win_trace.o elementwise.o embed.o optim.o loss.o
-    FIBER_HIP_LIB=tools/bin/libfiber_hip_wtrace.so python tools/win_trace.py [shift]"""
+    FIBER_HIP_LIB=tools/bin/libfiber_hip_wtrace.so python tools/win_trace.py [shift]
+The forward kernel of the same build keeps its sums in a device symbol (read through fiber_win_trace_read)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -39,3 +40,18 @@ for blk in range(2):
     for i in range(9):
         print(f"  {names[i]:52s}", " ".join(f"{float(d[(blk * 9 + w) * 12 + i]) / nwin:8.0f}" for w in (0, 4, 8)))
     print("  total", " ".join(f"{sum(float(d[(blk * 9 + w) * 12 + i]) for i in range(9)) / nwin:8.0f}" for w in (0, 4, 8)))
+
+# forward kernel: the TRACE build keeps its sums in a device symbol
+import ctypes as C
+L = C.CDLL(lib.LIB_PATH)
+if hasattr(L, "fiber_win_trace_read"):
+    buf = (C.c_float * 256)()
+    L.fiber_win_trace_read(buf)
+    fn = ["top barrier", "prefetch landed (vmcnt 0)", "staging", "barrier 2", "next prefetch issued", "QK^T, softmax, PV", "store o / lse"]
+    for blk in range(2):
+        nwin = buf[200 + blk]
+        if nwin:
+            print(f"forward workgroup {blk}: {nwin:.0f} windows; ticks per window and segment, waves 0 / 4 / 8")
+            for i in range(7):
+                print(f"  {fn[i]:30s}", " ".join(f"{buf[(blk * 10 + w) * 8 + i] / nwin:8.0f}" for w in (0, 4, 8)))
+            print("  total", " ".join(f"{sum(buf[(blk * 10 + w) * 8 + i] for i in range(7)) / nwin:8.0f}" for w in (0, 4, 8)))
