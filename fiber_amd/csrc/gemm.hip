@@ -947,9 +947,11 @@ __global__ __launch_bounds__(512) void gemm_nt_q8_kernel(GemmArgs a) {
       fb[j][ks] = *reinterpret_cast<const bf16x8*>(sb + BM * BK + swz(wn * WTN + j * 32 + frow, ks * 2 + fk));
   };
   // bias of column block j in accumulator layout (element q*4+e <-> column j*32 + q*8 + 4*(lane>>5) + e): scalar loads, one select each
+  // N need only be a multiple of 64 (a wave's 64 columns are then all inside or all outside): the waves of the last tile column
+  // whose columns lie past N run the K loop on clamped W rows and store nothing (Swin stage 0: qkv, N = 384 = 1.5 tiles)
   auto seed_of = [&](int n0w, int j) {
     f32x16 sd;
-    if (EPI != 2 && a.bias) {
+    if (EPI != 2 && a.bias && n0w < a.N) {
       typedef __attribute__((address_space(4))) const float cfloat;
       cfloat* bp = (cfloat*)(uintptr_t)(a.bias + n0w + j * 32);
 #pragma unroll
@@ -1102,7 +1104,8 @@ __global__ __launch_bounds__(512) void gemm_nt_q8_kernel(GemmArgs a) {
       bar_math();
       mark(15);
     }
-    if (tm0 + BM <= a.M)
+    if (n0w >= a.N) {
+    } else if (tm0 + BM <= a.M)
       wave_epilogue<TM, EPI, HAS_R, HAS_RS, true>(a, acc, cw, tm0 + wm * WTM, tn0 + wn * WTN);
     else
       wave_epilogue<TM, EPI, HAS_R, HAS_RS, false>(a, acc, cw, tm0 + wm * WTM, tn0 + wn * WTN);
@@ -1182,19 +1185,24 @@ extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bia
   // choice for A/B runs (tools/gemm_ab.py).
   static const int force = getenv("FIBER_GEMM_TILE") ? atoi(getenv("FIBER_GEMM_TILE")) : 0;
   static const int nowide = getenv("FIBER_GEMM_NOWIDE") ? atoi(getenv("FIBER_GEMM_NOWIDE")) : 0;
+  static const int persist_env = getenv("FIBER_GEMM_PERSIST") ? atoi(getenv("FIBER_GEMM_PERSIST")) : 1;
+  static const int persist_min = getenv("FIBER_GEMM_PERSIST_MIN") ? atoi(getenv("FIBER_GEMM_PERSIST_MIN")) : 200;
+  static const int q8_env = getenv("FIBER_GEMM_Q8") ? atoi(getenv("FIBER_GEMM_Q8")) : 1;   // 0: the v4 K loop (A/B runs)
+  // will FIBER_LAUNCH_EPI below pick gemm_nt_q8_kernel for this call?  (run-time mirror of kV4Ok and of the colpart exclusion)
+  const bool has_r = residual != nullptr, has_rs = rowscale != nullptr;
+  const bool v4ok = (act & 0x800) ? has_rs : mode == 0 ? (!has_r || has_rs) : mode == 1 ? !has_r : mode == 2;
+  const bool q8_serves = persist_env == 1 && q8_env && wide >= persist_min && v4ok && !(mode == 2 && colpart) && !(act & 0x1600);
   int shape;                                             // 0 wide, 1 256x128, 2 128x128, 3 64x64, 4/5 register-staged
   if (act & 0x100) {                                      // fp32 output: the register-staged kernels only
     if (mode != 0 || residual || colpart) return FIBER_EINVAL;
     shape = big >= 192 ? 4 : 5;
-  } else if (v2 && !nowide && force == 0 && wide >= 200 && N % 256 == 0 && K >= 128) shape = 0;
+  } else if (v2 && !nowide && force == 0 && wide >= 200 && K >= 128 &&
+             (N % 256 == 0 || (N % 64 == 0 && N > 256 && q8_serves))) shape = 0;   // (only the q8 kernel masks a partial tile column)
   else if (v2 && ((huge >= 400 && K >= 256 && force == 0) || force == 256)) shape = 1;
   else if (big >= 192 || force == 128) shape = v2 ? 2 : 4;
   else shape = v2 ? 3 : 5;
   const long small = (long)cdiv(M, 64) * cdiv(N, 64);
-  static const int persist_env = getenv("FIBER_GEMM_PERSIST") ? atoi(getenv("FIBER_GEMM_PERSIST")) : 1;
-  static const int persist_min = getenv("FIBER_GEMM_PERSIST_MIN") ? atoi(getenv("FIBER_GEMM_PERSIST_MIN")) : 200;
   const bool persist = persist_env && wide >= persist_min;   // (q8 wins from one tile per CU on: 240 tiles 31.5 -> 28.1 us, 97.5 -> 85.1 us at K = 3072)
-  static const int q8_env = getenv("FIBER_GEMM_Q8") ? atoi(getenv("FIBER_GEMM_Q8")) : 1;   // 0: the v4 K loop (A/B runs)
 #define FIBER_LAUNCH_EPI(EPI, R, RS)                                                                                          \
   do {                                                                                                                        \
     if (shape == 0 && persist && persist_env == 2) hipLaunchKernelGGL((gemm_nt_wide_persist_kernel<2, 4, EPI, R, RS>), dim3(256), dim3(512), 0, stream, a); \

@@ -59,7 +59,7 @@ def test_gemm_nt(ops, M, N, K, act, res):
 
 
 @pytest.mark.parametrize("M,N,K", [(33000, 2048, 512), (70001, 1024, 256), (40960, 1536, 1024), (52000, 512, 2048),
-                                   (33000, 2056, 512)])
+                                   (33000, 2056, 512), (30000, 384, 128), (26000, 832, 256)])   # last two: N = 1.5 / 3.25 tile columns
 @pytest.mark.parametrize("mode", ["plain", "bias", "gelu_pre", "res_rowscale", "gelu_grad_colsum"])
 def test_gemm_large_tiles(ops, M, N, K, mode):
     """Shapes with >= 200 256x256 tiles and N % 256 == 0 take the wide kernel (4-stage K=32 ring, epilogue in two halves);
