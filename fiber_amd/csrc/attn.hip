@@ -177,7 +177,7 @@ __device__ __forceinline__ void fill_rowmeta(const AttnP& p, const Lds& L, int g
 
 
 // ===================================================== forward =================================================
-template <int D, bool WINDOW>
+template <int D, bool WINDOW, int NT = NKT>       // NT: key (query) tiles held per chunk -- 3 for the 40-token text side
 __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = D / 32, DT = D / 16;
@@ -237,10 +237,10 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnP p) {
       stage<D>(p.v, p.ldv, h * D, L.rowmap, (tpc * 16 + 31) & ~31, valid, Vs);
       __syncthreads();
     }
-    f32x4 s[NKT];
+    f32x4 s[NT];
     float cmax = -INFINITY;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
+    for (int kt = 0; kt < NT; ++kt) {
       s[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
       if (kt < tpc) {
         f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnP p) {
     m = mnew;
     float psum = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
+    for (int kt = 0; kt < NT; ++kt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float e = kt < tpc ? __builtin_amdgcn_exp2f(s[kt][r] - mnew) : 0.f;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
 #pragma unroll
-    for (int t2 = 0; t2 < NKT / 2; ++t2) {
+    for (int t2 = 0; t2 < NT / 2; ++t2) {
       if (t2 * 2 < tpc) {
         const bf16x8 pf = pack8(s[2 * t2], s[2 * t2 + 1]);
 #pragma unroll
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
 }
 
 // ===================================================== backward, pass A: dQ (+ dbias) ==========================
-template <int D, bool WINDOW>
+template <int D, bool WINDOW, int NT = NKT>       // NT: key (query) tiles held per chunk -- 3 for the 40-token text side
 __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = D / 32, DT = D / 16;
@@ -355,9 +355,9 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
   // (N = 324 at 576^2 needs three); dQ is then accumulated across chunk passes by the lane that owns it.
   const int nouter = WINDOW ? nchunk : 1;
   for (int co = 0; co < nouter; ++co) {
-  f32x4 dbacc[NKT];
+  f32x4 dbacc[NT];
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) dbacc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int kt = 0; kt < NT; ++kt) dbacc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int c_lo = WINDOW ? co : 0, c_hi = WINDOW ? co + 1 : nchunk;
   for (int g = g0; g < g1; ++g) {
     // single-chunk key side without window bias (i2t cross-attention, text self-attention): stage once, then walk the query
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
         __syncthreads();
       }
 #pragma unroll
-      for (int t2 = 0; t2 < NKT / 2; ++t2) {
+      for (int t2 = 0; t2 < NT / 2; ++t2) {
         if (t2 * 2 < tpc) {
           f32x4 ds[2];
 #pragma unroll
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
   if (WINDOW && p.dbias_part && qvalid) {
     float* dst = p.dbias_part + (((size_t)blockIdx.z * p.H + h) * p.Lq + i) * p.Lk + co * tpc * 16;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
+    for (int kt = 0; kt < NT; ++kt) {
       if (kt < tpc) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
 }
 
 // ===================================================== backward, pass B: dK, dV ================================
-template <int D, bool WINDOW>
+template <int D, bool WINDOW, int NT = NKT>       // NT: key (query) tiles held per chunk -- 3 for the 40-token text side
 __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = D / 32, DT = D / 16;
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnP p) {
     }
     __syncthreads();
 #pragma unroll
-    for (int t2 = 0; t2 < NKT / 2; ++t2) {
+    for (int t2 = 0; t2 < NT / 2; ++t2) {
       if (t2 * 2 < tpc) {
         f32x4 ds[2], pd[2];
 #pragma unroll
@@ -654,6 +654,14 @@ int strip_blocks(const AttnP& p, int staged_len, int nstrips, int nw, int hg, bo
   return want < 1 ? 1 : (want < full ? want : full);
 }
 
+// chunks of at most 4 tiles (a 40-token text side: 3): the kernels instantiated with 4 tile slots instead of 10 hold 24 fewer score
+// registers per array and fit more waves per SIMD (the strip-walking kernels are bound by the latency of their per-strip loads)
+bool small_chunk(const AttnP& p, int staged_len) {
+  static const int off = getenv("FIBER_ATTN_NOSMALL") ? 1 : 0;
+  const int ntiles = cdiv(staged_len, 16), nchunk = cdiv(ntiles, p.tpc_cap);
+  return !off && cdiv(ntiles, nchunk) <= 4;
+}
+
 template <int D>
 int launch_fwd(AttnP& p, hipStream_t st) {
   const int nstrips = cdiv(p.Lq, 16), nw = pick_waves(nstrips, p.Lk);
@@ -662,6 +670,7 @@ int launch_fwd(AttnP& p, hipStream_t st) {
   const size_t sh = lds_bytes<D>(nb, 2, p.chrows);
   const int gx = strip_blocks(p, p.Lk, nstrips, nw, p.H * p.G, true);
   if (p.window) hipLaunchKernelGGL((attn_fwd_kernel<D, true>), dim3(gx, p.H, p.G), dim3(64 * nw), sh, st, p);
+  else if (small_chunk(p, p.Lk)) hipLaunchKernelGGL((attn_fwd_kernel<D, false, 4>), dim3(gx, p.H, p.G), dim3(64 * nw), sh, st, p);
   else hipLaunchKernelGGL((attn_fwd_kernel<D, false>), dim3(gx, p.H, p.G), dim3(64 * nw), sh, st, p);
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
@@ -693,6 +702,7 @@ int launch_bwd(AttnP& p, float* delta, float* dbias_table, float* dbias_ws, int 
     launch_geometry(p, p.Lk, nw, true);
     const size_t sh = lds_bytes<D>(nb, 2, p.chrows);
     if (p.window) hipLaunchKernelGGL((attn_bwd_dq_kernel<D, true>), dim3(cdiv(nstrips, nw), p.H, gz), dim3(64 * nw), sh, st, p);
+    else if (small_chunk(p, p.Lk)) hipLaunchKernelGGL((attn_bwd_dq_kernel<D, false, 4>), dim3(strip_blocks(p, p.Lk, nstrips, nw, p.H * gz, false), p.H, gz), dim3(64 * nw), sh, st, p);
     else hipLaunchKernelGGL((attn_bwd_dq_kernel<D, false>), dim3(strip_blocks(p, p.Lk, nstrips, nw, p.H * gz, false), p.H, gz), dim3(64 * nw), sh, st, p);
     FIBER_CHECK_LAUNCH();
     if (p.window) {
@@ -706,6 +716,7 @@ int launch_bwd(AttnP& p, float* delta, float* dbias_table, float* dbias_ws, int 
     launch_geometry(p, p.Lq, nw, true);
     const size_t sh = lds_bytes<D>(nb, 2, p.chrows);
     if (p.window) hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, true>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), sh, st, p);
+    else if (small_chunk(p, p.Lq)) hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, false, 4>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), sh, st, p);
     else hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, false>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), sh, st, p);
     FIBER_CHECK_LAUNCH();
   }
