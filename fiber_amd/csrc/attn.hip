@@ -90,20 +90,33 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
 // row-major LDS image.  Rows >= valid are zero filled.  Row stride D+16 elements (96 B / 160 B): 24 or 40 banks per row, which
 // makes both ds_read_b128 (operand straight) and ds_read_b64_tr_b16 (operand transposed) conflict-free (MI355X_MICROARCH.md,
 // LDS table); no transposed copy of an image is ever written.
-template <int D>
+template <int D, int U = 4>
 __device__ __forceinline__ void stage(const bf16* __restrict__ src, int ld, int hcol, const int* rowmap, int nrows,
                                       int valid, bf16* rm) {
   constexpr int CPR = D / 8;
-  for (int idx = threadIdx.x; idx < nrows * CPR; idx += blockDim.x) {
-    const int r = idx / CPR, c = idx - r * CPR;
-    bf16x8 v;
-    if (r < valid) {
-      v = *reinterpret_cast<const bf16x8*>(src + (size_t)rowmap[r] * ld + hcol + c * 8);
-    } else {
+  // Four pieces per thread are REQUESTED before the first is written: the one-piece loop (load, wait, LDS write) exposed one global
+  // latency per piece -- the t2i kernels (128-row chunks staged by 192 threads: 11 pieces per thread and chunk) spent ~16 us per chunk there
+  // and ran at 1.5-2 TB/s of their bytes.
+  const int total = nrows * CPR;
+  for (int base = threadIdx.x; base < total; base += U * blockDim.x) {
+    bf16x8 v[U];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = f2bf(0.f);
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * blockDim.x;
+      const int r = idx / CPR, c = idx - r * CPR;
+      if (idx < total && r < valid) {
+        v[u] = *reinterpret_cast<const bf16x8*>(src + (size_t)rowmap[r] * ld + hcol + c * 8);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[u][e] = f2bf(0.f);
+      }
     }
-    *reinterpret_cast<bf16x8*>(rm + r * (D + 16) + c * 8) = v;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * blockDim.x;
+      const int r = idx / CPR, c = idx - r * CPR;
+      if (idx < total) *reinterpret_cast<bf16x8*>(rm + r * (D + 16) + c * 8) = v[u];
+    }
   }
 }
 
@@ -368,8 +381,8 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
       fill_rowmeta(p, L, g, 0, tpc * 16, p.Lk, true);
       __syncthreads();
       const int valid = min(tpc * 16, p.Lk);
-      stage<D>(p.k, p.ldk, h * D, L.rowmap, (tpc * 16 + 31) & ~31, valid, Ks);
-      stage<D>(p.v, p.ldv, h * D, L.rowmap, tpc * 16, valid, Vs);
+      stage<D, 2>(p.k, p.ldk, h * D, L.rowmap, (tpc * 16 + 31) & ~31, valid, Ks);
+      stage<D, 2>(p.v, p.ldv, h * D, L.rowmap, tpc * 16, valid, Vs);
       __syncthreads();
     }
     for (int strip = blockIdx.x * nw + wave;; strip += gridDim.x * nw) {
@@ -400,8 +413,8 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
         fill_rowmeta(p, L, g, kbase, tpc * 16, p.Lk, true);
         __syncthreads();
         const int valid = min(tpc * 16, p.Lk - kbase);
-        stage<D>(p.k, p.ldk, h * D, L.rowmap, (tpc * 16 + 31) & ~31, valid, Ks);
-        stage<D>(p.v, p.ldv, h * D, L.rowmap, tpc * 16, valid, Vs);
+        stage<D, 2>(p.k, p.ldk, h * D, L.rowmap, (tpc * 16 + 31) & ~31, valid, Ks);
+        stage<D, 2>(p.v, p.ldv, h * D, L.rowmap, tpc * 16, valid, Vs);
         __syncthreads();
       }
 #pragma unroll
@@ -656,6 +669,10 @@ int strip_blocks(const AttnP& p, int staged_len, int nstrips, int nw, int hg, bo
 
 // chunks of at most 4 tiles (a 40-token text side: 3): the kernels instantiated with 4 tile slots instead of 10 hold 24 fewer score
 // registers per array and fit more waves per SIMD (the strip-walking kernels are bound by the latency of their per-strip loads)
+int chunk_tiles(const AttnP& p, int staged_len) {
+  const int ntiles = cdiv(staged_len, 16), nchunk = cdiv(ntiles, p.tpc_cap);
+  return cdiv(ntiles, nchunk);
+}
 bool small_chunk(const AttnP& p, int staged_len) {
   static const int off = getenv("FIBER_ATTN_NOSMALL") ? 1 : 0;
   const int ntiles = cdiv(staged_len, 16), nchunk = cdiv(ntiles, p.tpc_cap);
@@ -703,6 +720,7 @@ int launch_bwd(AttnP& p, float* delta, float* dbias_table, float* dbias_ws, int 
     const size_t sh = lds_bytes<D>(nb, 2, p.chrows);
     if (p.window) hipLaunchKernelGGL((attn_bwd_dq_kernel<D, true>), dim3(cdiv(nstrips, nw), p.H, gz), dim3(64 * nw), sh, st, p);
     else if (small_chunk(p, p.Lk)) hipLaunchKernelGGL((attn_bwd_dq_kernel<D, false, 4>), dim3(strip_blocks(p, p.Lk, nstrips, nw, p.H * gz, false), p.H, gz), dim3(64 * nw), sh, st, p);
+    else if (chunk_tiles(p, p.Lk) <= 6) hipLaunchKernelGGL((attn_bwd_dq_kernel<D, false, 6>), dim3(strip_blocks(p, p.Lk, nstrips, nw, p.H * gz, false), p.H, gz), dim3(64 * nw), sh, st, p);   // (t2i: 5-tile chunks; the 10-slot form spills)
     else hipLaunchKernelGGL((attn_bwd_dq_kernel<D, false>), dim3(strip_blocks(p, p.Lk, nstrips, nw, p.H * gz, false), p.H, gz), dim3(64 * nw), sh, st, p);
     FIBER_CHECK_LAUNCH();
     if (p.window) {
