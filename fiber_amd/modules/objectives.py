@@ -28,11 +28,32 @@ def _mlm_ce(logits, labels, head=None):
     return loss
 
 
+def _mlm_head(pl_module, text_feats, labels):
+    """MLM head + loss (objectives.py:17-33: `mlm_score(text_feats)`, cross entropy with ignore_index -100).
+
+    85 % of the rows carry the ignore label: the reference still pushes them through the 50265-way decoder (forward, dX, dW) and
+    writes a zero gradient row for each.  With `mlm_compact_rows` (default on) only the rows that carry a label go through the head:
+    same loss (the mean runs over labelled rows either way), same gradients (an ignored row's logit gradient is exactly zero), same
+    accuracy (the metric drops ignored rows).  The row count is data dependent, so the selection costs ONE host sync per step; it is
+    skipped while a hipGraph is being captured (static shapes) and when no row is labelled.  Returns (loss, logits, labels) --
+    the logits / labels of the labelled rows only ([n, V] / [n]) on the compact path, the full tensors otherwise."""
+    cfg = pl_module.hparams.config
+    V = cfg["vocab_size"]
+    flat = labels.reshape(-1)
+    if cfg.get("mlm_compact_rows", True) and text_feats.is_cuda and not torch.cuda.is_current_stream_capturing():
+        keep = (flat != -100).nonzero(as_tuple=True)[0]
+        if keep.numel() > 0:
+            feats = text_feats.reshape(-1, text_feats.shape[-1]).index_select(0, keep)
+            lab = flat.index_select(0, keep)
+            logits = pl_module.mlm_score(feats)
+            return _mlm_ce(logits, lab, pl_module.mlm_score), logits, lab
+    logits = pl_module.mlm_score(text_feats)
+    return _mlm_ce(logits.view(-1, V), flat, pl_module.mlm_score), logits, labels
+
+
 def compute_mlm(pl_module, batch):
     infer = pl_module.infer(batch, mask_text=True, mask_image=False)
-    mlm_logits = pl_module.mlm_score(infer["text_feats"])
-    mlm_labels = infer["text_labels"]
-    mlm_loss = _mlm_ce(mlm_logits.view(-1, pl_module.hparams.config["vocab_size"]), mlm_labels.view(-1), pl_module.mlm_score)
+    mlm_loss, mlm_logits, mlm_labels = _mlm_head(pl_module, infer["text_feats"], infer["text_labels"])
     ret = {"mlm_loss": mlm_loss, "mlm_logits": mlm_logits, "mlm_labels": mlm_labels, "mlm_ids": infer["text_ids"]}
     phase = "train" if pl_module.training else "val"
     loss = getattr(pl_module, f"{phase}_mlm_loss")(ret["mlm_loss"])
@@ -89,9 +110,7 @@ def compute_mlm_itm_fused(pl_module, batch, itm_labels=None):
         "text_masks": torch.cat([batch["text_masks"], batch["text_masks"]], 0),
     }
     infer = pl_module.infer(fused, mask_text=False, mask_image=False)
-    mlm_logits = pl_module.mlm_score(infer["text_feats"][:B])
-    mlm_labels = batch["text_labels_mlm"]
-    mlm_loss = _mlm_ce(mlm_logits.view(-1, pl_module.hparams.config["vocab_size"]), mlm_labels.view(-1), pl_module.mlm_score)
+    mlm_loss, mlm_logits, mlm_labels = _mlm_head(pl_module, infer["text_feats"][:B], batch["text_labels_mlm"])
     itm_logits = pl_module.itm_score(infer["cls_feats"][B:])
     itm_loss = F.cross_entropy(itm_logits, itm_labels.long())
     ret = {"mlm_loss": mlm_loss, "mlm_logits": mlm_logits, "mlm_labels": mlm_labels, "mlm_ids": batch["text_ids_mlm"],
@@ -190,9 +209,7 @@ def compute_mlm_itm_hardneg_fused(pl_module, batch, image_neg, text_neg, text_ma
         "text_masks": torch.cat([batch["text_masks"], batch["text_masks"], text_mask_neg, batch["text_masks"]], 0),
     }
     infer = pl_module.infer(fused, mask_text=False, mask_image=False)
-    mlm_logits = pl_module.mlm_score(infer["text_feats"][:B])
-    mlm_labels = batch["text_labels_mlm"]
-    mlm_loss = _mlm_ce(mlm_logits.view(-1, pl_module.hparams.config["vocab_size"]), mlm_labels.view(-1), pl_module.mlm_score)
+    mlm_loss, mlm_logits, mlm_labels = _mlm_head(pl_module, infer["text_feats"][:B], batch["text_labels_mlm"])
     itm_labels = torch.cat([torch.ones(B), torch.zeros(2 * B)]).to(pl_module.device)
     itm_logits = pl_module.itm_score(infer["cls_feats"][B:])
     itm_loss = F.cross_entropy(itm_logits, itm_labels.long())

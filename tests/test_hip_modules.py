@@ -674,3 +674,33 @@ def test_packed_biases_survive_a_lagging_second_stream():
             assert torch.equal(p.detach(), before[n]), n
             moved += int(p.data_ptr() != before[n].data_ptr())
     assert moved > 0 and all(torch.isfinite(v).all() for k, v in out.items() if "loss" in k)
+
+
+def test_mlm_head_on_labelled_rows_only_equals_full_head():
+    """`mlm_compact_rows`: the MLM head run on the labelled rows only gives the loss and the parameter gradients of the full head
+    (ignored rows have exactly zero logit gradients; the mean runs over labelled rows either way)."""
+    from fiber_amd import lib, ops, parallel
+    from fiber_amd.config import make_config
+    from fiber_amd.modules import FIBERTransformerSS, fiber_utils
+    lib.load()
+    res = {}
+    for compact in (True, False):
+        ops.clear_weight_cache()
+        torch.manual_seed(0)
+        model = FIBERTransformerSS(make_config(**cases.TINY, mlm_compact_rows=compact))
+        detgen.fill_(model)
+        parallel.freeze_unused(model, model.unused_parameter_names())
+        model.to(DEV).eval()
+        fiber_utils.set_task(model)
+        b = detgen.synth_batch(4, 96, 12, 1000, seed=40, min_len=6)
+        bd = {k: (v.to(DEV) if isinstance(v, torch.Tensor) else [t.to(DEV) for t in v] if isinstance(v, list) and isinstance(v[0], torch.Tensor) else v)
+              for k, v in b.items()}
+        bd["itm_labels_override"] = bd["itm_labels"]
+        out = model(bd)
+        n_lab = int((bd["text_labels_mlm"] != -100).sum())
+        assert out["mlm_logits"].shape[0] == (n_lab if compact else 4) and 0 < n_lab < bd["text_labels_mlm"].numel()
+        (out["mlm_loss"] + out["itm_loss"]).backward()
+        res[compact] = (float(out["mlm_loss"]), {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert abs(res[True][0] - res[False][0]) < 2e-3 * abs(res[False][0]), (res[True][0], res[False][0])
+    worst = max((float((res[True][1][n] - g).norm() / max(float(g.norm()), 1e-4)), n) for n, g in res[False][1].items())
+    assert worst[0] < 2e-2, worst          # different GEMM row counts -> different bf16 summation orders in dW, nothing else
