@@ -24,7 +24,9 @@ DEFAULTS = dict(
     # not a reference key: storage type of the residual streams of both backbones -- "bf16" (rounded at every block) or "fp32"
     # (fiber_amd/ops.py "fp32 residual stream"; the reference's fp32 run keeps them in fp32).  None = FIBER_RESIDUAL_DTYPE or bf16.
     residual_dtype=None,
-    mlm_compact_rows=True,       # MLM head only on the rows that carry a label (objectives._mlm_head): same loss and gradients
+    # not a reference key: True = MLM head only on the rows that carry a label (objectives._mlm_head): same loss, gradients and accuracy,
+    # but ret["mlm_logits"] is then [n_labelled, V]; the default keeps the reference's full [B, S, V] head
+    mlm_compact_rows=False,
 )
 
 

@@ -32,7 +32,7 @@ def _mlm_head(pl_module, text_feats, labels):
     """MLM head + loss (objectives.py:17-33: `mlm_score(text_feats)`, cross entropy with ignore_index -100).
 
     85 % of the rows carry the ignore label: the reference still pushes them through the 50265-way decoder (forward, dX, dW) and
-    writes a zero gradient row for each.  With `mlm_compact_rows` (default on) only the rows that carry a label go through the head:
+    writes a zero gradient row for each.  With `mlm_compact_rows` (default OFF: the reference's output shapes) only the rows that carry a label go through the head:
     same loss (the mean runs over labelled rows either way), same gradients (an ignored row's logit gradient is exactly zero), same
     accuracy (the metric drops ignored rows).  The row count is data dependent, so the selection costs ONE host sync per step; it is
     skipped while a hipGraph is being captured (static shapes) and when no row is labelled.  Returns (loss, logits, labels) --
@@ -40,7 +40,7 @@ def _mlm_head(pl_module, text_feats, labels):
     cfg = pl_module.hparams.config
     V = cfg["vocab_size"]
     flat = labels.reshape(-1)
-    if cfg.get("mlm_compact_rows", True) and text_feats.is_cuda and not torch.cuda.is_current_stream_capturing():
+    if cfg.get("mlm_compact_rows", False) and text_feats.is_cuda and not torch.cuda.is_current_stream_capturing():
         keep = (flat != -100).nonzero(as_tuple=True)[0]
         if keep.numel() > 0:
             feats = text_feats.reshape(-1, text_feats.shape[-1]).index_select(0, keep)
