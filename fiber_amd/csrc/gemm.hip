@@ -1171,6 +1171,7 @@ extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bia
   if ((act & 0xff) == 2 && (!aux || (ldaux & 7))) return FIBER_EINVAL;
   GemmArgs a{(const bf16*)X, (const bf16*)W, bias, (const bf16*)residual, (bf16*)Y, (bf16*)Ypre, rowscale,
              (const bf16*)aux, colpart, M, N, K, ldx, ldw, ldy, ldr, act, rows_per_sample, ldaux};
+  if ((size_t)M * N * 2 > ((size_t)256 << 20)) a.act |= 0x2000;   // output larger than the last-level cache: streaming stores (gemm_epilogue.h st_out)
   const long big = (long)cdiv(M, 128) * cdiv(N, 128);
   const long huge = (long)cdiv(M, 256) * cdiv(N, 128);
   const long wide = (long)cdiv(M, 256) * cdiv(N, 256);

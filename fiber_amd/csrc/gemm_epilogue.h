@@ -33,7 +33,12 @@ __device__ __forceinline__ int swz(int row, int chunk) { return (row * 8 + (chun
 // Y is read by the next kernel and is stored normally: marking it non-temporal made the isolated GEMM faster (fc1 845 ->
 // 772 us at M = 295k, less L2 pollution) but the whole step slower (670 -> 658 images/s, the consumer then misses the
 // Infinity Cache).  The pre-activation copy is only read again in the backward pass, so it does stream past the caches.
-__device__ __forceinline__ void st_out(bf16x8* p, bf16x8 v) { *p = v; }
+// Output rows: streaming (non-temporal) stores when the whole output is larger than the 256-MB last-level cache (act bit 0x2000, set by
+// the dispatcher) -- nothing of it survives until its consumer runs, and not allocating it keeps the K loop's operand panels in L2: same-box
+// step 288.7 -> 286.4 ms, fc1 + GELU 879 -> 845 us; outputs that fit (Swin stage 3: 151 MB) measured 2-4 % slower that way and keep plain stores.
+__device__ __forceinline__ void st_out(bf16x8* p, bf16x8 v, bool stream) {
+  if (stream) __builtin_nontemporal_store(v, p); else *p = v;
+}
 __device__ __forceinline__ void st_stream(bf16x8* p, bf16x8 v) { __builtin_nontemporal_store(v, p); }
 
 //   RAWBAR: barriers are s_waitcnt lgkmcnt(0) + s_barrier instead of __syncthreads() -- for the persistent kernel, where a
@@ -147,7 +152,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x16 (&acc)[B
             if (a.Y) {
               v[0] = f2bf(o0.x); v[1] = f2bf(o0.y); v[2] = f2bf(o0.z); v[3] = f2bf(o0.w);
               v[4] = f2bf(o1.x); v[5] = f2bf(o1.y); v[6] = f2bf(o1.z); v[7] = f2bf(o1.w);
-              st_out(reinterpret_cast<bf16x8*>(yp + pp * ystep), v);
+              st_out(reinterpret_cast<bf16x8*>(yp + pp * ystep), v, (a.act & 0x2000) != 0);
             }
             continue;
           }
@@ -155,7 +160,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x16 (&acc)[B
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(side[pp][e]));
           }
-          st_out(reinterpret_cast<bf16x8*>(yp + pp * ystep), v);
+          st_out(reinterpret_cast<bf16x8*>(yp + pp * ystep), v, (a.act & 0x2000) != 0);
           if constexpr (EPI == 2) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) csum[e] += bf2f(v[e]);
@@ -308,14 +313,14 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& a, f32x16 (&acc)[T
           if (a.Y) {
             v[0] = f2bf(o0.x); v[1] = f2bf(o0.y); v[2] = f2bf(o0.z); v[3] = f2bf(o0.w);
             v[4] = f2bf(o1.x); v[5] = f2bf(o1.y); v[6] = f2bf(o1.z); v[7] = f2bf(o1.w);
-            st_out(reinterpret_cast<bf16x8*>(yp + (size_t)pp * 8 * a.ldy), v);
+            st_out(reinterpret_cast<bf16x8*>(yp + (size_t)pp * 8 * a.ldy), v, (a.act & 0x2000) != 0);
           }
         } else {
           if constexpr (HAS_R) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(sd[pp][e]));
           }
-          st_out(reinterpret_cast<bf16x8*>(yp + (size_t)pp * 8 * a.ldy), v);
+          st_out(reinterpret_cast<bf16x8*>(yp + (size_t)pp * 8 * a.ldy), v, (a.act & 0x2000) != 0);
         }
       }
       if constexpr (HAS_R || EPI == 2) __builtin_amdgcn_sched_barrier(0);     // one pass at a time (keeps the residual variants out of scratch)
