@@ -1148,15 +1148,25 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
 }
 
 // dtable[rel_index(i,j), h] += sum_z part[z, h, i, j]
-__global__ __launch_bounds__(256) void win_dbias_scatter_kernel(const float* __restrict__ part, float* __restrict__ dtable,
+__global__ __launch_bounds__(512) void win_dbias_scatter_kernel(const float* __restrict__ part, float* __restrict__ dtable,
                                                                 int nz, int H, int ws) {
   const int i = blockIdx.x, h = blockIdx.y, N = ws * ws, W2 = 2 * ws - 1;
   const int pri = i / ws, pci = i - pri * ws;
-  for (int j = threadIdx.x; j < N; j += 256) {
-    float s = 0.f;
-    for (int z = 0; z < nz; ++z) s += part[(((size_t)z * H + h) * N + i) * N + j];
+  // blockDim = groups * N (N <= 512): group g takes the z slices g, g + groups, ...; four independent partial sums keep four loads in
+  // flight per thread (was: 256 threads, one j each -- 112 idle at N = 144 -- and one dependent chain over z)
+  const int groups = blockDim.x >= (unsigned)N ? blockDim.x / N : 1, grp = blockDim.x >= (unsigned)N ? threadIdx.x / N : 0;
+  if (grp >= groups) return;
+  const size_t zs = (size_t)H * N * N;
+  for (int j = blockDim.x >= (unsigned)N ? threadIdx.x - grp * N : threadIdx.x; j < N; j += blockDim.x >= (unsigned)N ? N : blockDim.x) {
+    const float* src = part + ((size_t)h * N + i) * N + j;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int z = grp;
+    for (; z + 3 * groups < nz; z += 4 * groups) {
+      s0 += src[(size_t)z * zs]; s1 += src[(size_t)(z + groups) * zs]; s2 += src[(size_t)(z + 2 * groups) * zs]; s3 += src[(size_t)(z + 3 * groups) * zs];
+    }
+    for (; z < nz; z += groups) s0 += src[(size_t)z * zs];
     const int prj = j / ws, pcj = j - prj * ws;
-    atomicAdd(dtable + (size_t)((pri - prj + ws - 1) * W2 + (pci - pcj + ws - 1)) * H + h, s);
+    atomicAdd(dtable + (size_t)((pri - prj + ws - 1) * W2 + (pci - pcj + ws - 1)) * H + h, (s0 + s1) + (s2 + s3));
   }
 }
 
@@ -1210,6 +1220,7 @@ int blocks_for(int G, int heads) {
 }
 
 bool big_window(int N) { return N > 160; }
+int scatter_threads(int N) { (void)N; return 256; }   // (z-split groups of N threads measured 2.6 x slower: the kernel is bound by its global atomics, one per (i, j, group))
 
 WinP make(const void* qkv, int B, int Hres, int Wres, int C, int heads, int ws, int shift, int hmajor) {
   WinP p{};
@@ -1283,7 +1294,7 @@ int fiber_win_bwd_launch(const void* qkv, const float* bias_table, const void* o
     else hipLaunchKernelGGL(win_bwd_fused_kernel<false>, dim3(gz, heads, 1), dim3(576), bytes, st, p);
     FIBER_CHECK_LAUNCH();
     if (hipMemsetAsync(dbias_table, 0, (size_t)nb * heads * sizeof(float), st) != hipSuccess) return FIBER_ELAUNCH;
-    hipLaunchKernelGGL(win_dbias_scatter_kernel, dim3(p.N, heads), dim3(256), 0, st, dbias_ws, dbias_table, gz, heads, ws);
+    hipLaunchKernelGGL(win_dbias_scatter_kernel, dim3(p.N, heads), dim3(scatter_threads(p.N)), 0, st, dbias_ws, dbias_table, gz, heads, ws);
     FIBER_CHECK_LAUNCH();
     if (colsum_ws) return fiber_fold_rows_f32(colsum_ws, dqkv_colsum, gz, 3 * C, st);
     return FIBER_OK;
@@ -1293,7 +1304,7 @@ int fiber_win_bwd_launch(const void* qkv, const float* bias_table, const void* o
   else hipLaunchKernelGGL((win_bwd_dq_kernel<1, 0>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2) + slab + csq, st, p);
   FIBER_CHECK_LAUNCH();
   if (hipMemsetAsync(dbias_table, 0, (size_t)nb * heads * sizeof(float), st) != hipSuccess) return FIBER_ELAUNCH;
-  hipLaunchKernelGGL(win_dbias_scatter_kernel, dim3(p.N, heads), dim3(256), 0, st, dbias_ws, dbias_table, gz, heads, ws);
+  hipLaunchKernelGGL(win_dbias_scatter_kernel, dim3(p.N, heads), dim3(scatter_threads(p.N)), 0, st, dbias_ws, dbias_table, gz, heads, ws);
   FIBER_CHECK_LAUNCH();
   if (big_window(p.N)) hipLaunchKernelGGL((win_bwd_dkv_kernel<3, 0, 21, false>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2) + cskv, st, p);
   else if (p.N == 144 && (ntc_mask() & 4)) hipLaunchKernelGGL((win_bwd_dkv_kernel<1, 9>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2) + cskv, st, p);
