@@ -167,6 +167,8 @@ def _window_ref(qkv, table, B, H, W, heads, ws, shift):
     # fine-grained backbone geometries (fusion_swin_transformer_v2.py:293-345): rectangular padded grids, and a SHIFTED
     # single-window grid (there odd blocks shift regardless of the resolution)
     (1, 24, 36, 4, 12, 6), (2, 12, 24, 2, 12, 6), (2, 12, 12, 2, 12, 6), (1, 48, 60, 2, 12, 0),
+    # runs of several windows per workgroup in the persistent kernels (G = 96 windows on 64 slices; 160 on 32: ragged last run)
+    (6, 48, 48, 4, 12, 6), (40, 24, 24, 16, 12, 0), (33, 24, 24, 16, 12, 6),
 ])
 def test_window_attention(ops, B, H, W, heads, ws, shift):
     C = heads * 32
