@@ -231,7 +231,8 @@ def test_window_attention_qkv_bias_grad_handover(ops):
     assert getattr(ops_mod._hint_tls, "slot", None) is None
 
 
-@pytest.mark.parametrize("B,H,W,heads,ws,shift", [(2, 8, 8, 2, 4, 2), (1, 24, 24, 4, 12, 6), (2, 14, 14, 3, 7, 3)])
+@pytest.mark.parametrize("B,H,W,heads,ws,shift", [(2, 8, 8, 2, 4, 2), (1, 24, 24, 4, 12, 6), (2, 14, 14, 3, 7, 3), (6, 48, 48, 4, 12, 6),
+                                                   (33, 24, 24, 16, 12, 0)])
 def test_window_attention_head_major_layout(ops, B, H, W, heads, ws, shift):
     """[heads][3][32] channel layout (permuted qkv projection) gives the same result as the reference [3][heads][32]."""
     C = heads * 32
