@@ -279,22 +279,64 @@ def main():
                     help="full (default) = the reference's MLM head over every text position; labelled = config mlm_compact_rows: the head "
                          "only on the rows that carry a label (same loss and gradients; -2.8 ms per step at B=256; the head's FLOPs are then "
                          "charged by the labelled fraction)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch / rendezvous check only: start the ranks, form the process group (gloo when no GPU is visible), "
+                         "all-reduce one tensor, print {n_gpus, rccl_ranks} and exit -- no model, no timing (tests/test_dp_gloo.py)")
     ap.add_argument("--task", choices=sorted(TASKS), default="mlm_itm",
                     help="default = BASELINE.json's metric; the others are extra configurations of the same path")
     args = ap.parse_args()
     if args.batch <= 0:
         args.batch = {"mlm_itm": 256, "mlm_itm_itc": 96, "vqa": 160}[args.task]
 
+    # `--gpus N` is the contract: one rank per GPU.  Under a launcher (torchrun sets WORLD_SIZE) the two must agree; without one,
+    # N > 1 re-executes this very command line under torch.distributed.run on a free local port (reference: Lightning spawns one
+    # process per GPU itself, coarse_grained/run.py:50-54).
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" in os.environ:
+        if int(os.environ["WORLD_SIZE"]) != args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks; "
+                     f"pass --gpus {os.environ['WORLD_SIZE']} (or launch {args.gpus} ranks)")
+    elif args.gpus > 1:
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print(f"[bench] --gpus {args.gpus} without a launcher: spawning {args.gpus} ranks ({' '.join(cmd[1:8])} ...)", file=sys.stderr, flush=True)
+        sys.exit(subprocess.call(cmd))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run:
+        import torch.distributed as dist
+        from fiber_amd import parallel
+        parallel.init_distributed(os.environ.get("FIBER_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo"))
+        ranks = dist.get_world_size() if dist.is_initialized() else 1
+        assert ranks == args.gpus == world, f"process group has {ranks} ranks, --gpus {args.gpus}, WORLD_SIZE {world}"
+        t = torch.ones(1, device=torch.device("cuda", local % torch.cuda.device_count()) if torch.cuda.is_available() else "cpu")
+        if ranks > 1:
+            dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "rccl_ranks": ranks, "allreduce_of_ones": t.item()}), flush=True)
+        if ranks > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     assert torch.cuda.is_available(), "bench.py needs MI355X devices (there is no CPU fallback for the product path)"
     local %= torch.cuda.device_count()                      # (only matters for the 2-ranks-on-1-GPU gloo wiring test)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
     from fiber_amd import parallel
-    parallel.init_distributed(os.environ.get("FIBER_DIST_BACKEND", "nccl"))   # RCCL; "gloo" only for 1-GPU wiring tests
+    backend = os.environ.get("FIBER_DIST_BACKEND", "nccl")                    # RCCL; "gloo" only for 1-GPU wiring tests
+    parallel.init_distributed(backend)
+    ranks = dist.get_world_size() if dist.is_initialized() else 1
+    assert ranks == args.gpus == world, f"process group has {ranks} ranks, --gpus {args.gpus}, WORLD_SIZE {world}"
 
     from fiber_amd import lib, ops
     from fiber_amd.config import make_config
@@ -416,7 +458,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": task["workload"], "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"dp{world}", "dropout": "reference defaults (text 0.1, DropPath linspace 0..0.1)",
+                       "parallelism": f"dp{world}", "rccl_ranks": ranks,
+                       "dist_backend": (backend + (" (RCCL over xGMI)" if backend == "nccl" else "")) if world > 1 else None,
+                       "dropout": "reference defaults (text 0.1, DropPath linspace 0..0.1)",
                        "residual_dtype": "fp32" if ops.residual_fp32() else "bf16", "mlm_head_rows": head_rows,
                        "launch": "hipGraph replay of the captured step" if use_graph else "eager (one launch per kernel)"},
             "loss": round(lossv, 4),

@@ -1011,7 +1011,13 @@ __global__ __launch_bounds__(512) void gemm_nt_q8_kernel(GemmArgs a) {
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  if (wm == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }   // group 1 runs one barrier behind from here on
+  // Group 1 runs one barrier behind group 0 INSIDE a tile's K loop.  Round 4: the stagger is taken down at the end of every K loop
+  // (one extra barrier for group 0) and put up again at the start of the next (one for group 1), so that both groups enter their
+  // wave-private epilogues together.  With the stagger kept across tiles (round 3; act bit 0x4000 = that form, for A/B runs) group 1
+  // sat at its last P4 barrier for the whole of group 0's epilogue and group 0 at its first P1 barrier for the whole of group 1's:
+  // the two epilogues ran one after the other with one wave per SIMD (trace: 2 x 11.2 k ticks per GELU tile, K loop 27 k).
+  const bool keep_stagger = (a.act & 0x4000) != 0;
+  if (keep_stagger && wm == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
   int g = 0;
   // TRACE build (tools/gemm_trace.py q8): s_memtime ticks per wave summed over its K tiles -- for each of the four phases
   // [4p + 0] load half (reads + DMA issued AND the reads returned: s_memtime drains lgkmcnt)  [4p + 1] wait + first barrier
@@ -1031,6 +1037,7 @@ __global__ __launch_bounds__(512) void gemm_nt_q8_kernel(GemmArgs a) {
     const int id = first + seq * P;
     const int tm0 = (id / tilesN) * BM, tn0 = (id % tilesN) * BN;
     const int n0w = tn0 + wn * WTN;
+    if (!keep_stagger && wm == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
     for (int kt = 0; kt < nk; ++kt, ++g) {
       const bf16* sb = smem + (g & 1) * STAGE;
       // P1: quadrant (0, 0)
@@ -1104,6 +1111,8 @@ __global__ __launch_bounds__(512) void gemm_nt_q8_kernel(GemmArgs a) {
       bar_math();
       mark(15);
     }
+    if (!keep_stagger && wm == 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+    if constexpr (TRACE) t0 = __builtin_amdgcn_s_memtime();
     if (n0w >= a.N) {
     } else if (tm0 + BM <= a.M)
       wave_epilogue<TM, EPI, HAS_R, HAS_RS, true>(a, acc, cw, tm0 + wm * WTM, tn0 + wn * WTN);
@@ -1111,7 +1120,7 @@ __global__ __launch_bounds__(512) void gemm_nt_q8_kernel(GemmArgs a) {
       wave_epilogue<TM, EPI, HAS_R, HAS_RS, false>(a, acc, cw, tm0 + wm * WTM, tn0 + wn * WTN);
     mark(16);
   }
-  if (wm == 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }   // every wave passes the same number of barriers
+  if (keep_stagger && wm == 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }   // every wave passes the same number of barriers
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may outlive the workgroup's LDS allocation
   if constexpr (TRACE) {
     if (lane == 0 && blockIdx.x < 8) {
@@ -1171,6 +1180,8 @@ extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bia
   if ((act & 0xff) == 2 && (!aux || (ldaux & 7))) return FIBER_EINVAL;
   GemmArgs a{(const bf16*)X, (const bf16*)W, bias, (const bf16*)residual, (bf16*)Y, (bf16*)Ypre, rowscale,
              (const bf16*)aux, colpart, M, N, K, ldx, ldw, ldy, ldr, act, rows_per_sample, ldaux};
+  static const int stagger_env = getenv("FIBER_GEMM_STAGGER") ? atoi(getenv("FIBER_GEMM_STAGGER")) : 0;   // 1: round-3 barrier form (A/B runs)
+  if (stagger_env) a.act |= 0x4000;
   if ((size_t)M * N * 2 > ((size_t)256 << 20)) a.act |= 0x2000;   // output larger than the last-level cache: streaming stores (gemm_epilogue.h st_out)
   const long big = (long)cdiv(M, 128) * cdiv(N, 128);
   const long huge = (long)cdiv(M, 256) * cdiv(N, 128);
@@ -1216,7 +1227,7 @@ extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bia
     else hipLaunchKernelGGL((gemm_nt_glds_kernel<64, 64, 2, 2, 2, EPI, R, RS>), dim3((unsigned)small), dim3(256), 0, stream, a);                   \
   } while (0)
   if (shape == 0 && (act & 0x1000)) {                     // tools/gemm_trace.py q8: per-phase timing of the v5 kernel
-    a.act &= 0xff;
+    a.act &= 0x40ff;
     if ((act & 0xff) == 1) hipLaunchKernelGGL((gemm_nt_q8_kernel<1, false, false, true>), dim3(256), dim3(512), 0, stream, a);
     else hipLaunchKernelGGL((gemm_nt_q8_kernel<0, false, false, true>), dim3(256), dim3(512), 0, stream, a);
     FIBER_CHECK_LAUNCH();

@@ -1267,6 +1267,15 @@ def collate_seed():
     return ((hi << 32) | (_seed_state["collate_ctr"] & 0xFFFFFFFF)) & _M64
 
 
+def collate_counter():
+    """Position of the collate key stream (saved in checkpoints so a resumed run does not replay the masks of batches 1..k)."""
+    return int(_seed_state.get("collate_ctr", 0))
+
+
+def set_collate_counter(n):
+    _seed_state["collate_ctr"] = int(n)
+
+
 def dropout(x, p, training):
     if not training or p <= 0.0:
         return x

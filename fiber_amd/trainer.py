@@ -14,6 +14,101 @@ from . import parallel
 from .lightning import seed_everything
 
 
+_CKPT_KEYS = ("state_dict", "optimizer_states", "lr_schedulers", "global_step", "epoch", "best_metric", "collate_ctr")
+
+
+class _Opaque:
+    """Placeholder for every object of a checkpoint whose class is not plain tensor / container data (Lightning's
+    `hyper_parameters` AttributeDict, `callbacks` keyed by callback classes, ...): built, never executed, dropped."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Opaque()
+
+    def __setstate__(self, state):
+        pass
+
+    def __setitem__(self, k, v):
+        pass
+
+    def __hash__(self):
+        return id(self)
+
+    def append(self, *a):
+        pass
+
+    def extend(self, *a):
+        pass
+
+    def update(self, *a, **k):
+        pass
+
+
+class _restricted_pickle:
+    """`pickle_module` for torch.load: resolves the globals a tensor checkpoint needs and maps EVERYTHING else to _Opaque --
+    no class or function from the file is imported or called, so a foreign checkpoint cannot run code here."""
+    import pickle as _p
+    __name__ = "fiber_amd.trainer._restricted_pickle"
+    _ALLOWED = {
+        ("collections", "OrderedDict"), ("collections", "defaultdict"), ("builtins", "set"), ("builtins", "frozenset"),
+        ("builtins", "dict"), ("builtins", "list"), ("builtins", "tuple"), ("builtins", "int"), ("builtins", "float"),
+        ("builtins", "bool"), ("builtins", "str"), ("builtins", "bytes"), ("builtins", "complex"), ("builtins", "slice"),
+        ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+        ("torch._utils", "_rebuild_parameter_with_state"), ("torch._tensor", "_rebuild_from_type_v2"),
+        ("torch.nn.parameter", "Parameter"), ("torch", "Size"), ("torch", "device"), ("torch", "Tensor"),
+        ("torch.serialization", "_get_layout"),
+    }
+
+    class Unpickler(_p.Unpickler):
+        def find_class(self, module, name):
+            if (module, name) in _restricted_pickle._ALLOWED:
+                return super().find_class(module, name)
+            if module == "torch" and (name.endswith("Storage") or name in _restricted_pickle._DTYPES):
+                return getattr(torch, name)
+            return _Opaque
+
+    _DTYPES = {n for n in dir(torch) if isinstance(getattr(torch, n), torch.dtype)}
+    load = staticmethod(_p.load)
+    loads = staticmethod(_p.loads)
+    UnpicklingError = _p.UnpicklingError
+    Pickler = _p.Pickler
+
+
+def load_checkpoint(path, map_location=None):
+    """Read a training checkpoint: this Trainer's own files, or a reference (PyTorch-Lightning 1.3) `.ckpt`
+    (coarse_grained/run.py:29-35 ModelCheckpoint, `resume_from_checkpoint` run.py:66).  Own files are tensors / numbers /
+    containers and load under `weights_only=True`.  A Lightning file also pickles `hyper_parameters`, `callbacks`, ... through
+    classes that are neither allow-listed nor (here) installed: those are read through a restricted unpickler that turns every
+    such object into an inert placeholder, and only the entries a resume needs are kept: state_dict, optimizer_states,
+    lr_schedulers, global_step, epoch (+ best_metric, collate_ctr of own files)."""
+    import pickle
+    try:
+        ck = torch.load(path, map_location=map_location, weights_only=True)
+    except (pickle.UnpicklingError, RuntimeError, AttributeError, ModuleNotFoundError):
+        ck = torch.load(path, map_location=map_location, weights_only=False, pickle_module=_restricted_pickle)
+    if not isinstance(ck, dict) or "state_dict" not in ck:
+        raise ValueError(f"{path}: not a training checkpoint (no 'state_dict' entry; found {sorted(ck) if isinstance(ck, dict) else type(ck).__name__})")
+
+    def plain(o):                                               # an entry we keep must not contain placeholders
+        if isinstance(o, _Opaque) or o is _Opaque:
+            return False
+        if isinstance(o, dict):
+            return all(plain(k) and plain(v) for k, v in o.items())
+        if isinstance(o, (list, tuple)):
+            return all(plain(v) for v in o)
+        return True
+
+    out = {}
+    for k in _CKPT_KEYS:
+        if k in ck:
+            if not plain(ck[k]):
+                raise ValueError(f"{path}: checkpoint entry '{k}' holds objects of classes this loader does not read")
+            out[k] = ck[k]
+    return out
+
+
 def _to_device(batch, device):
     return {k: (v.to(device) if isinstance(v, torch.Tensor) else [t.to(device) for t in v]
                 if isinstance(v, list) and v and isinstance(v[0], torch.Tensor) else v) for k, v in batch.items()}
@@ -57,12 +152,14 @@ class Trainer:
         if not self.default_root_dir:
             return
         os.makedirs(self.default_root_dir, exist_ok=True)
+        from . import ops
         torch.save({"state_dict": model.state_dict(), "global_step": self.global_step, "epoch": self.current_epoch,
                     "optimizer_states": [opt.state_dict()], "lr_schedulers": [sched["scheduler"].state_dict()],
-                    "best_metric": self.best_metric}, os.path.join(self.default_root_dir, name))
+                    "best_metric": self.best_metric, "collate_ctr": ops.collate_counter()},
+                   os.path.join(self.default_root_dir, name))
 
     def _resume(self, model, opt, sched, device):
-        ck = torch.load(self.resume_from_checkpoint, map_location=device, weights_only=True)   # tensors / numbers / containers only
+        ck = load_checkpoint(self.resume_from_checkpoint, map_location=device)
         model.load_state_dict(ck["state_dict"], strict=False)
         if ck.get("optimizer_states"):
             opt.load_state_dict(ck["optimizer_states"][0])      # FiberAdamW drops its cached device tables here
@@ -74,6 +171,9 @@ class Trainer:
         model.global_step = self.global_step
         from . import ops
         ops.mark_weights_dirty()                                # cached bf16 working copies belong to the old weights
+        # the MLM-masking key stream of data.device_collate: continue where the saved run stopped (a reference checkpoint has no
+        # such entry: one collated batch per micro-batch so far)
+        self._resume_collate_ctr = int(ck.get("collate_ctr", self.global_step * self.accumulate_grad_batches))
 
     # ---- loops ---------------------------------------------------------------------------------------------------
     def fit(self, model, train_dataloader, val_dataloader=None, device=None):
@@ -91,6 +191,8 @@ class Trainer:
         (opt,), (sched,) = model.configure_optimizers()
         if self.resume_from_checkpoint:
             self._resume(model, opt, sched, device)
+            from . import ops
+            ops.set_collate_counter(self._resume_collate_ctr)
         net = parallel.wrap_ddp(model, device)
         opt.zero_grad(set_to_none=True)
         micro, t0, last, step0 = 0, time.time(), None, self.global_step
@@ -114,7 +216,7 @@ class Trainer:
                 raise ValueError("a fractional val_check_interval needs a training dataloader with a length")
             every = max(1, int(len(train_dataloader) * vci))
         while not self._done() and (self.max_epochs is None or self.current_epoch < self.max_epochs):
-            seen, validated_at = 0, -1
+            seen = 0
             for batch_idx, batch in enumerate(train_dataloader):
                 seen += 1
                 batch = _to_device(batch, device)
@@ -148,14 +250,17 @@ class Trainer:
                         break
                 if every is not None and seen % every == 0:
                     run_validation()
-                    validated_at = seen
             if seen == 0:
                 raise ValueError("Trainer.fit: the training dataloader yielded no batch")
             if hasattr(model, "training_epoch_end"):
                 model.training_epoch_end([])
             self.current_epoch += 1
-            if validated_at != seen:                            # the epoch-end check, unless an interval check just ran
+            if every is None:                                   # val_check_interval = 1.0: the check at the end of the epoch
                 run_validation()
+            elif rank == 0:
+                # interval checks (pl.Trainer runs no additional epoch-end validation for them): the checkpoints written inside
+                # the epoch carry the epoch as unfinished -- re-save so that a resume does not repeat it
+                self._save(model, opt, sched, "last.ckpt")
             if val_dataloader is None and rank == 0:
                 self._save(model, opt, sched, "last.ckpt")
         return last

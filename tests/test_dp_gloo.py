@@ -220,3 +220,32 @@ def test_itc_queue_all_gather_world2(tmp_path):
     assert torch.equal(a["image_queue"][:, 9], feats[(1, 1)][0])           # step 1, rank 1 -> slots 9, 0, 1
     assert torch.equal(a["image_queue"][:, 0:2], feats[(1, 1)][1:].T)
     assert torch.equal(a["image_queue"][:, 2:6], torch.cat([feats[(0, 0)], feats[(0, 1)]])[2:6].T)   # survivors of step 0
+
+
+def _run_bench(args, extra_env=None, timeout=600):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, cwd=root, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_bench_gpus_n_spawns_n_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no launcher must itself start 2 ranks (one per GPU; reference: Lightning DDP spawns them,
+    coarse_grained/run.py:50-54) and form a 2-rank process group.  --dry-run stops after the rendezvous + one all-reduce, which
+    is all a machine without GPUs can execute; tests/test_hip_ddp.py runs the full self-spawned bench on a GPU."""
+    import json
+    res = _run_bench(["--gpus", "2", "--dry-run"], {"FIBER_DIST_BACKEND": "gloo"})
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]               # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["allreduce_of_ones"] == 2.0
+
+
+def test_bench_gpus_disagreeing_with_the_launcher_fails_loudly():
+    res = _run_bench(["--gpus", "2", "--dry-run"], {"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
+    assert res.returncode != 0 and "--gpus 2" in res.stderr and "WORLD_SIZE=4" in res.stderr, res.stderr[-500:]
+    assert not [l for l in res.stdout.splitlines() if l.startswith("{")]

@@ -173,3 +173,22 @@ def test_bench_contract_two_ranks_one_gpu():
     assert abs(d["value"] - 16 / (d["ms_per_step"] * 1e-3)) < 0.05 * d["value"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in d["roofline"], k
+
+
+def test_bench_self_spawns_two_ranks_one_gpu():
+    """`python bench.py --gpus 2` with NO external launcher: bench.py re-executes itself under torch.distributed.run, the two
+    ranks share the one visible GPU over gloo, and rank 0 prints the contract line with n_gpus = 2 and the process-group size."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FIBER_DIST_BACKEND"] = "gloo"
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8",
+                          "--no-extras"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["global_batch"] == 16
+    assert len(d["step_ms"]["per_rank_mean"]) == 2

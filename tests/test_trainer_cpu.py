@@ -274,9 +274,9 @@ def test_val_check_interval_int_and_fraction(tmp_path):
         return m.val_runs
 
     assert runs(1.0) == 2                      # once per epoch
-    assert runs(2) == 6                        # after batches 2, 4, 6 of each epoch (the one at 6 IS the epoch-end check)
+    assert runs(2) == 6                        # after batches 2, 4, 6 of each epoch
     assert runs(0.5) == 4                      # after batches 3 and 6
-    assert runs(4) == 4                        # after batch 4, plus the epoch-end check
+    assert runs(4) == 2                        # after batch 4 of each epoch; pl.Trainer runs no extra epoch-end check for an interval
     for bad in (0.0, 1.5, 0):
         with pytest.raises(ValueError):
             Trainer(val_check_interval=bad)
@@ -303,3 +303,88 @@ def test_collate_seed_advances_in_graph_rng_mode():
     assert a == [ops.collate_seed() for _ in range(3)]
     ops.manual_seed(12)
     assert ops.collate_seed() not in a
+
+
+def test_resume_from_a_lightning_shaped_checkpoint(tmp_path):
+    """a reference (PyTorch-Lightning 1.3) `.ckpt` pickles `hyper_parameters` / `callbacks` through classes that
+    `weights_only=True` rejects (and that are not installed here).  `load_checkpoint` must still resume from it: those objects
+    become inert placeholders, only state_dict / optimizer_states / lr_schedulers / global_step / epoch are kept, and nothing
+    from the file is imported or executed."""
+    import sys
+    import types
+    import pytest
+    from fiber_amd.trainer import load_checkpoint
+    torch.manual_seed(0)
+    data = [{"x": torch.randn(8, 4), "y": torch.randn(8, 1)} for _ in range(4)]
+    m = ToyVal(_cfg(optim_type="adamw", max_steps=8))
+    tr = Trainer(max_steps=4, log_every_n_steps=0, default_root_dir=str(tmp_path))
+    tr.fit(m, data, device=torch.device("cpu"))
+    own = torch.load(tmp_path / "last.ckpt", weights_only=True)
+    # a module that exists only while the file is written, like pytorch_lightning on the machine that trained the reference
+    fake = types.ModuleType("pl_absent_here")
+
+    class AttributeDict(dict):
+        pass
+
+    class ModelCheckpoint:
+        executed = False
+
+        def __reduce__(self):                                  # a callable the loader must never call
+            return (_boom, ())
+
+    AttributeDict.__module__ = ModelCheckpoint.__module__ = "pl_absent_here"
+    AttributeDict.__qualname__, ModelCheckpoint.__qualname__ = "AttributeDict", "ModelCheckpoint"
+    fake.AttributeDict, fake.ModelCheckpoint, fake._boom = AttributeDict, ModelCheckpoint, _boom
+    _boom.__module__ = "pl_absent_here"
+    sys.modules["pl_absent_here"] = fake
+    try:
+        ck = dict(own, hyper_parameters=AttributeDict(config={"vit": "swin_base"}), callbacks={ModelCheckpoint: {"best": 1.0}},
+                  extra=ModelCheckpoint(), **{"pytorch-lightning_version": "1.3.2"})
+        ck.pop("collate_ctr", None)
+        torch.save(ck, tmp_path / "pl.ckpt")
+    finally:
+        del sys.modules["pl_absent_here"]
+    with pytest.raises(Exception):
+        torch.load(tmp_path / "pl.ckpt", weights_only=True)
+    got = load_checkpoint(str(tmp_path / "pl.ckpt"))
+    assert not _boom.called
+    assert set(got) == {"state_dict", "optimizer_states", "lr_schedulers", "global_step", "epoch", "best_metric"}
+    assert got["global_step"] == 4 and all(torch.equal(got["state_dict"][k], v) for k, v in own["state_dict"].items())
+    m2 = ToyVal(_cfg(optim_type="adamw", max_steps=8))
+    tr2 = Trainer(max_steps=6, log_every_n_steps=0, resume_from_checkpoint=str(tmp_path / "pl.ckpt"))
+    tr2.fit(m2, data, device=torch.device("cpu"))
+    assert tr2.global_step == 6
+    with pytest.raises(ValueError):                             # not a training checkpoint
+        torch.save({"weights": torch.zeros(2)}, tmp_path / "w.pt")
+        load_checkpoint(str(tmp_path / "w.pt"))
+
+
+def _boom():
+    _boom.called = True
+    raise RuntimeError("code from a checkpoint was executed")
+
+
+_boom.called = False
+
+
+def test_interval_checkpoints_finish_the_epoch_and_collate_stream_resumes(tmp_path):
+    """(a) with an interval check on the last batch the epoch-end save used to be skipped, so last.ckpt recorded the
+    finished epoch as unfinished; (b) the collate (MLM-masking) key stream restarts at 0 on manual_seed -- its position is now
+    part of the checkpoint and a resumed run continues it."""
+    from fiber_amd import ops
+    torch.manual_seed(0)
+    data = [{"x": torch.randn(8, 4), "y": torch.randn(8, 1)} for _ in range(4)]
+    m = ToyVal(_cfg(optim_type="adamw", max_steps=8))
+    ops.manual_seed(5)
+    keys = [ops.collate_seed() for _ in range(4)]              # four batches collated by the first run
+    tr = Trainer(max_steps=None, max_epochs=1, log_every_n_steps=0, default_root_dir=str(tmp_path), val_check_interval=2)
+    tr.fit(m, data, val_dataloader=data[:2], device=torch.device("cpu"))
+    ck = torch.load(tmp_path / "last.ckpt", weights_only=True)
+    assert ck["epoch"] == 1 and ck["global_step"] == 4 and ck["collate_ctr"] == 4
+    ops.manual_seed(5)                                          # a fresh process seeds again: the stream is back at 0 ...
+    m2 = ToyVal(_cfg(optim_type="adamw", max_steps=8))
+    tr2 = Trainer(max_steps=5, log_every_n_steps=0, resume_from_checkpoint=str(tmp_path / "last.ckpt"))
+    tr2.fit(m2, data, device=torch.device("cpu"))
+    assert tr2.current_epoch >= 1
+    nxt = ops.collate_seed()                                    # ... and the resume moved it past the first run's batches
+    assert nxt not in keys and (nxt & 0xFFFFFFFF) == 5
