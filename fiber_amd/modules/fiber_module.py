@@ -43,8 +43,9 @@ class FIBERTransformerSS(LightningModule):
         bert_config = types.SimpleNamespace(        # RobertaConfig defaults: layer_norm_eps = 1e-12
             vocab_size=config["vocab_size"], hidden_size=config["hidden_size"], layer_norm_eps=1e-12)
 
-        if config.get("residual_dtype"):                  # process-wide switch, like the reference's module globals below
-            ops.set_residual_dtype(config["residual_dtype"])
+        # process-wide switch, like the reference's module globals below; ALWAYS set, so that a model built without the key does
+        # not inherit the mode of the model built before it (default: env FIBER_RESIDUAL_DTYPE, else bf16)
+        ops.set_residual_dtype(config.get("residual_dtype") or os.environ.get("FIBER_RESIDUAL_DTYPE", "bf16"))
         self.num_fuse_block = config["num_fuse_block"]
         self.num_text_layer = config["num_layers"]
         roberta.NUM_FUSE_BLOCK = swin_transformer.NUM_FUSE_BLOCK = self.num_fuse_block

@@ -577,9 +577,11 @@ class _MLP(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dy32=None):
+        dres = dy if ctx.has_res else None
+        if not ctx.saved_tensors:                      # frozen block on a trainable stream: only the residual needs a gradient
+            return (None,) * 5 + (dres, None, None, None)
         x2, w1, w2, h, g, rowscale = ctx.saved_tensors
         dy2 = _c(dy).view(-1, w2.shape[0])
-        dres = dy if ctx.has_res else None
         db2 = None
         C, C4 = dy2.shape[1], h.shape[1]
         fused = C % 64 == 0 and C4 % 8 == 0 and (_FUSED_MLP_BWD == "1" or (_FUSED_MLP_BWD == "auto" and C < 1024))
@@ -678,7 +680,7 @@ def layernorm(x, gamma, beta, eps=1e-5, want_f32=None):
     input, i.e. on when x carries a payload and residual_fp32() -- the post-LN text stack) attaches the output's own payload."""
     x32 = f32_of(x)
     if want_f32 is None:
-        want_f32 = False
+        want_f32 = x32 is not None and residual_fp32()
     y, y32 = _LayerNorm.apply(x, gamma, beta, eps, x32, bool(want_f32))
     return with_f32(y, y32)
 
@@ -915,8 +917,10 @@ def _pack_get(weights, biases):
             ok = ok and b.data_ptr() == bp.data_ptr() + off * 4
             off += n
         if not ok:                                          # first use / the parameters moved (model.to, load with assign)
+            if any(b.dtype != torch.float32 for b in biases):   # the members' .data is re-pointed at the pack: it must keep their dtype
+                raise TypeError("linear_packed: biases must be fp32 masters (got " + ", ".join(str(b.dtype) for b in biases) + ")")
             with torch.no_grad():
-                bp = torch.cat([b.detach().float().reshape(-1) for b in biases])
+                bp = torch.cat([b.detach().reshape(-1) for b in biases])
                 off = 0
                 for b, n in zip(biases, pk["Ns"]):
                     if b.is_cuda:
