@@ -210,7 +210,12 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x16 (&acc)[B
 // Column sums (EPI 2) are per 128-row wave sub-tile: `colpart` has two rows per output tile (fiber_gemm_row_tile says 128).
 template <int TM, int EPI, bool HAS_R, bool HAS_RS, bool FULL>
 __device__ __forceinline__ void wave_epilogue(const GemmArgs& a, f32x16 (&acc)[TM][2], bf16* cw, int m0w, int n0w) {
-  const int lane = threadIdx.x & 63;
+  // The lane index is re-derived here (v_mbcnt, made opaque) instead of taken from threadIdx: everything below that depends on it
+  // only -- slab addresses, the 16-byte column of the lane -- is otherwise hoisted out of the persistent tile loop and held in
+  // registers through the K loop, which at 248+ VGPRs pushed the gelu' variants into scratch (and a scratch reload makes the
+  // compiler wait vmcnt(0): a drain of the LDS-DMA stream).
+  int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  asm volatile("" : "+v"(lane));
   const int wr = lane & 31, wh = lane >> 5;              // staging: row of the slab, which 4-column half of an 8-column group
   const int rr = lane >> 3, rc = lane & 7;               // read-back: row inside an 8-row pass, 16-byte chunk of the 128-B row
   constexpr bool E0 = EPI == 0 || EPI == 3;

@@ -608,7 +608,20 @@ def test_loss_curve_fiber_base_384_mlm_itm_8_steps():
     optimizer steps over 2 fixed batches against the fp32 oracle on the host cores (the oracle's 8 steps of 4 image passes at
     384^2 are what bounds the length).  Bound = 2x the measured values (profiles/r02_loss_curve_fiber_base.json)."""
     summary = _loss_curve(dict(cases.SWIN_B), 384, 2, 8, 2, 2, "fiber_base")
-    assert summary["gap_max"] < 2.5e-2 and summary["gap_median"] < 1.0e-2, summary
+    # measured over three rounds: median 3.6-3.7e-3, max 5.0e-3 .. 1.1e-2 (batch 2: a 12-token MLM mean); bound = 1.5 x the worst seen
+    assert summary["gap_max"] < 1.6e-2 and summary["gap_median"] < 5.6e-3, summary
+
+
+def test_loss_curve_swin_t_224_realistic_batch():
+    """Round 4 (review item 6): the curves above run at batch 2 on cycled batches -- the regime that maximises rounding noise.  At a
+    realistic per-GPU batch the picture is different.  tools/loss_curve_study.py, Swin-T 224^2, B = 32, 50 FRESH batches
+    (profiles/r04_loss_curve_swin_t_b32.json): gap to the fp32 oracle median 6.0e-4 / p90 1.1e-3 / max 1.4e-3, 41 of 50 steps inside
+    the north star's +-1e-3 -- the same count as the oracle under torch.autocast(bf16), the reference's own mixed precision (median
+    5.2e-4 / max 1.9e-3); with the fp32 residual stream 2.8e-4 / 1.5e-3, 46 of 50.  FIBER-Base 384^2 at the reference's B = 8, 20
+    steps: 1.3e-3 / 3.5e-3 (autocast oracle 1.05e-3 / 2.0e-3), profiles/r04_loss_curve_fiber_base_b8.json.  This test repeats the
+    first 10 steps of the Swin-T run (the fp32 oracle's 10 steps at B = 32 cost ~2 minutes of host time); bounds = 1.5 x measured."""
+    summary = _loss_curve(dict(cases.SWIN_T), 224, 32, 10, 10, 1, "swin_t_b32")
+    assert summary["gap_median"] < 1.3e-3 and summary["gap_max"] < 2.2e-3, summary
 
 
 def test_library_gemm_only_from_heads():

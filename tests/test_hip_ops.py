@@ -262,6 +262,8 @@ def test_window_attention_head_major_layout(ops, B, H, W, heads, ws, shift):
     (70, 16, 24),            # tiny: one K tile with a tail, one partly filled 128x128 tile
     (64, 8, 8), (130, 264, 520),
     (18432, 128, 64),        # patch embedding (K = 48 padded to 64)
+    (73728, 1536, 512),      # qkv at stage 2: the q8-schedule kernel (round 4), 12 tiles x 21 splits
+    (8192, 1024, 1024), (128, 256, 256), (64, 512, 256),   # ... its short K loops: 2 K tiles per split, a single K tile
 ])
 def test_wgrad_tn_kernel(ops, M, N, K):
     """dW = dY^T X (+ bias gradient = column sums of dY) on csrc/gemm_tn.hip against fp32 products of the same bf16 operands.

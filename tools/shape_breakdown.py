@@ -48,6 +48,40 @@ def gemm_row(name, sc):
     return None
 
 
+def stream_row(name, sc, nn):
+    """(flops, algorithmic bytes, label) of a non-GEMM launch: `sc` its scalar arguments, `nn` = which pointer arguments were non-NULL
+    (in signature order).  Bytes = every tensor read or written once (round 4: so that the per-shape roofline table covers the
+    streaming kernels too)."""
+    if name == "fiber_layernorm_fwd_bf16":
+        rows, C = sc[0], sc[1]
+        return 0.0, 4 * rows * C, "LayerNorm fwd"
+    if name == "fiber_layernorm_bwd_bf16":
+        rows, C = sc[0], sc[1]
+        dres = nn[5]
+        return 0.0, (8 if dres else 6) * rows * C, "LayerNorm bwd" + (" + residual grad" if dres else "")
+    if name in ("fiber_window_attn_fwd_bf16", "fiber_window_attn_bwd_bf16"):
+        Bn, H, W, C, heads, ws = sc[:6]
+        T, N = Bn * H * W, ws * ws
+        if name.endswith("fwd_bf16"):
+            return 4.0 * T * N * C, 8 * T * C, f"window attention fwd ws{ws}"
+        return 10.0 * T * N * C, 16 * T * C, f"window attention bwd ws{ws}"
+    if name in ("fiber_mha_fwd_bf16", "fiber_mha_bwd_bf16"):
+        Bn, heads, Lq, Lk, D = sc[:5]
+        e = Bn * heads * D * 2
+        if name.endswith("fwd_bf16"):
+            return 4.0 * Bn * heads * Lq * Lk * D, e * (2 * Lq + 2 * Lk), f"attention fwd {Lq}x{Lk} d{D}"
+        return 10.0 * Bn * heads * Lq * Lk * D, e * (4 * Lq + 4 * Lk), f"attention bwd {Lq}x{Lk} d{D}"
+    if name == "fiber_stream_add":
+        n, res_kind = sc[-1], sc[0]
+        by = (2 if res_kind == 1 else 4 if res_kind == 2 else 0) + 2 + (2 if nn[2] else 0) + (4 if nn[6] else 0) + (2 if nn[7] else 0)
+        return 0.0, by * n, "residual glue fwd"
+    if name == "fiber_stream_add_bwd":
+        n = sc[-1]
+        by = 2 + (2 if nn[1] else 0) + 2 + (2 if nn[6] else 0)
+        return 0.0, by * n, "residual glue bwd"
+    return None
+
+
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
@@ -75,9 +109,10 @@ def main():
         if recording[0]:
             sig = lib.SIGNATURES[name]
             sc = tuple(a for a, t in zip(args, sig) if t is not lib.P)
+            nn = tuple(a is not None for a, t in zip(args, sig) if t is lib.P)
             e = torch.cuda.Event(enable_timing=True)
             e.record()
-            log.append((name, sc, e))
+            log.append((name, sc, e, nn))
 
     lib.call = traced
     ops.lib.call = traced
@@ -109,19 +144,23 @@ def main():
         torch.cuda.synchronize()
         total_ms += e0.elapsed_time(e1) / steps
         prev = e0
-        for name, sc, e in log:
+        for name, sc, e, nn in log:
             # time since the previous traced launch: this entry point's kernels plus whatever ATen work ran in between
             ms = prev.elapsed_time(e)
             prev = e
-            key = (name, sc)
+            key = (name, sc, nn if name in ("fiber_layernorm_bwd_bf16", "fiber_stream_add", "fiber_stream_add_bwd") else ())
             a = agg.setdefault(key, [0.0, 0])
             a[0] += ms / steps
             a[1] += 1
     rows = []
-    for (name, sc), (ms, n) in agg.items():
+    for (name, sc, nn), (ms, n) in agg.items():
         calls = n / steps
         r = {"entry": name, "args": list(sc), "ms_per_step": round(ms, 3), "calls_per_step": round(calls, 1), "us_per_call": round(ms / calls * 1e3, 1)}
         g = gemm_row(name, sc)
+        st = None if g else stream_row(name, list(sc), nn if nn else tuple(True for _ in range(16)))
+        if st:
+            fl, by, kind = st
+            r.update(kind=kind, TFLOPs=round(fl * calls / ms / 1e9, 1), TBps=round(by * calls / ms / 1e9, 3), flop_per_call=fl, bytes_per_call=by)
         if g:
             fl, by, kind, shp = g
             r.update(kind=kind, shape=list(shp), TFLOPs=round(fl * calls / ms / 1e9, 1), TBps=round(by * calls / ms / 1e9, 3),
