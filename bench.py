@@ -146,13 +146,25 @@ def cpu_baseline(budget_s=80.0, batch=2):
     return dict(base, value=round(batch / b, 4), cores=t)
 
 
+def _latest_profile(suffix):
+    """profiles/rNN_<suffix> of the latest round that committed one (path, file name) -- (None, None) when there is none."""
+    import glob
+    import re
+    best = None
+    for p in glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{suffix}")):
+        n = int(re.match(r"r(\d\d)_", os.path.basename(p)).group(1))
+        if best is None or n > best[0]:
+            best = (n, p)
+    return (best[1], "profiles/" + os.path.basename(best[1])) if best else (None, None)
+
+
 def _dominant_from_profile(B):
     """The (entry point, shape) with the largest share of the step in the committed per-shape profile of this bench
-    (profiles/r03_shape_breakdown.json, written by tools/shape_breakdown.py at the bench batch); None when the file is missing or
-    was taken at another batch."""
+    (profiles/rNN_shape_breakdown.json of the latest round, written by tools/shape_breakdown.py at the bench batch); None when the file
+    is missing or was taken at another batch."""
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r03_shape_breakdown.json")))
-    except (OSError, ValueError):
+        prof = json.load(open(_latest_profile("shape_breakdown.json")[0]))
+    except (OSError, ValueError, TypeError):
         return None
     if prof.get("batch") != B:
         return None
@@ -226,17 +238,19 @@ def time_dominant_kernel(B, device):
     bound = "hbm" if hbm_floor_us >= mfma_floor_us else "mfma"
     out = {"kernel": name, "entry": row["entry"], "kind": kind, "shape": [M, N, K], "us": round(us, 2),
            "share_of_step": (round(row["ms_per_step"] / step_ms, 4) if step_ms else None),
-           "selected_from": "profiles/r03_shape_breakdown.json (largest ms per step)" if dom else "default (no profile at this batch)",
+           "selected_from": f"{_latest_profile('shape_breakdown.json')[1]} (largest ms per step)" if dom else "default (no profile at this batch)",
            "bound": bound, "flop_per_byte": round(flops / alg_bytes, 1),
            "achieved": round(gbps if bound == "hbm" else tf, 1), "peak": PEAK_HBM_GBPS if bound == "hbm" else PEAK_BF16_TFLOPS,
            "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round((gbps / PEAK_HBM_GBPS) if bound == "hbm" else (tf / PEAK_BF16_TFLOPS), 4),
            "hbm_GBps": round(gbps, 1), "hbm_frac": round(gbps / PEAK_HBM_GBPS, 4), "mfma_TFLOPs": round(tf, 1),
            "mfma_frac": round(tf / PEAK_BF16_TFLOPS, 4), "algorithmic_bytes": alg_bytes, "traffic": None}
     try:   # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs on this shape)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_kernels.json")))["dominant"]
+        pmc_path, pmc_name = _latest_profile("pmc_kernels.json")
+        pmc = json.load(open(pmc_path))["dominant"]
         if pmc["algorithmic_bytes_per_launch"] == alg_bytes and pmc.get("shape") == [M, N, K]:
             out["traffic"] = int(pmc["traffic_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
+            out["traffic_from"] = pmc_name
+    except (OSError, KeyError, ValueError, TypeError):
         pass
     return out
 

@@ -15,7 +15,7 @@
 // Structure (flash-style, no score tensor in HBM): a wave owns a strip of 16 queries; K and V of up to 160 keys are
 // staged in LDS per workgroup as row-major images and shared by its waves (the transposed MFMA operands -- V^T for P.V,
 // K^T, Q^T, dO^T in the backward -- are read with ds_read_b64_tr_b16); S^T = K.Q^T is computed with swapped MFMA operands so a lane
-// holds 4 consecutive keys of ONE query => row max / row sum are in-lane + two __shfl_xor (no LDS round trip), and the
+// holds 4 consecutive keys of ONE query => row max / row sum are in-lane + two row swaps (v_permlane16/32_swap: VALU, no LDS round trip), and the
 // fp32 probabilities convert in-register into the B operand of O^T = V^T.P^T (the key order inside a 32-key MFMA
 // k-slot is permuted identically on the V^T side, which is free).  Longer key ranges are walked in chunks with an
 // online softmax.  Backward recomputes P from the saved log-sum-exp (one fp32 per query/head) in two passes:
@@ -66,8 +66,8 @@ __device__ __forceinline__ void window_tok(const AttnP& p, int g, int i, int& to
   reg = p.shift > 0 ? region_of(R, p.Hres, p.ws, p.shift) * 3 + region_of(C, p.Wres, p.ws, p.shift) : 0;
 }
 
-__device__ __forceinline__ float group4_max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
-__device__ __forceinline__ float group4_sum(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
+__device__ __forceinline__ float group4_max(float v) { return rows4_max(v); }
+__device__ __forceinline__ float group4_sum(float v) { return rows4_sum(v); }
 
 // Head served by block y.  With head_dim 32 a head's slice of a token row is 64 B = half a cache line, and blocks y and y+1 (which
 // share every line) land on different XCDs when grid.x == 1 (linear block id = y + H*z, XCD = id % 8): each XCD's L2 then fetches

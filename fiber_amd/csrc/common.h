@@ -34,6 +34,29 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Reductions over the four lanes {l, l^16, l^32, l^48} that share one MFMA-C row: two gfx950 row swaps (v_permlane16_swap / v_permlane32_swap,
+// plain VALU) instead of two ds_bpermute round trips through the LDS pipe.  With both operands the same register the swap returns
+// (mine-or-partner, partner-or-mine) in every lane, so combining the two halves is the xor-shuffle reduction, bit for bit (max and + commute).
+#ifdef FIBER_ROWS4_SHFL   // A/B build only (tools/): the ds_bpermute form
+__device__ __forceinline__ float rows4_max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
+__device__ __forceinline__ float rows4_sum(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
+#else
+__device__ __forceinline__ float rows4_max(float v) {
+  unsigned u = __builtin_bit_cast(unsigned, v);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  u = __builtin_bit_cast(unsigned, fmaxf(__builtin_bit_cast(float, (unsigned)a[0]), __builtin_bit_cast(float, (unsigned)a[1])));
+  auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__builtin_bit_cast(float, (unsigned)b[0]), __builtin_bit_cast(float, (unsigned)b[1]));
+}
+__device__ __forceinline__ float rows4_sum(float v) {
+  unsigned u = __builtin_bit_cast(unsigned, v);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  u = __builtin_bit_cast(unsigned, __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
+}
+#endif
+
 // Exact (erf) GELU, cheap enough for a GEMM epilogue.  Phi(x) = 0.5 (1 + erf(x / sqrt 2)) from Abramowitz-Stegun 7.1.28,
 //   erf(z) = 1 - (1 + a1 z + ... + a6 z^6)^-16  (z >= 0, |err| <= 3e-7),
 // with z = |x| / sqrt 2 folded into the coefficients and the 0.5 folded in as a 2^(1/16) scale of the polynomial, so that

@@ -50,8 +50,8 @@ struct WinP {
 };
 
 __device__ __forceinline__ int region_of(int x, int n, int ws, int shift) { return x < n - ws ? 0 : (x < n - shift ? 1 : 2); }
-__device__ __forceinline__ float g4max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
-__device__ __forceinline__ float g4sum(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
+__device__ __forceinline__ float g4max(float v) { return rows4_max(v); }
+__device__ __forceinline__ float g4sum(float v) { return rows4_sum(v); }
 __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
   bf16x8 o;
 #pragma unroll

@@ -3,7 +3,7 @@
 
 For the GEMM entry points the row carries the algorithmic FLOPs and bytes, so the table gives achieved TFLOP/s and TB/s per shape --
 the per-shape view rocprofv3's per-kernel-name statistics cannot give (one kernel name serves many shapes).  bench.py reads the
-committed result (profiles/r03_shape_breakdown.json) to pick the dominant kernel it times live.
+committed result (the latest profiles/rNN_shape_breakdown.json) to pick the dominant kernel it times live.
 
     FIBER_NO_OVERLAP=1 python tools/shape_breakdown.py [batch=256] [steps=3]   ->  gpurun_out/shape_breakdown.json
 """
@@ -148,6 +148,8 @@ def main():
             # time since the previous traced launch: this entry point's kernels plus whatever ATen work ran in between
             ms = prev.elapsed_time(e)
             prev = e
+            if name.startswith("fiber_mha_"):
+                sc = sc[:-1] + (0,)                  # the dropout seed differs per call: not part of the shape
             key = (name, sc, nn if name in ("fiber_layernorm_bwd_bf16", "fiber_stream_add", "fiber_stream_add_bwd") else ())
             a = agg.setdefault(key, [0.0, 0])
             a[0] += ms / steps
