@@ -157,8 +157,25 @@ __global__ __launch_bounds__(TS * 2) void gemm_tn_kernel(TnArgs a) {
 #pragma unroll
   for (int t = 0; t < TA; ++t) csa[t] = 0.f;
   const bool do_cs = a.cs != nullptr && tk == 0 && wb == 0;       // wave-uniform
-  // K tile kt belongs to sample (m0 + kt*BKM) / rows_per_sample; its MFMAs are skipped when that sample was dropped
-  auto kept = [&](int kt) { return a.row_mask == nullptr || a.row_mask[(m0 + kt * BKM) / a.rows_per_sample] != 0.f; };
+  // K tile kt belongs to sample (m0 + kt*BKM) / rows_per_sample; its MFMAs are skipped when that sample was dropped.  The factors of the
+  // next 64 samples are fetched with ONE vector load and kept as a ballot in an SGPR pair: a load in front of every K tile's branch cost
+  // the masked form 18 % of its rate (and any vector load inside the loop makes hipcc wait with vmcnt(0), which also drains the LDS-DMA
+  // requests of the next K tile -- the compiler does not count what inline asm issued).  The reload every 64 samples sits at the top of
+  // an iteration, where no DMA is outstanding.
+  const int tps = a.row_mask ? a.rows_per_sample / BKM : 1;       // K tiles per sample
+  const int nsamp = a.row_mask ? (a.M + a.rows_per_sample - 1) / a.rows_per_sample : 1;
+  int samp0 = a.row_mask ? (m0 / BKM) / tps : 0, srem = a.row_mask ? (m0 / BKM) % tps : 0, sbit = 0;
+  unsigned long long keepbits = ~0ull;
+  auto reload_mask = [&]() {
+    if (a.row_mask) keepbits = __builtin_amdgcn_ballot_w64(a.row_mask[min(samp0 + lane, nsamp - 1)] != 0.f);
+  };
+  auto kept_then_advance = [&]() {                                 // is the K tile the counters point at kept?  then step to the next tile
+    if (sbit == 64) { samp0 += 64; sbit = 0; reload_mask(); }
+    const bool k = (keepbits >> sbit) & 1ull;
+    if (++srem == tps) { srem = 0; ++sbit; }
+    return k;
+  };
+  reload_mask();
 
   bf16x8 fa[2][TA], fb[2][TB];
   auto load_phase = [&](int kt, int sub) {
@@ -203,7 +220,7 @@ __global__ __launch_bounds__(TS * 2) void gemm_tn_kernel(TnArgs a) {
     phase_barrier(true);
     if (wa == 1) phase_barrier(false);                   // group 1 runs one phase behind (see gemm.hip, wide kernel)
     for (int kt = 0; kt < nk; ++kt) {
-      const bool inc = kept(kt);
+      const bool inc = kept_then_advance();
       load_phase(kt, 0);
       if (kt + 1 < nk) dma(kt + 1);
       phase_barrier(false);
@@ -219,6 +236,7 @@ __global__ __launch_bounds__(TS * 2) void gemm_tn_kernel(TnArgs a) {
     static_assert(STAG || (NS == 4 && NDI == 2), "counted vmcnt below: 3 tiles x 4 DMA instructions per wave in flight");
     for (int pre = 0; pre < NS - 1 && pre < nk; ++pre) dma(pre);
     for (int kt = 0; kt < nk; ++kt) {
+      const bool inc = kept_then_advance();
       const int newer = min(nk - 1 - kt, NS - 2);          // K tiles requested after tile kt (2 NDI instructions per wave each)
       if (newer >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
       else if (newer == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
@@ -228,7 +246,7 @@ __global__ __launch_bounds__(TS * 2) void gemm_tn_kernel(TnArgs a) {
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       if (kt + NS - 1 < nk) dma(kt + NS - 1);             // into the stage tile kt-1 just vacated
-      if (kept(kt)) {
+      if (inc) {
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) {
           load_phase(kt, sub);

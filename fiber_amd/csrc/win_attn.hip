@@ -1045,7 +1045,7 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
         if constexpr (BORDER) sv = region_mask(sv, qg, kregf_own, -144.26950408889634f);
         const f32x4 pr = exp2x4(sv);
         const f32x4 ds = pr * sdp;
-        if (qi < NL) db_mine[qi * NTH] += ds; else dbacc[qi - NL] += ds;
+        if constexpr (qi < NL) db_mine[qi * NTH] += ds; else dbacc[qi - NL] += ds;
         bf16x4 dsb, pb;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { dsb[r] = f2bf(ds[r]); pb[r] = f2bf(pr[r]); }

@@ -46,3 +46,10 @@ out = {"dominant": {"kernel": name, "selected": info["kernel"], "kind": info["ki
 json.dump(out, open(f"gpurun_out/{TAG}_pmc_kernels.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
+# the bench line itself (50 steps, CPU baseline included), the same step with the round-3 tile boundary, and the small-batch sweep
+python bench.py --steps 50 --warmup 10 > gpurun_out/${TAG}_bench_b256.log 2>&1
+FIBER_GEMM_STAGGER=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out/${TAG}_bench_b256_stagger_kept.log 2>&1
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out/${TAG}_bench_b256_again.log 2>&1
+for b in 8 16 32 64; do
+  python bench.py --batch $b --steps 30 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import json,sys; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print($b, d['value'], d['ms_per_step'])"
+done > gpurun_out/${TAG}_batch_sweep.log 2>&1
