@@ -7,7 +7,7 @@
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-#define LDSP(T, p) ((__attribute__((address_space(3))) T*)(p))
+#define LDSP(T, p) ((__attribute__((address_space(3))) T*)(size_t)(p))      // p: 32-bit LDS byte address
 
 // OP 0: b128 lane-linear   1: b64 lane-linear   2: b64_tr, TN pattern   3: plain b64, TN pattern   4: b64_tr lane-linear (8 B per lane)
 // 5: b128 with the NT kernel's fragment pattern (row = lane & 31, 16-byte chunk (lane >> 5) ^ swizzle, 128-byte rows)
@@ -26,13 +26,15 @@ __global__ __launch_bounds__(1024) void k(int* out, long long* cyc, int iters) {
     const int rowl = kh * 8 + (fi >> 2), sx = (fi >> 2) << 1;
     off = rowl * 512 + (((cg) ^ sx) << 5) + (fi & 3) * 8;
   }
-  const char* base = smem + (wave & 3) * 16384 + off;      // 4 x 16 KB regions: waves of one SIMD group read their own region
+  // 4 x 16 KB regions: waves of one SIMD group read their own region
+  unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (wave & 3) * 16384 + off;
   i32x4 acc = {0, 0, 0, 0};
   long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
+    asm volatile("" : "+v"(base));          // the addresses are loop-invariant: keep the compiler from hoisting the plain reads
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const char* p = base + (OP == 0 ? j * 1024 : (OP == 1 || OP == 4) ? j * 512 : OP == 5 ? j * 4096 % 16384 + (j >> 2) * 64 : (j & 3) * 64 + (j >> 2) * 8192);
+      const unsigned p = base + (OP == 0 ? j * 1024 : (OP == 1 || OP == 4) ? j * 512 : OP == 5 ? j * 4096 % 16384 + (j >> 2) * 64 : (j & 3) * 64 + (j >> 2) * 8192);
       if (OP == 0 || OP == 5) { i32x4 v = *LDSP(i32x4, p); acc ^= v; }
       else if (OP == 1 || OP == 3) { i32x2 v = *LDSP(i32x2, p); acc[0] ^= v[0]; acc[1] ^= v[1]; }
       else { s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDSP(s16x4, p)); i32x2 w = __builtin_bit_cast(i32x2, v); acc[0] ^= w[0]; acc[1] ^= w[1]; }
