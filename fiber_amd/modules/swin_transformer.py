@@ -97,8 +97,10 @@ class WindowAttention(nn.Module):
         S = y.shape[1]
         assert y.shape[0] == B, "text batch must match image batch"
         kv = ops.linear(y, self.qkv_text_i2t.weight, self.qkv_text_i2t.bias).view(B * S, 2 * C)
-        qi = ops.linear(ops.layernorm(a, self.norm_i2t_i.weight, self.norm_i2t_i.bias, self.norm_i2t_i.eps),
-                        self.qkv_i2t.weight, self.qkv_i2t.bias).view(B * L, C)
+        # `a` feeds the i2t query LayerNorm AND the block's sum below: one autograd node for both uses, so that the LayerNorm backward adds
+        # the other use's gradient in its own pass (no separate fan-in add over [B, L, C] in the backward)
+        an, a = ops.layernorm_res(a, self.norm_i2t_i.weight, self.norm_i2t_i.bias, self.norm_i2t_i.eps)
+        qi = ops.linear(an, self.qkv_i2t.weight, self.qkv_i2t.bias).view(B * L, C)
         km = y_mask.reshape(B, S) if y_mask is not None else None
         yi = ops.mha(qi, kv[:, :C], kv[:, C:], km, B, self.num_heads, self.scale)
         yi = ops.linear(yi.view(B, L, C), self.proj_i2t.weight, self.proj_i2t.bias)
