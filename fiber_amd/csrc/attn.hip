@@ -348,7 +348,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
 
 // ===================================================== backward, pass A: dQ (+ dbias) ==========================
 template <int D, bool WINDOW, int NT = NKT>       // NT: key (query) tiles held per chunk -- 3 for the 40-token text side
-__global__ __launch_bounds__(768) void attn_bwd_dq_kernel(AttnP p) {
+// (WINDOW mode keeps its bias-gradient slice in registers, the 10-slot form 40 score registers per array: at most 8 waves per workgroup so
+//  that the allocator has 256 registers -- the 168 of a 12-wave bound left 24-260 bytes of scratch per lane)
+__global__ __launch_bounds__((WINDOW || NT > 6) ? 512 : 768) void attn_bwd_dq_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = D / 32, DT = D / 16;
   const int nb = WINDOW ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
@@ -706,7 +708,11 @@ int launch_bwd(AttnP& p, float* delta, float* dbias_table, float* dbias_ws, int 
   p.delta = delta;
   const int nb = p.window ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
   {
-    const int nstrips = cdiv(p.Lq, 16), nw = pick_waves(nstrips, p.Lk);
+    const int nstrips = cdiv(p.Lq, 16);
+    int nw = pick_waves(nstrips, p.Lk);
+    launch_geometry(p, p.Lk, nw, true);                  // (the chunking only changes at nw <= 4, the cap below only acts on nw > 8)
+    const bool wide_form = p.window || (!small_chunk(p, p.Lk) && chunk_tiles(p, p.Lk) > 6);
+    if (wide_form && nw > 8) nw = 8;                     // launch bound of those instantiations (strips beyond 8 go to further workgroups)
     int gz = p.G;
     p.groups_per_block = 1;
     p.dbias_part = nullptr;
