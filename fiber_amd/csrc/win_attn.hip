@@ -436,8 +436,10 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
 // ================================================================ backward pass A: dQ + dbias =================
 // MAXC: 16-byte staging chunks per thread; NTC: key/query tiles if known at compile time (9 for 12x12 windows);
 // MTT: tile capacity (10 / 21); BREG: window-invariant bias slice in registers (else LDS look-ups per score)
+// The run-time-tile-count instance (NTC = 0, MAXC = 1: windows of at most 128 tokens, e.g. the 7 x 7 windows of Swin-T) is bounded at 8 waves:
+// under the 10-wave bound's 168 registers it left 92 bytes of scratch per lane.  NTH stays the slot stride of the LDS column-sum slots.
 template <int MAXC, int NTC = 0, int MTT = 10, bool BREG = true>
-__global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP p) {
+__global__ __launch_bounds__(MAXC == 1 ? (NTC ? 640 : 512) : 448) void win_bwd_dq_kernel(WinP p) {
   WIN_DIMS(MTT);
   constexpr int NTH = MAXC == 1 ? 640 : 448;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -473,9 +475,14 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
   // nothing for keeping LDS operands in flight.
   f32x4* slab = reinterpret_cast<f32x4*>(S.a1 + MAXN * RS) + wave * MT * 64 + lane;
   // column-sum slots of this kernel's dQ values (after the bias slab when there is one)
-  f32x4* cs_all = reinterpret_cast<f32x4*>(S.a1 + MAXN * RS) + (BREG ? (blockDim.x >> 6) * MT * 64 : 0);
+  constexpr int NLD = MTT > 10 ? 8 : 0;                   // dbias tiles kept in LDS slots (see below), in front of the column-sum slots
+  f32x4* cs_all = reinterpret_cast<f32x4*>(S.a1 + MAXN * RS) + (BREG ? (blockDim.x >> 6) * MT * 64 : 0) + NLD * NTH;
   if (p.colsum_part) colsum_zero<2, NTH>(cs_all);
-  f32x4 dbacc[MTP];
+  // dbias accumulators: one f32x4 per key tile and lane, summed over the windows of the run.  With 21 tiles (18 x 18 windows) 84 registers
+  // of them left 156 bytes of scratch per lane; the first NLD tiles live in private LDS slots instead (ds_read_b128 + add + ds_write_b128
+  // on the thread's own slot, lane-contiguous), in front of the column-sum slots.
+  f32x4* dbl = cs_all - NLD * NTH + threadIdx.x;
+  f32x4 dbacc[MTP - NLD];
   auto bias_tile = [&](int kt) -> f32x4 {                 // bias / scale (the seed of the q.k accumulator), -inf on padded keys
     if constexpr (BREG) {
       return slab[kt * 64];
@@ -489,7 +496,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
   __syncthreads();
 #pragma unroll
   for (int kt = 0; kt < MT; ++kt) {
-    dbacc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (kt < NLD) dbl[kt * NTH] = f32x4{0.f, 0.f, 0.f, 0.f}; else dbacc[kt < NLD ? 0 : kt - NLD] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (BREG) {
       f32x4 b;
 #pragma unroll
@@ -595,7 +602,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
               if constexpr (BORDER) sv = region_mask(sv, kg[u], qregf, -144.26950408889634f);
               const f32x4 d = exp2x4(sv) * (sdp[u] + dc);   // (-delta as a seed of the dP MFMA would pin four more registers)
               ds[u] = d;
-              dbacc[kt] += d;
+              if (kt < NLD) dbl[kt * NTH] += d; else dbacc[kt < NLD ? 0 : kt - NLD] += d;
             }
           };
           if constexpr (PIPE) {
@@ -642,7 +649,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dq_kernel(WinP 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int j = kt * 16 + gq * 4 + r;
-          if (j < p.N) dst[j] = dbacc[kt][r];
+          if (j < p.N) dst[j] = kt < NLD ? dbl[kt * NTH][r] : dbacc[kt < NLD ? 0 : kt - NLD][r];
         }
   }
   if (p.colsum_part) {
@@ -1299,8 +1306,9 @@ int fiber_win_bwd_launch(const void* qkv, const float* bias_table, const void* o
     if (colsum_ws) return fiber_fold_rows_f32(colsum_ws, dqkv_colsum, gz, 3 * C, st);
     return FIBER_OK;
   }
-  if (big_window(p.N)) hipLaunchKernelGGL((win_bwd_dq_kernel<3, 0, 21, false>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2) + csq, st, p);
-  else if (p.N == 144 && (ntc_mask() & 2)) hipLaunchKernelGGL((win_bwd_dq_kernel<1, 9>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2) + slab + csq, st, p);
+  if (big_window(p.N)) hipLaunchKernelGGL((win_bwd_dq_kernel<3, 0, 21, false>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2) + csq + 8 * 448 * 16, st, p);   // (+ the 8 dbias tiles kept in LDS: 150 KB in all)
+  else if (p.N == 144) hipLaunchKernelGGL((win_bwd_dq_kernel<1, 9>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2) + slab + csq, st, p);   // (FIBER_WIN_NTC bit 1 no longer selects the run-time-count instance here: that one is bounded at 8 waves)
+  else if (nw > 8) return FIBER_EINVAL;                  // (N = ws * ws: no square window has 129..160 tokens other than 12 x 12)
   else hipLaunchKernelGGL((win_bwd_dq_kernel<1, 0>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2) + slab + csq, st, p);
   FIBER_CHECK_LAUNCH();
   if (hipMemsetAsync(dbias_table, 0, (size_t)nb * heads * sizeof(float), st) != hipSuccess) return FIBER_ELAUNCH;
