@@ -24,8 +24,9 @@
 //    two-wave-group schedule as the forward GEMM (gemm.hip): the groups run the K loop half a sub-tile apart so that on every
 //    SIMD one wave feeds the matrix pipe while its partner reads fragments.  A 128x128 / 4-wave instance covers the narrow
 //    weights (stage-0 / stage-1 linears, patch embedding, test configurations);
-//  * the bias gradient: waves of the first K-column tile add their dY fragments up with v_dot2_f32_bf16 against (1, 1) --
-//    two VALU issues per MFMA gap -- so no separate pass ever streams dY for its column sums;
+//  * the bias gradient: in the workgroups of the first K-column tile every wave adds ONE of its dY fragment tiles up with
+//    v_dot2_f32_bf16 against (1, 1) -- four VALU issues per MFMA k-step behind a scalar branch -- so no separate pass ever streams dY
+//    for its column sums;
 //  * DropPath backward (timm 0.4.12, swin_transformer.py:390-391): the branch gradient is s_b dY with a per-sample factor
 //    s_b in {0, 1/keep}.  Instead of a pass that writes s_b dY, the kernel skips the K tiles of dropped samples (row_mask)
 //    and multiplies the result by 1/keep (scale): dW = (1/keep) sum over kept samples of dY^T X.
@@ -153,10 +154,13 @@ __global__ __launch_bounds__(TS * 2) void gemm_tn_kernel(TnArgs a) {
     for (int u = 0; u < TB; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
-  float csa[TA];
-#pragma unroll
-  for (int t = 0; t < TA; ++t) csa[t] = 0.f;
-  const bool do_cs = a.cs != nullptr && tk == 0 && wb == 0;       // wave-uniform
+  // Bias gradient = column sums of dY: in the workgroups of the first K-column tile wave (wa, wb) sums A tile t = wb of its four (two)
+  // (TA == WB), i.e. 4 v_dot2 per MFMA k-step behind a SCALAR branch.  Round 3 had the wb = 0 waves sum all their tiles behind an
+  // `if` the compiler turned into selects: every wave of every workgroup issued 16 v_dot2 + 8 moves / selects per k-step, which cost the
+  // kernel 10-12 % of its rate (1095 TFLOP/s without the code, 980 with it; tools/tn_bias_probe.py).
+  static_assert(TA == WB, "column sums: one A tile per wave");
+  float csa = 0.f;
+  const bool do_cs = a.cs != nullptr && tk == 0;                  // workgroup-uniform
   // K tile kt belongs to sample (m0 + kt*BKM) / rows_per_sample; its MFMAs are skipped when that sample was dropped.  The factors of the
   // next 64 samples are fetched with ONE vector load and kept as a ballot in an SGPR pair: a load in front of every K tile's branch cost
   // the masked form 18 % of its rate (and any vector load inside the loop makes hipcc wait with vmcnt(0), which also drains the LDS-DMA
@@ -198,10 +202,11 @@ __global__ __launch_bounds__(TS * 2) void gemm_tn_kernel(TnArgs a) {
 #pragma unroll
         for (int u = 0; u < TB; ++u)
           acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][t], fb[ks][u], acc[t][u], 0, 0, 0);
-        if (do_cs) {
+        if (do_cs && wb == t) {
+          asm volatile("" : "+v"(csa));                     // (keeps this a branch: no speculation into selects)
 #pragma unroll
           for (int e = 0; e < 8; e += 2)
-            csa[t] = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{fa[ks][t][e], fa[ks][t][e + 1]}, ones, csa[t], false);
+            csa = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{fa[ks][t][e], fa[ks][t][e + 1]}, ones, csa, false);
         }
       }
     __builtin_amdgcn_s_setprio(0);
@@ -275,12 +280,9 @@ __global__ __launch_bounds__(TS * 2) void gemm_tn_kernel(TnArgs a) {
     }
   if (do_cs) {
     float* csp = a.cs + (size_t)s * a.N;
-#pragma unroll
-    for (int t = 0; t < TA; ++t) {
-      const float v = (csa[t] + __shfl_xor(csa[t], 32)) * a.scale;
-      const int n = n0 + wa * WTA + t * 32 + (lane & 31);
-      if (lane < 32 && n < a.N) csp[n] = v;
-    }
+    const float v = (csa + __shfl_xor(csa, 32)) * a.scale;
+    const int n = n0 + wa * WTA + wb * 32 + (lane & 31);
+    if (lane < 32 && n < a.N) csp[n] = v;
   }
 }
 
