@@ -204,6 +204,7 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnP p) {
   const int ntiles = (p.Lk + 15) / 16, nchunk = (ntiles + p.tpc_cap - 1) / p.tpc_cap, tpc = (ntiles + nchunk - 1) / nchunk;
   const float sc2 = p.scale * 1.4426950408889634f;
   const uint32_t thresh = (uint32_t)((double)p.p_drop * 4294967296.0);
+  const uint32_t dseed = p.p_drop > 0.f ? drop_seed32(p.seed + (p.seed_base ? *p.seed_base : 0ull)) : 0u;
   const float inv_keep = 1.f / (1.f - p.p_drop);
   // A key side that fits one chunk (text keys of the i2t cross-attention, text self-attention) is staged ONCE and the workgroup
   // then walks query strips blockIdx.x*nw + wave, + gridDim.x*nw, ... without any further barrier: with one strip per wave the
@@ -287,8 +288,7 @@ __global__ __launch_bounds__(768) void attn_fwd_kernel(AttnP p) {
         float e = kt < tpc ? __builtin_amdgcn_exp2f(s[kt][r] - mnew) : 0.f;
         psum += e;
         if (p.p_drop > 0.f) {
-          const uint64_t idx = (((uint64_t)g * p.H + h) * p.Lq + (qvalid ? i : 0)) * p.Lk + kbase + kt * 16 + gq * 4 + r;
-          e = drop_keep(p.seed + (p.seed_base ? *p.seed_base : 0ull), idx, thresh) ? e * inv_keep : 0.f;
+          e = drop_keep_rk(dseed, (uint32_t)((g * p.H + h) * p.Lq + (qvalid ? i : 0)), (uint32_t)(kbase + kt * 16 + gq * 4 + r), thresh) ? e * inv_keep : 0.f;
         }
         s[kt][r] = e;
       }
@@ -362,6 +362,7 @@ __global__ __launch_bounds__((WINDOW || NT > 6) ? 512 : 768) void attn_bwd_dq_ke
   for (int t = threadIdx.x; t < nb; t += blockDim.x) L.btab[t] = p.bias_table[(size_t)t * p.H + h] * 1.4426950408889634f;   // log2 domain
   const int ntiles = (p.Lk + 15) / 16, nchunk = (ntiles + p.tpc_cap - 1) / p.tpc_cap, tpc = (ntiles + nchunk - 1) / nchunk;
   const uint32_t thresh = (uint32_t)((double)p.p_drop * 4294967296.0);
+  const uint32_t dseed = p.p_drop > 0.f ? drop_seed32(p.seed + (p.seed_base ? *p.seed_base : 0ull)) : 0u;
   const float inv_keep = 1.f / (1.f - p.p_drop);
 
   const float sc2 = p.scale * 1.4426950408889634f;
@@ -447,8 +448,7 @@ __global__ __launch_bounds__((WINDOW || NT > 6) ? 512 : 768) void attn_bwd_dq_ke
                 const float pr = __builtin_amdgcn_exp2f(sv - lse);
                 float dpe = dp[r];
                 if (p.p_drop > 0.f) {
-                  const uint64_t idx = (((uint64_t)g * p.H + h) * p.Lq + (qvalid ? i : 0)) * p.Lk + kbase + jl;
-                  dpe = drop_keep(p.seed + (p.seed_base ? *p.seed_base : 0ull), idx, thresh) ? dpe * inv_keep : 0.f;
+                  dpe = drop_keep_rk(dseed, (uint32_t)((g * p.H + h) * p.Lq + (qvalid ? i : 0)), (uint32_t)(kbase + jl), thresh) ? dpe * inv_keep : 0.f;
                 }
                 const float d = qvalid ? pr * (dpe - dlt) : 0.f;
                 ds[u][r] = d;
@@ -536,6 +536,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnP p) {
   }
   const int ntiles = (p.Lq + 15) / 16, nchunk = (ntiles + p.tpc_cap - 1) / p.tpc_cap, tpc = (ntiles + nchunk - 1) / nchunk;
   const uint32_t thresh = (uint32_t)((double)p.p_drop * 4294967296.0);
+  const uint32_t dseed = p.p_drop > 0.f ? drop_seed32(p.seed + (p.seed_base ? *p.seed_base : 0ull)) : 0u;
   const float inv_keep = 1.f / (1.f - p.p_drop);
   const float sc2 = p.scale * 1.4426950408889634f;
   f32x4 dkacc[DT], dvacc[DT];
@@ -587,8 +588,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnP p) {
               float pr = kvalid ? __builtin_amdgcn_exp2f(sv - L.addmask[il]) : 0.f;
               float dpe = dp[r], prd = pr;
               if (p.p_drop > 0.f) {
-                const uint64_t idx = (((uint64_t)g * p.H + h) * p.Lq + ig) * p.Lk + (kvalid ? j : 0);
-                const bool keep = drop_keep(p.seed + (p.seed_base ? *p.seed_base : 0ull), idx, thresh);
+                const bool keep = drop_keep_rk(dseed, (uint32_t)((g * p.H + h) * p.Lq + ig), (uint32_t)(kvalid ? j : 0), thresh);
                 dpe = keep ? dpe * inv_keep : 0.f;
                 prd = keep ? pr * inv_keep : 0.f;
               }

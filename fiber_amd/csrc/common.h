@@ -152,6 +152,19 @@ __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t 
   return hash_u32(seed, idx) >= thresh;
 }
 
+// Attention-probability dropout: keep decision of score (row, key) -- row = ((sample * heads + head) * Lq + query) -- of a launch keyed by
+// seed32.  Three 32-bit multiplies per score (two when the row or the key term is lane-constant and hoisted) instead of the three 64-bit
+// multiplies of hash_u32 (twelve quarter-rate VALU multiplies): the t2i forward + backward lost 19 % to its dropout (tools/option_ablation.py).
+// Forward and both backward passes call this with the same (seed32, row, key); the element-wise hidden dropout and the MLM collate keep hash_u32.
+__device__ __forceinline__ uint32_t fmix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t drop_seed32(uint64_t seed) { return (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B1u); }
+__device__ __forceinline__ bool drop_keep_rk(uint32_t seed32, uint32_t row, uint32_t key, uint32_t thresh) {
+  return fmix32(seed32 + row * 0x9E3779B1u + key * 0x7FEB352Du) >= thresh;
+}
+
 // One LDS-DMA instruction (64 lanes x 16 B -> 1 KB at `lds_wave_base`, lane-linear) issued from inline asm.  The builtin
 // form tells the compiler that LDS is being written behind the vmcnt counter, and its waitcnt pass then guards LDS reads
 // with vmcnt(0) wherever it loses count (after branches, around other VMEM traffic): in the persistent kernel that put a

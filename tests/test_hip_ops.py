@@ -379,6 +379,31 @@ def test_mha_dropout_adjoint(ops):
     assert rel_l2(acc / n, base) < 0.08
 
 
+def test_mha_dropout_mask_is_the_same_in_all_three_passes(ops):
+    """The keep mask is recomputed from (seed, row, key) in the forward, the dQ pass and the dK/dV pass.  Recover it from a forward with
+    one-hot value rows (o[i, head, j] = P[i, j] * keep[i, j] / (1 - p)), then check dq / dk / dv of a real problem against torch autograd
+    through softmax * mask."""
+    B, heads, L, D, p = 2, 12, 40, 64, 0.1
+    C = heads * D
+    q, k, v = (bf(rnd(B * L, C, seed=s)).requires_grad_(True) for s in (0, 1, 2))
+    from fiber_amd.ops import _MHA
+    eye = torch.zeros(B, L, heads, D, device=q.device)
+    eye[:, torch.arange(L), :, torch.arange(L)] = 1.0                      # value row j = e_j in every head
+    probe = _MHA.apply(q.detach(), k.detach(), bf(eye.view(B * L, C)), None, B, heads, D ** -0.5, p, 4321)
+    keep = (probe.view(B, L, heads, D)[..., :L] != 0).permute(0, 2, 1, 3).float()          # [B, heads, Lq, Lk]
+    assert 0.85 < keep.mean().item() < 0.95
+    o = _MHA.apply(q, k, v, None, B, heads, D ** -0.5, p, 4321)
+    do = bf(rnd(B * L, C, seed=3))
+    o.backward(do)
+    qr, kr, vr = (t.detach().float().view(B, L, heads, D).permute(0, 2, 1, 3).requires_grad_(True) for t in (q, k, v))
+    pr = torch.softmax(qr @ kr.transpose(-1, -2) * D ** -0.5, -1) * keep / (1 - p)
+    oref = (pr @ vr).permute(0, 2, 1, 3).reshape(B * L, C)
+    oref.backward(do.float())
+    assert_close("o", o, oref, 1e-2)
+    for name, got, ref in (("dq", q.grad, qr.grad), ("dk", k.grad, kr.grad), ("dv", v.grad, vr.grad)):
+        assert_close(name, got, ref.permute(0, 2, 1, 3).reshape(B * L, C), 2e-2)
+
+
 def test_roberta_embed(ops):
     from oracle import detgen
     V, C, S, B = 1000, 768, 40, 3
