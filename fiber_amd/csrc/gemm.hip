@@ -1136,6 +1136,8 @@ __global__ __launch_bounds__(512) void gemm_nt_q8_kernel(GemmArgs a) {
 // Variants the v4 (wave-private epilogue) persistent kernel serves: those it compiles without scratch.  gelu' * aux WITH column sums
 // and the residual-without-DropPath forms spill 60-120 VGPRs around its longer live ranges and stay on v3; gelu' * aux without
 // column sums (the caller takes the bias gradient from the weight-gradient kernel) is served.
+__device__ float g_gemm_one = 1.0f;        // the scale of the residual-without-DropPath form served by the DropPath instantiation
+
 template <int EPI, bool R, bool RS>
 constexpr bool kV4Ok = (EPI == 0 && (!R || RS)) || (EPI == 1 && !R) || EPI == 2 || (EPI == 3 && RS);
 
@@ -1252,6 +1254,14 @@ extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bia
   else if (mode == 1 && residual) { if (rowscale) FIBER_LAUNCH_EPI(1, true, true); else FIBER_LAUNCH_EPI(1, true, false); }
   else if (mode == 1) { if (rowscale) FIBER_LAUNCH_EPI(1, false, true); else FIBER_LAUNCH_EPI(1, false, false); }
   else if (residual && rowscale) FIBER_LAUNCH_EPI(0, true, true);
+  else if (residual && shape == 0 && persist && persist_env == 1 && q8_env) {
+    // residual without DropPath (text-layer output projections, blocks with drop_path = 0) on the large-shape path: the q8 instantiation
+    // for it spills 120 bytes per lane, the DropPath one does not -- run that one with a one-element scale of 1.0f (x * 1.0f is exact)
+    static const float* one = [] { float* p = nullptr; hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_gemm_one)); return (const float*)p; }();
+    if (one == nullptr) return FIBER_ELAUNCH;
+    a.rowscale = one; a.rows_per_sample = a.M;
+    FIBER_LAUNCH_EPI(0, true, true);
+  }
   else if (residual) FIBER_LAUNCH_EPI(0, true, false);
   else if (rowscale) FIBER_LAUNCH_EPI(0, false, true);
   else FIBER_LAUNCH_EPI(0, false, false);
