@@ -34,8 +34,9 @@ def _cache_put(key, stamp, value, w):
     _wcache[key] = (stamp, value, weakref.ref(w, lambda _r, k=key: _wcache.pop(k, None)))
 # (dY.W2^T)*gelu'(H) + fc1 bias gradient as ONE hand-written GEMM instead of library GEMM + gelu_bwd_colsum.  Measured at 512
 # images (tools/op_bench.py 512 mlpbwd, persistent 256x256 kernel + select-free gelu', library dgrad in NT form): 3866 vs 4294 us
-# at C=128, 2084 vs 2369 at C=256, 1284 vs 1394 at C=512, 899 vs 859 at C=1024 -> on below C = 1024 ("auto"; an earlier build of
-# the GEMM lost at C <= 256); FIBER_FUSED_MLP_BWD=0 / 1 forces it off / on everywhere.
+# at C=128, 2084 vs 2369 at C=256, 1284 vs 1394 at C=512, 899 vs 859 at C=1024 in round 2 (hence "auto" = below C = 1024 then).  Round 4:
+# with both wave groups of the q8 kernel in the epilogue together the gelu' form gained 5-12 %, and the whole step is 0.8 ms faster with
+# stage 3 fused as well (275.1 / 275.6 -> 274.5 / 274.7 ms, same box) -> "auto" = everywhere; FIBER_FUSED_MLP_BWD=0 / 1 forces it off / on.
 _FUSED_MLP_BWD = os.environ.get("FIBER_FUSED_MLP_BWD", "auto")
 
 
@@ -584,7 +585,7 @@ class _MLP(torch.autograd.Function):
         dy2 = _c(dy).view(-1, w2.shape[0])
         db2 = None
         C, C4 = dy2.shape[1], h.shape[1]
-        fused = C % 64 == 0 and C4 % 8 == 0 and (_FUSED_MLP_BWD == "1" or (_FUSED_MLP_BWD == "auto" and C < 1024))
+        fused = C % 64 == 0 and C4 % 8 == 0 and _FUSED_MLP_BWD != "0"
         fold = fused and dy2.shape[1] % 8 == 0 and droppath_foldable(dy2.shape[0], rowscale, ctx.rs_value)
         rs_arg, rps, mask, scale = None, 0, None, 1.0
         if fold:                                       # DropPath factor rides in the gelu' GEMM epilogue and the wgrad kernel
@@ -600,7 +601,7 @@ class _MLP(torch.autograd.Function):
         if fused:
             dh, _ = gemm_nt(dy2, bf16_weight_t(w2), None, None, 2, False, rs_arg, rps, aux=h)
             db1 = None
-        else:                                         # C = 1024, or shapes the DMA kernel does not cover (e.g. Swin-T C=96)
+        else:                                         # shapes the DMA kernel does not cover (e.g. Swin-T C=96), or FIBER_FUSED_MLP_BWD=0
             dh, db1 = gelu_bwd_colsum(_dgrad(dy2, w2), h)
         if db2 is None:
             dw2, db2 = wgrad(dy2, g, want_bias=True, row_mask=mask, scale=scale)
