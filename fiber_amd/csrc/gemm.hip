@@ -949,22 +949,30 @@ __global__ __launch_bounds__(512) void gemm_nt_q8_kernel(GemmArgs a) {
   // bias of column block j in accumulator layout (element q*4+e <-> column j*32 + q*8 + 4*(lane>>5) + e): scalar loads, one select each
   // N need only be a multiple of 64 (a wave's 64 columns are then all inside or all outside): the waves of the last tile column
   // whose columns lie past N run the K loop on clamped W rows and store nothing (Swin stage 0: qkv, N = 384 = 1.5 tiles)
-  auto seed_of = [&](int n0w, int j) {
-    f32x16 sd;
-    if (EPI != 2 && a.bias && n0w < a.N) {
+  // Two steps: the scalar loads are REQUESTED in the load half of the phase, the selects that consume them sit behind the phase's barrier
+  // (bar_load's s_waitcnt lgkmcnt(0) then finds them landed) -- requested and consumed back to back, each seed exposed a scalar-load
+  // latency of ~350 cycles, four times per tile: a bias cost the plain GEMM 6 % (tools/option_ablation.py).
+  struct SeedRaw { float v[32]; bool on; };
+  auto seed_raw = [&](int n0w, int j) {
+    SeedRaw r;
+    r.on = EPI != 2 && a.bias && n0w < a.N;
+    if (r.on) {
       typedef __attribute__((address_space(4))) const float cfloat;
       cfloat* bp = (cfloat*)(uintptr_t)(a.bias + n0w + j * 32);
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float lo = bp[q * 8 + e], hi = bp[q * 8 + 4 + e];
-          sd[q * 4 + e] = fk ? hi : lo;
-        }
+      for (int i = 0; i < 32; ++i) r.v[i] = bp[i];
     } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sd[r] = 0.f;
+      for (int i = 0; i < 32; ++i) r.v[i] = 0.f;
     }
+    return r;
+  };
+  auto seed_sel = [&](const SeedRaw& r) {
+    f32x16 sd;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sd[q * 4 + e] = fk ? r.v[q * 8 + 4 + e] : r.v[q * 8 + e];
     return sd;
   };
   auto mma = [&](int h, int j) {
@@ -1047,10 +1055,10 @@ __global__ __launch_bounds__(512) void gemm_nt_q8_kernel(GemmArgs a) {
       stageW(1);
       mark(0);
       if (kt == 0) {
-        const f32x16 sd = seed_of(n0w, 0);
+        const SeedRaw raw = seed_raw(n0w, 0);
         bar_load(false);
         mark(1);
-        mma_seeded(0, 0, sd);
+        mma_seeded(0, 0, seed_sel(raw));
       } else {
         bar_load(false);
         mark(1);
@@ -1065,10 +1073,10 @@ __global__ __launch_bounds__(512) void gemm_nt_q8_kernel(GemmArgs a) {
       advance();
       mark(4);
       if (kt == 0) {
-        const f32x16 sd = seed_of(n0w, 1);
+        const SeedRaw raw = seed_raw(n0w, 1);
         bar_load(true);
         mark(5);
-        mma_seeded(0, 1, sd);
+        mma_seeded(0, 1, seed_sel(raw));
       } else {
         bar_load(true);
         mark(5);
@@ -1082,10 +1090,10 @@ __global__ __launch_bounds__(512) void gemm_nt_q8_kernel(GemmArgs a) {
       stageA(0);
       mark(8);
       if (kt == 0) {
-        const f32x16 sd = seed_of(n0w, 1);
+        const SeedRaw raw = seed_raw(n0w, 1);
         bar_load(false);
         mark(9);
-        mma_seeded(1, 1, sd);
+        mma_seeded(1, 1, seed_sel(raw));
       } else {
         bar_load(false);
         mark(9);
@@ -1098,10 +1106,10 @@ __global__ __launch_bounds__(512) void gemm_nt_q8_kernel(GemmArgs a) {
       stageW(0);
       mark(12);
       if (kt == 0) {
-        const f32x16 sd = seed_of(n0w, 0);
+        const SeedRaw raw = seed_raw(n0w, 0);
         bar_load(true);
         mark(13);
-        mma_seeded(1, 0, sd);
+        mma_seeded(1, 0, seed_sel(raw));
       } else {
         bar_load(true);
         mark(13);
