@@ -38,6 +38,7 @@ def _cache_put(key, stamp, value, w):
 # with both wave groups of the q8 kernel in the epilogue together the gelu' form gained 5-12 %, and the whole step is 0.8 ms faster with
 # stage 3 fused as well (275.1 / 275.6 -> 274.5 / 274.7 ms, same box) -> "auto" = everywhere; FIBER_FUSED_MLP_BWD=0 / 1 forces it off / on.
 _FUSED_MLP_BWD = os.environ.get("FIBER_FUSED_MLP_BWD", "auto")
+_WIN_COLSUM = os.environ.get("FIBER_WIN_COLSUM", "0") == "1"     # dqkv column sums inside the window backward (see _WindowAttn.backward)
 
 
 _gen = [0]
@@ -783,8 +784,11 @@ class _WindowAttn(torch.autograd.Function):
         delta = torch.empty((rows, heads), dtype=torch.float32, device=do.device)
         nz = lib.plain("fiber_window_attn_bwd_slices", rows // N, heads)
         part = torch.empty(nz * heads * N * N, dtype=torch.float32, device=do.device)
-        # column sums of dqkv (= bias gradient of the qkv linear) come out of the same two passes
-        cs_rows = lib.plain("fiber_window_attn_colsum_rows", rows // N, heads, ws)
+        # Column sums of dqkv (= bias gradient of the qkv linear) CAN come out of the same passes (round 2: -5 ms per step against a pass of
+        # their own over dqkv).  Round 4: they cost the window backward 6-12 % (tools/win_colsum_probe.py: stage 2 780 -> 730 us, stage 0
+        # 2950 -> 2610), while the weight-gradient kernel of the qkv linear now takes its bias sums for ~1 % -- so by default the qkv linear's
+        # backward asks that kernel (no offer is made); FIBER_WIN_COLSUM=1 restores the in-kernel sums.
+        cs_rows = lib.plain("fiber_window_attn_colsum_rows", rows // N, heads, ws) if _WIN_COLSUM else 0
         csum = torch.empty(3 * C, dtype=torch.float32, device=do.device) if cs_rows else None
         cs_ws = torch.empty(cs_rows * 3 * C, dtype=torch.float32, device=do.device) if cs_rows else None
         lib.call("fiber_window_attn_bwd_bf16", lib.ptr(qkv), lib.ptr(bias_table), lib.ptr(o), lib.ptr(do), lib.ptr(lse), lib.ptr(dqkv),

@@ -184,26 +184,34 @@ def test_window_attention(ops, B, H, W, heads, ws, shift):
     oref.backward(do.float())
     assert_close("dqkv", qkv.grad, qr.grad, 1e-2)
     assert_close("dbias_table", table.grad, tr.grad, 1e-2)
-    # the backward passes also offer the column sums of dqkv (the qkv bias gradient) to the next linear backward; an offer
-    # nobody took does not outlive its autograd pass
+    # with FIBER_WIN_COLSUM=1 (round 4: off by default, the qkv linear's weight-gradient kernel takes the sums) the backward passes also
+    # offer the column sums of dqkv (the qkv bias gradient) to the next linear backward; an offer nobody took does not outlive its
+    # autograd pass.  By default no offer is made.
     from fiber_amd import ops as ops_mod
     assert getattr(ops_mod._hint_tls, "slot", None) is None
-    seen = []
-    real_offer = ops_mod._offer_colsum
-    ops_mod._offer_colsum = lambda t, sums: (seen.append((tuple(t.shape), sums)), real_offer(t, sums))[1]
-    try:
-        qkv.grad = None
-        ops.window_attention(qkv, table, B, H, W, heads, ws, shift).backward(do)
-    finally:
-        ops_mod._offer_colsum = real_offer
-    assert getattr(ops_mod._hint_tls, "slot", None) is None and len(seen) == 1 and seen[0][0] == (B * H * W, 3 * C)
-    assert_close("colsum(dqkv)", seen[0][1], qr.grad.reshape(-1, 3 * C).sum(0), 1e-2)
+    real_offer, was = ops_mod._offer_colsum, ops_mod._WIN_COLSUM
+    for mode in (False, True):
+        seen = []
+        ops_mod._offer_colsum = lambda t, sums: (seen.append((tuple(t.shape), sums)), real_offer(t, sums))[1]
+        ops_mod._WIN_COLSUM = mode
+        try:
+            qkv.grad = None
+            ops.window_attention(qkv, table, B, H, W, heads, ws, shift).backward(do)
+        finally:
+            ops_mod._offer_colsum, ops_mod._WIN_COLSUM = real_offer, was
+        assert getattr(ops_mod._hint_tls, "slot", None) is None
+        assert_close("dqkv", qkv.grad, qr.grad, 1e-2)
+        if mode:
+            assert len(seen) == 1 and seen[0][0] == (B * H * W, 3 * C)
+            assert_close("colsum(dqkv)", seen[0][1], qr.grad.reshape(-1, 3 * C).sum(0), 1e-2)
+        else:
+            assert not seen
 
 
 def test_window_attention_qkv_bias_grad_handover(ops):
-    """linear -> window attention: the qkv bias gradient comes from the attention backward's fused column sums (no colsum
-    launch), also with the head-major layout, and equals the column sums of the dqkv it describes; an unrelated linear
-    backward in between clears the hand-over slot instead of consuming it."""
+    """linear -> window attention: the qkv bias gradient comes from the weight-gradient kernel's column sums (default) or, with
+    FIBER_WIN_COLSUM=1, from the attention backward's fused column sums -- never from a colsum launch of its own --, also with the
+    head-major layout, and equals the column sums of the dqkv it describes; nothing is left in the hand-over slot."""
     from fiber_amd import lib as lib_mod, ops as ops_mod
     B, H, W, heads, ws, shift = 2, 24, 24, 4, 12, 6
     C = heads * 32
@@ -214,7 +222,10 @@ def test_window_attention_qkv_bias_grad_handover(ops):
     do = bf(rnd(B, H * W, C, seed=5))
     real_call, launched = lib_mod.call, []
     lib_mod.call = lambda name, *a: (launched.append(name), real_call(name, *a))[1]
+    was = ops_mod._WIN_COLSUM
     try:
+      for mode in (False, True):
+        ops_mod._WIN_COLSUM = mode
         for hm in (False, True):
             b.grad = None
             launched.clear()
@@ -228,6 +239,7 @@ def test_window_attention_qkv_bias_grad_handover(ops):
             assert_close("db", b.grad, ref, 1e-2)
     finally:
         lib_mod.call = real_call
+        ops_mod._WIN_COLSUM = was
     assert getattr(ops_mod._hint_tls, "slot", None) is None
 
 
