@@ -139,13 +139,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ xv
   }
 }
 
-// dx = rstd * (dy*g - mean_c(dy*g) - xhat * mean_c(dy*g*xhat)); one fp32 partial row of dgamma/dbeta per wave.
+// dx = rstd * (dy*g - mean_c(dy*g) - xhat * mean_c(dy*g*xhat)); one fp32 partial row of dgamma/dbeta per workgroup.
 template <int LPR, int NV, bool MERGE, bool X32, int U>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy, const void* __restrict__ xv,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const bf16* __restrict__ dres,
                                                      bf16* __restrict__ dx,
-                                                     float* __restrict__ part /*[grid*4 waves][2][C]*/, int rows, int C,
+                                                     float* __restrict__ part /*[grid][2][C]*/, int rows, int C,
                                                      MergeMap mm, float* __restrict__ zero_g, float* __restrict__ zero_b) {
   constexpr int RPW = 64 / LPR;
   // the fold kernel that follows accumulates into dgamma / dbeta with atomics: they are zeroed here (the fold runs after this
@@ -248,19 +248,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dy
     for (int e = 0; e < 8; ++e)
 #pragma unroll
       for (int o = 32; o >= LPR; o >>= 1) { ag[i][e] += __shfl_xor(ag[i][e], o); ab[i][e] += __shfl_xor(ab[i][e], o); }
-  float* my = part + (size_t)(blockIdx.x * 4 + wave) * 2 * C;
-  if (sub == 0) {
+  // ... and the four waves of the workgroup through LDS: ONE partial row per workgroup (round 4: the fold kernel read four times the rows,
+  // 16 MB per LayerNorm backward at C = 512, 82 launches of 13.5 us per step).  The same lanes own the same columns in every wave, so the
+  // waves add in turn behind barriers (no atomics, fixed order).
+  __shared__ float red[2 * LPR * NV * 8];
+  constexpr int CP = LPR * NV * 8;                       // >= C
+#pragma unroll 1
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w && sub == 0) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int vi = gl + i * LPR;
-      if (vi < nvec)
+      for (int i = 0; i < NV; ++i) {
+        const int vi = gl + i * LPR;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          my[vi * 8 + e] = ag[i][e];
-          my[C + vi * 8 + e] = ab[i][e];
+          if (w == 0) { red[vi * 8 + e] = ag[i][e]; red[CP + vi * 8 + e] = ab[i][e]; }
+          else { red[vi * 8 + e] += ag[i][e]; red[CP + vi * 8 + e] += ab[i][e]; }
         }
+      }
     }
+    __syncthreads();
   }
+  float* my = part + (size_t)blockIdx.x * 2 * C;
+  for (int c = threadIdx.x; c < C; c += 256) { my[c] = red[c]; my[C + c] = red[CP + c]; }
 }
 
 // fold the per-wave partial rows: block = 64 columns x 4 row lanes (coalesced along columns); the row range is split
@@ -331,7 +340,7 @@ int launch_bwd(const bf16* dy, const void* x, const float* g, const float* mean,
   LN_DISPATCH(BWD, LN_UB, 1, dy, x, g, mean, rstd, dres, dx, ws, rows, C, mm, dgamma, dbeta);
 #undef BWD
   FIBER_CHECK_LAUNCH();
-  const int nrows = grid * 4, ysplit = nrows >= 64 ? 32 : 1;
+  const int nrows = grid, ysplit = nrows >= 64 ? 16 : 1;          // one partial row per workgroup
   hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * C, 64), ysplit), dim3(256), 0, st, ws, dgamma, dbeta, nrows, C);
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
