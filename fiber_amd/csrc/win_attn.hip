@@ -1154,27 +1154,49 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
   }
 }
 
-// dtable[rel_index(i,j), h] += sum_z part[z, h, i, j]
-__global__ __launch_bounds__(512) void win_dbias_scatter_kernel(const float* __restrict__ part, float* __restrict__ dtable,
-                                                                int nz, int H, int ws) {
-  const int i = blockIdx.x, h = blockIdx.y, N = ws * ws, W2 = 2 * ws - 1;
-  const int pri = i / ws, pci = i - pri * ws;
-  // blockDim = groups * N (N <= 512): group g takes the z slices g, g + groups, ...; four independent partial sums keep four loads in
-  // flight per thread (was: 256 threads, one j each -- 112 idle at N = 144 -- and one dependent chain over z)
-  const int groups = blockDim.x >= (unsigned)N ? blockDim.x / N : 1, grp = blockDim.x >= (unsigned)N ? threadIdx.x / N : 0;
-  if (grp >= groups) return;
-  const size_t zs = (size_t)H * N * N;
-  for (int j = blockDim.x >= (unsigned)N ? threadIdx.x - grp * N : threadIdx.x; j < N; j += blockDim.x >= (unsigned)N ? N : blockDim.x) {
-    const float* src = part + ((size_t)h * N + i) * N + j;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int z = grp;
-    for (; z + 3 * groups < nz; z += 4 * groups) {
-      s0 += src[(size_t)z * zs]; s1 += src[(size_t)(z + groups) * zs]; s2 += src[(size_t)(z + 2 * groups) * zs]; s3 += src[(size_t)(z + 3 * groups) * zs];
-    }
-    for (; z < nz; z += groups) s0 += src[(size_t)z * zs];
-    const int prj = j / ws, pcj = j - prj * ws;
-    atomicAdd(dtable + (size_t)((pri - prj + ws - 1) * W2 + (pci - pcj + ws - 1)) * H + h, (s0 + s1) + (s2 + s3));
+// dtable[rel_index(i, j), h] = sum_z part[z, h, i, j], without atomics (round 4; the one-kernel form with one global atomic per (i, j)
+// was bound by them: 51 us for 42 MB at stage 2, 1.2 ms per step -- and summed in a run-dependent order):
+//   fold:   part[0, h, i, j] = sum_z part[z, h, i, j]      one thread per float4 of the [H, N, N] slice, coalesced over z slices
+//   gather: dtable[e, h] = sum over the (ws - |dr|)(ws - |dc|) pairs (i, j) with relative offset e = (dr, dc), read from slice 0
+__global__ __launch_bounds__(256) void win_dbias_fold_kernel(float* __restrict__ part, int nz, long n4) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n4) return;
+  float4* p = reinterpret_cast<float4*>(part) + t;
+  float4 a = p[0], b = {0.f, 0.f, 0.f, 0.f}, c = b, d = b;
+  int z = 1;
+  for (; z + 3 < nz; z += 4) {
+    const float4 v0 = p[(long)z * n4], v1 = p[(long)(z + 1) * n4], v2 = p[(long)(z + 2) * n4], v3 = p[(long)(z + 3) * n4];
+    a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;  b.x += v1.x; b.y += v1.y; b.z += v1.z; b.w += v1.w;
+    c.x += v2.x; c.y += v2.y; c.z += v2.z; c.w += v2.w;  d.x += v3.x; d.y += v3.y; d.z += v3.z; d.w += v3.w;
   }
+  for (; z < nz; ++z) { const float4 v = p[(long)z * n4]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+  p[0] = float4{(a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w)};
+}
+__global__ __launch_bounds__(256) void win_dbias_fold1_kernel(float* __restrict__ part, int nz, long n) {   // slices that are not float4-sized (odd windows)
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  float a = part[t], b = 0.f;
+  int z = 1;
+  for (; z + 1 < nz; z += 2) { a += part[(long)z * n + t]; b += part[(long)(z + 1) * n + t]; }
+  if (z < nz) a += part[(long)z * n + t];
+  part[t] = a + b;
+}
+__global__ __launch_bounds__(256) void win_dbias_gather_kernel(const float* __restrict__ dense, float* __restrict__ dtable, int H, int ws) {
+  const int W2 = 2 * ws - 1, N = ws * ws;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= W2 * W2 * H) return;
+  const int h = t % H, e = t / H;
+  const int dr = e / W2 - (ws - 1), dc = e % W2 - (ws - 1);               // dr = row(i) - row(j), dc = col(i) - col(j)
+  const int r0 = dr > 0 ? dr : 0, r1 = dr < 0 ? ws + dr : ws, c0 = dc > 0 ? dc : 0, c1 = dc < 0 ? ws + dc : ws;
+  const float* src = dense + (size_t)h * N * N;
+  float s0 = 0.f, s1 = 0.f;
+  for (int pri = r0; pri < r1; ++pri) {
+    const float* row = src + (size_t)(pri * ws) * N + (pri - dr) * ws - dc;      // + pci * N + pci  ->  element (i = pri*ws + pci, j = (pri-dr)*ws + pci - dc)
+    int pci = c0;
+    for (; pci + 1 < c1; pci += 2) { s0 += row[(size_t)pci * N + pci]; s1 += row[(size_t)(pci + 1) * N + pci + 1]; }
+    if (pci < c1) s0 += row[(size_t)pci * N + pci];
+  }
+  dtable[(size_t)e * H + h] = s0 + s1;
 }
 
 bool attrs_set = false;
@@ -1227,7 +1249,17 @@ int blocks_for(int G, int heads) {
 }
 
 bool big_window(int N) { return N > 160; }
-int scatter_threads(int N) { (void)N; return 256; }   // (z-split groups of N threads measured 2.6 x slower: the kernel is bound by its global atomics, one per (i, j, group))
+// bias-table gradient from the per-workgroup-run partials [nz, H, N, N] (slice 0 is overwritten with the sum)
+int dbias_fold_gather(float* part, float* dtable, int nz, int H, int ws, hipStream_t st) {
+  const int N = ws * ws, W2 = 2 * ws - 1;
+  const long n = (long)H * N * N, n4 = n / 4;
+  if (n % 4 == 0) hipLaunchKernelGGL(win_dbias_fold_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, nz, n4);
+  else hipLaunchKernelGGL(win_dbias_fold1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, nz, n);   // (odd windows: slices are not float4-sized)
+  FIBER_CHECK_LAUNCH();
+  hipLaunchKernelGGL(win_dbias_gather_kernel, dim3((unsigned)((W2 * W2 * H + 255) / 256)), dim3(256), 0, st, part, dtable, H, ws);
+  FIBER_CHECK_LAUNCH();
+  return FIBER_OK;
+}
 
 WinP make(const void* qkv, int B, int Hres, int Wres, int C, int heads, int ws, int shift, int hmajor) {
   WinP p{};
@@ -1300,9 +1332,7 @@ int fiber_win_bwd_launch(const void* qkv, const float* bias_table, const void* o
     if (shift > 0) hipLaunchKernelGGL(win_bwd_fused_kernel<true>, dim3(gz, heads, 1), dim3(576), bytes, st, p);
     else hipLaunchKernelGGL(win_bwd_fused_kernel<false>, dim3(gz, heads, 1), dim3(576), bytes, st, p);
     FIBER_CHECK_LAUNCH();
-    if (hipMemsetAsync(dbias_table, 0, (size_t)nb * heads * sizeof(float), st) != hipSuccess) return FIBER_ELAUNCH;
-    hipLaunchKernelGGL(win_dbias_scatter_kernel, dim3(p.N, heads), dim3(scatter_threads(p.N)), 0, st, dbias_ws, dbias_table, gz, heads, ws);
-    FIBER_CHECK_LAUNCH();
+    if (int rc = dbias_fold_gather(dbias_ws, dbias_table, gz, heads, ws, st)) return rc;
     if (colsum_ws) return fiber_fold_rows_f32(colsum_ws, dqkv_colsum, gz, 3 * C, st);
     return FIBER_OK;
   }
@@ -1311,9 +1341,7 @@ int fiber_win_bwd_launch(const void* qkv, const float* bias_table, const void* o
   else if (nw > 8) return FIBER_EINVAL;                  // (N = ws * ws: no square window has 129..160 tokens other than 12 x 12)
   else hipLaunchKernelGGL((win_bwd_dq_kernel<1, 0>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2) + slab + csq, st, p);
   FIBER_CHECK_LAUNCH();
-  if (hipMemsetAsync(dbias_table, 0, (size_t)nb * heads * sizeof(float), st) != hipSuccess) return FIBER_ELAUNCH;
-  hipLaunchKernelGGL(win_dbias_scatter_kernel, dim3(p.N, heads), dim3(scatter_threads(p.N)), 0, st, dbias_ws, dbias_table, gz, heads, ws);
-  FIBER_CHECK_LAUNCH();
+  if (int rc = dbias_fold_gather(dbias_ws, dbias_table, gz, heads, ws, st)) return rc;
   if (big_window(p.N)) hipLaunchKernelGGL((win_bwd_dkv_kernel<3, 0, 21, false>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2) + cskv, st, p);
   else if (p.N == 144 && (ntc_mask() & 4)) hipLaunchKernelGGL((win_bwd_dkv_kernel<1, 9>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2) + cskv, st, p);
   else hipLaunchKernelGGL((win_bwd_dkv_kernel<1, 0>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2) + cskv, st, p);
