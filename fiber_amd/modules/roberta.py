@@ -126,10 +126,23 @@ class RobertaOutput(nn.Module):
             h = ops.stream_add(input_tensor, ops.linear(hidden_states, self.dense.weight, self.dense.bias), p_a=self.dropout.p)
         else:
             h = ops.linear(hidden_states, self.dense.weight, self.dense.bias, residual=input_tensor)
+        return self._norm(h, last_norm)
+
+    def _norm(self, h, last_norm):
         if not last_norm:
             return h
         # post-LN: this output is the next layer's residual -> it keeps an fp32 copy in fp32-stream mode
         return ops.layernorm(h, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps, want_f32=ops.residual_fp32())
+
+    def ffn(self, intermediate, input_tensor, last_norm=True):
+        """intermediate + output of one layer as ONE autograd node for fc1 -> GELU -> fc2 (ops.mlp): the backward is the fused
+        (dY.W2^T) * gelu'(H) GEMM instead of a dX GEMM + a gelu' pass over [B*S, 3072] (roberta.py:398-423; same forward kernels)."""
+        wi, bi = intermediate.dense.weight, intermediate.dense.bias
+        if self.training and self.dropout.p > 0:
+            h = ops.stream_add(input_tensor, ops.mlp(input_tensor, wi, bi, self.dense.weight, self.dense.bias), p_a=self.dropout.p)
+        else:
+            h = ops.mlp(input_tensor, wi, bi, self.dense.weight, self.dense.bias, residual=input_tensor)
+        return self._norm(h, last_norm)
 
 
 class RobertaLayer(nn.Module):
@@ -155,7 +168,7 @@ class RobertaLayer(nn.Module):
             # hidden + (a + alpha_t2i * dropout(c)) in one pass (roberta.py:474-485: RobertaSelfOutput's dropout, the gate, the residual)
             a = ops.stream_add(hidden_states, a, b=c, alpha=self.alpha_t2i, p_b=ca.output.dropout.p, training=self.training)
         a = ops.layernorm(a, ln.weight, ln.bias, ln.eps, want_f32=ops.residual_fp32())
-        return (self.output(self.intermediate(a), a, last_norm=last_norm),)
+        return (self.output.ffn(self.intermediate, a, last_norm=last_norm),)
 
 
 class RobertaEncoder(nn.Module):
