@@ -507,7 +507,8 @@ __global__ __launch_bounds__((WINDOW || NT > 6) ? 512 : 768) void attn_bwd_dq_ke
 
 // ===================================================== backward, pass B: dK, dV ================================
 template <int D, bool WINDOW, int NT = NKT>       // NT: key (query) tiles held per chunk -- 3 for the 40-token text side
-__global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnP p) {
+// (the 10-slot form at D = 64 carries 8 more registers for the next strip's K / V: bounded at 8 waves so that it does not spill)
+__global__ __launch_bounds__((!WINDOW && NT > 6 && D == 64) ? 512 : 768) void attn_bwd_dkv_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = D / 32, DT = D / 16;
   const int nb = WINDOW ? (2 * p.ws - 1) * (2 * p.ws - 1) : 0;
@@ -516,35 +517,13 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnP p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int gq = lane >> 4, lq = lane & 15;
   const int h = head_of<D, WINDOW>(blockIdx.y, p.H), g = blockIdx.z;
-  const int strip = blockIdx.x * nw + wave;
-  const int j = strip * 16 + lq;                      // this lane's key
-  const bool kvalid = j < p.Lk;
-  const int joff = WINDOW ? win_off(p, kvalid ? j : 0) - win_const(p) : 0;    // this lane's key
-  int ktok = 0, kreg = 0;
-  float kadd = 0.f;
-  {
-    const int jc = kvalid ? j : p.Lk - 1;
-    if (WINDOW) window_tok(p, g, jc, ktok, kreg);
-    else { ktok = g * p.Lk + jc; if (p.kmask) kadd = p.kmask[(size_t)g * p.Lk + jc] * 1.4426950408889634f; }
-  }
-  for (int t = threadIdx.x; t < nb; t += blockDim.x) L.btab[t] = p.bias_table[(size_t)t * p.H + h] * 1.4426950408889634f;   // log2 domain
-  bf16x8 kf[KS], vf[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    kf[ks] = *reinterpret_cast<const bf16x8*>(p.k + (size_t)ktok * p.ldk + h * D + ks * 32 + gq * 8);
-    vf[ks] = *reinterpret_cast<const bf16x8*>(p.v + (size_t)ktok * p.ldv + h * D + ks * 32 + gq * 8);
-  }
   const int ntiles = (p.Lq + 15) / 16, nchunk = (ntiles + p.tpc_cap - 1) / p.tpc_cap, tpc = (ntiles + nchunk - 1) / nchunk;
-  const uint32_t thresh = (uint32_t)((double)p.p_drop * 4294967296.0);
-  const uint32_t dseed = p.p_drop > 0.f ? drop_seed32(p.seed + (p.seed_base ? *p.seed_base : 0ull)) : 0u;
-  const float inv_keep = 1.f / (1.f - p.p_drop);
-  const float sc2 = p.scale * 1.4426950408889634f;
-  f32x4 dkacc[DT], dvacc[DT];
-#pragma unroll
-  for (int dt = 0; dt < DT; ++dt) { dkacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-
-  for (int c = 0; c < nchunk; ++c) {
-    const int qbase = c * tpc * 16;
+  const int nstrips = (p.Lk + 15) / 16;
+  // `once`: the query side fits ONE staged chunk (the 40-token text side of t2i / text self-attention): it is staged once per workgroup and
+  // the waves walk key strips blockIdx.x*nw + wave, + gridDim.x*nw, ... without any further barrier (round 4; one strip per wave and a
+  // re-staged chunk per 9 strips left this pass all set-up: three barriers and 10 KB of staging for ~20 MFMAs per wave).
+  const bool once = !WINDOW && nchunk == 1;
+  auto stage_chunk = [&](int qbase) {
     __syncthreads();
     fill_rowmeta(p, L, g, qbase, tpc * 16, p.Lq, false);
     __syncthreads();
@@ -558,65 +537,118 @@ __global__ __launch_bounds__(768) void attn_bwd_dkv_kernel(AttnP p) {
       L.aux[r] = ok ? p.delta[(size_t)L.rowmap[r] * p.H + h] : 0.f;
     }
     __syncthreads();
+  };
+  for (int t = threadIdx.x; t < nb; t += blockDim.x) L.btab[t] = p.bias_table[(size_t)t * p.H + h] * 1.4426950408889634f;   // log2 domain
+  const uint32_t thresh = (uint32_t)((double)p.p_drop * 4294967296.0);
+  const uint32_t dseed = p.p_drop > 0.f ? drop_seed32(p.seed + (p.seed_base ? *p.seed_base : 0ull)) : 0u;
+  const float inv_keep = 1.f / (1.f - p.p_drop);
+  const float sc2 = p.scale * 1.4426950408889634f;
+  // K / V rows of this lane's key in strip `st` (the next strip's are requested before the current one is computed: `once` mode)
+  auto load_kv = [&](int st, bf16x8* kfo, bf16x8* vfo) {
+    if (WINDOW) return;
+    const int jn = min(st * 16 + lq, p.Lk - 1);
+    const size_t tok = (size_t)g * p.Lk + jn;
 #pragma unroll
-    for (int t2 = 0; t2 < NT / 2; ++t2) {
-      if (t2 * 2 < tpc) {
-        f32x4 ds[2], pd[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int qt = 2 * t2 + u;
-          ds[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-          pd[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (qt < tpc) {
-            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-              const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + (qt * 16 + lq) * (D + 16) + ks * 32 + gq * 8);
-              const bf16x8 df = *reinterpret_cast<const bf16x8*>(dOs + (qt * 16 + lq) * (D + 16) + ks * 32 + gq * 8);
-              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[ks], a, 0, 0, 0);    // S[query][key]
-              dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf[ks], dp, 0, 0, 0);  // dP[query][key]
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int il = qt * 16 + gq * 4 + r;      // chunk-local query
-              const int ig = min(qbase + il, p.Lq - 1);
-              float sv = a[r] * sc2 + kadd;
-              if (WINDOW) {
-                sv += L.btab[L.woff[il] - joff];
-                if (L.reg[il] != kreg) sv += -144.26950408889634f;
+    for (int ks = 0; ks < KS; ++ks) {
+      kfo[ks] = *reinterpret_cast<const bf16x8*>(p.k + tok * p.ldk + h * D + ks * 32 + gq * 8);
+      vfo[ks] = *reinterpret_cast<const bf16x8*>(p.v + tok * p.ldv + h * D + ks * 32 + gq * 8);
+    }
+  };
+  bf16x8 kfn[KS], vfn[KS];
+  if (once && (int)(blockIdx.x * nw + wave) < nstrips) load_kv(blockIdx.x * nw + wave, kfn, vfn);
+  if (once) stage_chunk(0);
+  for (int strip = blockIdx.x * nw + wave; ; strip += gridDim.x * nw) {
+    if (once && strip >= nstrips) break;
+    const int j = strip * 16 + lq;                      // this lane's key
+    const bool kvalid = j < p.Lk;
+    const int joff = WINDOW ? win_off(p, kvalid ? j : 0) - win_const(p) : 0;    // this lane's key
+    int ktok = 0, kreg = 0;
+    float kadd = 0.f;
+    {
+      const int jc = kvalid ? j : p.Lk - 1;
+      if (WINDOW) window_tok(p, g, jc, ktok, kreg);
+      else { ktok = g * p.Lk + jc; if (p.kmask) kadd = p.kmask[(size_t)g * p.Lk + jc] * 1.4426950408889634f; }
+    }
+    bf16x8 kf[KS], vf[KS];
+    if (once) {
+  #pragma unroll
+      for (int ks = 0; ks < KS; ++ks) { kf[ks] = kfn[ks]; vf[ks] = vfn[ks]; }
+      if (strip + (int)(gridDim.x * nw) < nstrips) load_kv(strip + gridDim.x * nw, kfn, vfn);
+    } else {
+  #pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        kf[ks] = *reinterpret_cast<const bf16x8*>(p.k + (size_t)ktok * p.ldk + h * D + ks * 32 + gq * 8);
+        vf[ks] = *reinterpret_cast<const bf16x8*>(p.v + (size_t)ktok * p.ldv + h * D + ks * 32 + gq * 8);
+      }
+    }
+    f32x4 dkacc[DT], dvacc[DT];
+  #pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { dkacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    for (int c = 0; c < nchunk; ++c) {
+      const int qbase = c * tpc * 16;
+      if (!once) stage_chunk(qbase);
+  #pragma unroll
+      for (int t2 = 0; t2 < NT / 2; ++t2) {
+        if (t2 * 2 < tpc) {
+          f32x4 ds[2], pd[2];
+  #pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int qt = 2 * t2 + u;
+            ds[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            pd[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (qt < tpc) {
+              f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
+              for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + (qt * 16 + lq) * (D + 16) + ks * 32 + gq * 8);
+                const bf16x8 df = *reinterpret_cast<const bf16x8*>(dOs + (qt * 16 + lq) * (D + 16) + ks * 32 + gq * 8);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[ks], a, 0, 0, 0);    // S[query][key]
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf[ks], dp, 0, 0, 0);  // dP[query][key]
               }
-              float pr = kvalid ? __builtin_amdgcn_exp2f(sv - L.addmask[il]) : 0.f;
-              float dpe = dp[r], prd = pr;
-              if (p.p_drop > 0.f) {
-                const bool keep = drop_keep_rk(dseed, (uint32_t)((g * p.H + h) * p.Lq + ig), (uint32_t)(kvalid ? j : 0), thresh);
-                dpe = keep ? dpe * inv_keep : 0.f;
-                prd = keep ? pr * inv_keep : 0.f;
+  #pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int il = qt * 16 + gq * 4 + r;      // chunk-local query
+                const int ig = min(qbase + il, p.Lq - 1);
+                float sv = a[r] * sc2 + kadd;
+                if (WINDOW) {
+                  sv += L.btab[L.woff[il] - joff];
+                  if (L.reg[il] != kreg) sv += -144.26950408889634f;
+                }
+                float pr = kvalid ? __builtin_amdgcn_exp2f(sv - L.addmask[il]) : 0.f;
+                float dpe = dp[r], prd = pr;
+                if (p.p_drop > 0.f) {
+                  const bool keep = drop_keep_rk(dseed, (uint32_t)((g * p.H + h) * p.Lq + ig), (uint32_t)(kvalid ? j : 0), thresh);
+                  dpe = keep ? dpe * inv_keep : 0.f;
+                  prd = keep ? pr * inv_keep : 0.f;
+                }
+                ds[u][r] = pr * (dpe - L.aux[il]);
+                pd[u][r] = prd;
               }
-              ds[u][r] = pr * (dpe - L.aux[il]);
-              pd[u][r] = prd;
             }
           }
-        }
-        const bf16x8 dsf = pack8(ds[0], ds[1]), pf = pack8(pd[0], pd[1]);
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-          const bf16x8 qtf = trr_frag<D>(Qs, dt * 16, 2 * t2, gq, lq);
-          const bf16x8 dotf = trr_frag<D>(dOs, dt * 16, 2 * t2, gq, lq);
-          dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf, dkacc[dt], 0, 0, 0);   // dK^T[d][key]
-          dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotf, pf, dvacc[dt], 0, 0, 0);   // dV^T[d][key]
+          const bf16x8 dsf = pack8(ds[0], ds[1]), pf = pack8(pd[0], pd[1]);
+  #pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const bf16x8 qtf = trr_frag<D>(Qs, dt * 16, 2 * t2, gq, lq);
+            const bf16x8 dotf = trr_frag<D>(dOs, dt * 16, 2 * t2, gq, lq);
+            dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf, dkacc[dt], 0, 0, 0);   // dK^T[d][key]
+            dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotf, pf, dvacc[dt], 0, 0, 0);   // dV^T[d][key]
+          }
         }
       }
     }
-  }
-  if (kvalid) {
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-      bf16x4 ok, ov;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { ok[r] = f2bf(dkacc[dt][r] * p.scale); ov[r] = f2bf(dvacc[dt][r]); }
-      *reinterpret_cast<bf16x4*>(p.dk + (size_t)ktok * p.lddk + h * D + dt * 16 + gq * 4) = ok;
-      *reinterpret_cast<bf16x4*>(p.dv + (size_t)ktok * p.lddv + h * D + dt * 16 + gq * 4) = ov;
+    if (kvalid) {
+  #pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        bf16x4 ok, ov;
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) { ok[r] = f2bf(dkacc[dt][r] * p.scale); ov[r] = f2bf(dvacc[dt][r]); }
+        *reinterpret_cast<bf16x4*>(p.dk + (size_t)ktok * p.lddk + h * D + dt * 16 + gq * 4) = ok;
+        *reinterpret_cast<bf16x4*>(p.dv + (size_t)ktok * p.lddv + h * D + dt * 16 + gq * 4) = ov;
+      }
     }
+    if (!once) break;
   }
 }
 
@@ -736,12 +768,18 @@ int launch_bwd(AttnP& p, float* delta, float* dbias_table, float* dbias_ws, int 
     }
   }
   {
-    const int nstrips = cdiv(p.Lk, 16), nw = pick_waves(nstrips, 1 << 20);   // key-strip pass: measured worse with small workgroups
+    const int nstrips = cdiv(p.Lk, 16);
+    int nw = pick_waves(nstrips, 1 << 20);               // key-strip pass: measured worse with small workgroups
     launch_geometry(p, p.Lq, nw, true);
+    if (!p.window && D == 64 && !small_chunk(p, p.Lq) && nw > 8) nw = 8;   // launch bound of that instantiation (the chunking only changes at nw <= 4)
     const size_t sh = lds_bytes<D>(nb, 2, p.chrows);
+    // query side in one staged chunk: the kernel stages it once and walks key strips, so only as many workgroups per (head, sample) as it
+    // takes to fill the chip (strip_blocks); otherwise one workgroup per nw strips
+    static const int once_env = getenv("FIBER_ATTN_DKV_ONCE") ? atoi(getenv("FIBER_ATTN_DKV_ONCE")) : 1;   // 0: one strip per wave (A/B runs)
+    const int gx = once_env ? strip_blocks(p, p.Lq, nstrips, nw, p.H * p.G, false) : cdiv(nstrips, nw);
     if (p.window) hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, true>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), sh, st, p);
-    else if (small_chunk(p, p.Lq)) hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, false, 4>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), sh, st, p);
-    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, false>), dim3(cdiv(nstrips, nw), p.H, p.G), dim3(64 * nw), sh, st, p);
+    else if (small_chunk(p, p.Lq)) hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, false, 4>), dim3(gx, p.H, p.G), dim3(64 * nw), sh, st, p);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, false>), dim3(gx, p.H, p.G), dim3(64 * nw), sh, st, p);
     FIBER_CHECK_LAUNCH();
   }
   return FIBER_OK;
