@@ -70,8 +70,16 @@ class _restricted_pickle:
             return _Opaque
 
     _DTYPES = {n for n in dir(torch) if isinstance(getattr(torch, n), torch.dtype)}
-    load = staticmethod(_p.load)
-    loads = staticmethod(_p.loads)
+
+    @staticmethod
+    def load(f, **kw):                                          # every entry point goes through the restricted Unpickler
+        return _restricted_pickle.Unpickler(f, **kw).load()
+
+    @staticmethod
+    def loads(b, **kw):
+        import io
+        return _restricted_pickle.Unpickler(io.BytesIO(b), **kw).load()
+
     UnpicklingError = _p.UnpicklingError
     Pickler = _p.Pickler
 
@@ -84,10 +92,18 @@ def load_checkpoint(path, map_location=None):
     such object into an inert placeholder, and only the entries a resume needs are kept: state_dict, optimizer_states,
     lr_schedulers, global_step, epoch (+ best_metric, collate_ctr of own files)."""
     import pickle
+    import zipfile
     try:
         ck = torch.load(path, map_location=map_location, weights_only=True)
-    except (pickle.UnpicklingError, RuntimeError, AttributeError, ModuleNotFoundError):
-        ck = torch.load(path, map_location=map_location, weights_only=False, pickle_module=_restricted_pickle)
+    except pickle.UnpicklingError as first:
+        # Only the zip container (torch >= 1.6, what Lightning 1.3 writes) is read permissively; a legacy-format file
+        # would have its header pickles read before any tensor and is refused outright.
+        if not zipfile.is_zipfile(path):
+            raise ValueError(f"{path}: not a zip-format torch checkpoint; refusing the permissive reader") from first
+        try:
+            ck = torch.load(path, map_location=map_location, weights_only=False, pickle_module=_restricted_pickle)
+        except Exception as second:
+            raise second from first
     if not isinstance(ck, dict) or "state_dict" not in ck:
         raise ValueError(f"{path}: not a training checkpoint (no 'state_dict' entry; found {sorted(ck) if isinstance(ck, dict) else type(ck).__name__})")
 
@@ -257,11 +273,10 @@ class Trainer:
             self.current_epoch += 1
             if every is None:                                   # val_check_interval = 1.0: the check at the end of the epoch
                 run_validation()
-            elif rank == 0:
+            if rank == 0 and (every is not None or val_dataloader is None):
                 # interval checks (pl.Trainer runs no additional epoch-end validation for them): the checkpoints written inside
-                # the epoch carry the epoch as unfinished -- re-save so that a resume does not repeat it
-                self._save(model, opt, sched, "last.ckpt")
-            if val_dataloader is None and rank == 0:
+                # the epoch carry the epoch as unfinished -- re-save so that a resume does not repeat it; without a validation
+                # loader this is the epoch's only `last.ckpt`
                 self._save(model, opt, sched, "last.ckpt")
         return last
 

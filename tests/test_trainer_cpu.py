@@ -359,6 +359,41 @@ def test_resume_from_a_lightning_shaped_checkpoint(tmp_path):
         load_checkpoint(str(tmp_path / "w.pt"))
 
 
+def test_load_checkpoint_never_executes_a_legacy_format_pickle(tmp_path):
+    """a non-zip file whose first pickle carries a `__reduce__` payload.  torch's legacy reader goes through
+    `pickle_module.load` for the header -- every entry point of the restricted module must be the restricted Unpickler, and the
+    permissive fallback refuses non-zip files before reading them."""
+    import io
+    import pickle
+    import pytest
+    from fiber_amd.trainer import _restricted_pickle, load_checkpoint
+
+    class Evil:
+        def __reduce__(self):
+            return (_boom2, ())
+
+    _boom2.called = False
+    blob = pickle.dumps(Evil())
+    (tmp_path / "evil.ckpt").write_bytes(blob)
+    with pytest.raises(Exception):
+        load_checkpoint(str(tmp_path / "evil.ckpt"))
+    assert not _boom2.called
+    # the module-level entry points torch.load may call, directly: the payload's callable resolves to a placeholder
+    _restricted_pickle.load(io.BytesIO(blob))
+    _restricted_pickle.loads(blob)
+    assert not _boom2.called
+    # a legacy-format (non-zip) torch file with the payload inside is refused as well
+    torch.save({"state_dict": {}, "x": Evil()}, tmp_path / "legacy.ckpt", _use_new_zipfile_serialization=False)
+    with pytest.raises(Exception):
+        load_checkpoint(str(tmp_path / "legacy.ckpt"))
+    assert not _boom2.called
+
+
+def _boom2():
+    _boom2.called = True
+    raise RuntimeError("code from a legacy-format checkpoint was executed")
+
+
 def _boom():
     _boom.called = True
     raise RuntimeError("code from a checkpoint was executed")
