@@ -42,12 +42,19 @@ __device__ float g_win_trace[256];
 
 struct WinP {
   const bf16* qkv; bf16* o; const bf16* dout; bf16* dqkv;
-  float* lse; float* delta;   // delta: written by the dQ pass, read by the dK/dV pass
+  // lse, delta: [image][head][token] (round 5; [token][head] made every strip's 16 values 16 scattered 4-byte requests); delta: written by the
+  // dQ pass, read by the dK/dV pass
+  float* lse; float* delta;
   const float* bias_table; float* dbias_part;
   float* colsum_part;   // optional [gridDim.x * gridDim.z, 3C] fp32: per-workgroup column sums of dqkv (bias gradient of the qkv linear)
   int B, Hres, Wres, C, heads, ws, shift, nWw, nWh, nW, G, N, gpb;
-  int hmajor;   // qkv channel layout: 0 = [3][heads][32] (reference, swin_transformer.py:202), 1 = [heads][3][32] (q|k|v of a head adjacent)
+  // qkv channel layout: 0 = [3][heads][32] (reference, swin_transformer.py:202); 1 = [heads][3][32] (q|k|v of a head adjacent: one 192-byte run);
+  // 2 = [heads][32] q, then [heads][2][32] k|v: the k and v rows of a (token, head) are ONE aligned 128-byte line
+  int hmajor;
 };
+__device__ __forceinline__ int chan_q(const WinP& p, int h) { return p.hmajor == 1 ? h * 96 : h * 32; }
+__device__ __forceinline__ int chan_k(const WinP& p, int h) { return p.hmajor == 1 ? h * 96 + 32 : p.hmajor == 2 ? p.C + h * 64 : p.C + h * 32; }
+__device__ __forceinline__ int chan_v(const WinP& p, int h) { return p.hmajor == 1 ? h * 96 + 64 : p.hmajor == 2 ? p.C + h * 64 + 32 : 2 * p.C + h * 32; }
 
 __device__ __forceinline__ int region_of(int x, int n, int ws, int shift) { return x < n - ws ? 0 : (x < n - shift ? 1 : 2); }
 __device__ __forceinline__ float g4max(float v) { return rows4_max(v); }
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gq = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y, C = p.C, ld = 3 * C;
-  const int qo = p.hmajor ? h * 96 : h * 32, ko = p.hmajor ? h * 96 + 32 : C + h * 32, vo = p.hmajor ? h * 96 + 64 : 2 * C + h * 32;
+  const int qo = chan_q(p, h), ko = chan_k(p, h), vo = chan_v(p, h);
   // compile-time for the 12x12 window (guards fold, the 10th tile's code disappears) and for the 21-tile variant (18x18
   // windows fill it; padded tiles of smaller windows carry bias = -inf and zero rows, so running them is only wasted work)
   const int ntile = NTC ? NTC : MT > 10 ? MT : (p.N + 15) >> 4;
@@ -419,7 +426,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
         for (int r = 0; r < 4; ++r) o[r] = f2bf(oacc[dt][r] * inv);
         *reinterpret_cast<bf16x4*>(at(p.o + oimg * C, opix * C + h * 32 + dt * 16 + gq * 4)) = o;
       }
-      if (gq == 0) *at(p.lse + oimg * p.heads, opix * p.heads + h) = mx * scale + __logf(sum);
+      if (gq == 0) *at(p.lse + oimg * p.heads + (size_t)h * p.Hres * p.Wres, opix) = mx * scale + __logf(sum);
     }
     FWD_MARK(6);
   }
@@ -449,7 +456,7 @@ __global__ __launch_bounds__(MAXC == 1 ? (NTC ? 640 : 512) : 448) void win_bwd_d
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gq = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y, C = p.C, ld = 3 * C;
-  const int qo = p.hmajor ? h * 96 : h * 32, ko = p.hmajor ? h * 96 + 32 : C + h * 32, vo = p.hmajor ? h * 96 + 64 : 2 * C + h * 32;
+  const int qo = chan_q(p, h), ko = chan_k(p, h), vo = chan_v(p, h);
   // compile-time for the 12x12 window (guards fold, the 10th tile's code disappears) and for the 21-tile variant (18x18
   // windows fill it; padded tiles of smaller windows carry bias = -inf and zero rows, so running them is only wasted work)
   const int ntile = NTC ? NTC : MT > 10 ? MT : (p.N + 15) >> 4;
@@ -528,7 +535,7 @@ __global__ __launch_bounds__(MAXC == 1 ? (NTC ? 640 : 512) : 448) void win_bwd_d
     qn = *reinterpret_cast<const bf16x8*>(at(base, qpix * ld + qo + gq * 8));
     don = *reinterpret_cast<const bf16x8*>(at(p.dout + qimg * C, qpix * C + h * 32 + gq * 8));
     on = *reinterpret_cast<const bf16x8*>(at(static_cast<const bf16*>(p.o) + qimg * C, qpix * C + h * 32 + gq * 8));
-    lsen = *at(p.lse + qimg * p.heads, qpix * p.heads + h);
+    lsen = *at(p.lse + qimg * p.heads + (size_t)h * p.Hres * p.Wres, qpix);
   };
   if (g0 < g1) {
     geo.set(p, g0);
@@ -563,7 +570,7 @@ __global__ __launch_bounds__(MAXC == 1 ? (NTC ? 640 : 512) : 448) void win_bwd_d
     const float dlt = g4sum(dpart);
     const unsigned opix = qpix;
     const size_t oimg = qimg;
-    if (gq == 0 && qval) *at(p.delta + oimg * p.heads, opix * p.heads + h) = dlt;
+    if (gq == 0 && qval) *at(p.delta + oimg * p.heads + (size_t)h * p.Hres * p.Wres, opix) = dlt;
     const float nlse = qval ? lsen * -1.4426950408889634f : -INFINITY, dc = -dlt;
     __syncthreads();
     if (g + 1 < g1) {
@@ -674,7 +681,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dkv_kernel(WinP
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gq = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y, C = p.C, ld = 3 * C;
-  const int qo = p.hmajor ? h * 96 : h * 32, ko = p.hmajor ? h * 96 + 32 : C + h * 32, vo = p.hmajor ? h * 96 + 64 : 2 * C + h * 32;
+  const int qo = chan_q(p, h), ko = chan_k(p, h), vo = chan_v(p, h);
   // compile-time for the 12x12 window (guards fold, the 10th tile's code disappears) and for the 21-tile variant (18x18
   // windows fill it; padded tiles of smaller windows carry bias = -inf and zero rows, so running them is only wasted work)
   const int ntile = NTC ? NTC : MT > 10 ? MT : (p.N + 15) >> 4;
@@ -734,7 +741,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_bwd_dkv_kernel(WinP
         const unsigned st = geo.pix(p, spr[c], spc[c]);
         qr[c] = *reinterpret_cast<const bf16x8*>(at(base, st * ld + qo + sc * 8));
         dr[c] = *reinterpret_cast<const bf16x8*>(at(p.dout + kimg * C, st * C + h * 32 + sc * 8));
-        if (sc == 0) { lser[c] = *at(p.lse + kimg * p.heads, st * p.heads + h); dltr[c] = *at(p.delta + kimg * p.heads, st * p.heads + h); }
+        if (sc == 0) { lser[c] = *at(p.lse + kimg * p.heads + (size_t)h * p.Hres * p.Wres, st); dltr[c] = *at(p.delta + kimg * p.heads + (size_t)h * p.Hres * p.Wres, st); }
       }
     }
     kn = *reinterpret_cast<const bf16x8*>(at(base, kpix * ld + ko + gq * 8));
@@ -896,7 +903,7 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gq = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y, C = p.C, ld = 3 * C;
-  const int qo = p.hmajor ? h * 96 : h * 32, ko = p.hmajor ? h * 96 + 32 : C + h * 32, vo = p.hmajor ? h * 96 + 64 : 2 * C + h * 32;
+  const int qo = chan_q(p, h), ko = chan_k(p, h), vo = chan_v(p, h);
   setup<10>(p, S, h, nb, 0, 1.4426950408889634f, -INFINITY);
   {                                                      // zero the three images once: rows 144..159 (tile 9) are never staged
     uint32_t* z = reinterpret_cast<uint32_t*>(Qs);
@@ -952,7 +959,7 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
     kr = *reinterpret_cast<const bf16x8*>(at(base, st * ld + ko + sc * 8));
     dr = *reinterpret_cast<const bf16x8*>(at(p.dout + kimg * C, st * C + h * 32 + sc * 8));
     orr = *reinterpret_cast<const bf16x8*>(at(static_cast<const bf16*>(p.o) + kimg * C, st * C + h * 32 + sc * 8));
-    if (sc == 0) lser = *at(p.lse + kimg * p.heads, st * p.heads + h);
+    if (sc == 0) lser = *at(p.lse + kimg * p.heads + (size_t)h * p.Hres * p.Wres, st);
     vn = *reinterpret_cast<const bf16x8*>(at(base, kpix * ld + vo + gq * 8));
   };
   prefetch();
@@ -1034,17 +1041,16 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
         // 10 k cycles per window); the odd tile of a pair brings both tiles' transposed operands, the last tile (8) runs alone
         constexpr bool PAIR_END = (qi & 1) == 1, ALONE = qi == MT - 1;
         bf16x8 qt2[2], dt2[2];
-        s16x4 qt[2], dt_[2];
         if constexpr (PAIR_END) {
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt) { qt2[dt] = trr_frag(Qs, dt * 16, qi - 1, gq, lq); dt2[dt] = trr_frag(dOs, dt * 16, qi - 1, gq, lq); }
         } else if constexpr (ALONE) {
+          // Q^T / dO^T of this tile and of the (all-zero, never staged) image rows 144..159 behind it: the lone tile runs as a K = 32
+          // MFMA whose upper half is zero.  NOT the K = 16 opcode (round 5): a 16x16x16 MFMA that takes the D of a 16x16x32 MFMA as
+          // its C is padded by hipcc like an accumulate chain of ONE opcode (one wait state) and can read the accumulator before the
+          // K = 32 instruction has written it -- seen in a forward kernel as row sums of "last tile + stale registers".
 #pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {                 // Q^T / dO^T of this tile: [d = dt*16 + lq][queries gq*4 .. +3]
-            const int off = (qi * 16 + gq * 4 + (lq >> 2)) * RS + dt * 16 + (lq & 3) * 4;
-            qt[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Qs + off));
-            dt_[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(dOs + off));
-          }
+          for (int dt = 0; dt < 2; ++dt) { qt2[dt] = trr_frag(Qs, dt * 16, qi, gq, lq); dt2[dt] = trr_frag(dOs, dt * 16, qi, gq, lq); }
         }
         sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, sa, 0, 0, 0);        // S[query][key] - lse/scale
         sdp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf, sdp, 0, 0, 0);      // dP[query][key] - delta
@@ -1067,11 +1073,13 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
             dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dt2[dt], pf, dvacc[dt], 0, 0, 0);
           }
         } else if constexpr (ALONE) {
-          const s16x4 dsv = __builtin_bit_cast(s16x4, dsb), pv = __builtin_bit_cast(s16x4, pb);
+          bf16x8 dsf, pf;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { dsf[r] = dsb[r]; dsf[4 + r] = f2bf(0.f); pf[r] = pb[r]; pf[4 + r] = f2bf(0.f); }
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt) {
-            dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qt[dt], dsv, dkacc[dt], 0, 0, 0);
-            dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dt_[dt], pv, dvacc[dt], 0, 0, 0);
+            dkacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt2[dt], dsf, dkacc[dt], 0, 0, 0);
+            dvacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dt2[dt], pf, dvacc[dt], 0, 0, 0);
           }
         } else {
           ds_prev = dsb; p_prev = pb;

@@ -801,7 +801,7 @@ class _WindowAttn(torch.autograd.Function):
 def window_attention(qkv, bias_table, B, H, W, heads, ws, shift, head_major=False):
     """qkv [B, H*W, 3C] in image-token order -> attention output [B, H*W, C] (shift/partition/reverse folded in).
     head_major: qkv channels are [heads][3][32] (see linear_qkv_head_major) instead of the reference [3][heads][32]."""
-    return _WindowAttn.apply(qkv, bias_table, B, H, W, heads, ws, shift, 1 if head_major else 0)
+    return _WindowAttn.apply(qkv, bias_table, B, H, W, heads, ws, shift, int(head_major))
 
 
 def head_major_supported(ws):
