@@ -71,17 +71,34 @@ import json, os, sys, time, torch
 sys.path.insert(0, {root!r})
 from oracle import cases, detgen, fiber_ref
 torch.set_num_threads({threads})
-m = fiber_ref.FiberRef(dict(cases.SWIN_B, text_dropout=0.1, drop_path_rate=0.1)).train()
-for n, p in m.named_parameters():
-    if "alpha_" in n:
-        p.data.fill_(0.5)
-B = {batch}
-b = detgen.synth_batch(B, 384, 40, 50265, seed=0)
-for i in range(7):
-    t = time.time()
-    m.zero_grad(set_to_none=True)
-    m.training_loss(b, b["itm_labels"]).backward()
-    print(json.dumps({{"step": i, "sec": time.time() - t}}), flush=True)
+LEGS = {legs!r}
+
+
+def run(tag, cfg, size, B):
+    m = fiber_ref.FiberRef(dict(cfg, text_dropout=0.1, drop_path_rate=0.1)).train()
+    for n, p in m.named_parameters():
+        if "alpha_" in n:
+            p.data.fill_(0.5)
+    b = detgen.synth_batch(B, size, 40, 50265, seed=0)
+    if "train" in LEGS[tag]:
+        for i in range(7):                                    # 2 warm-ups + 5 timed, MLM + ITM forward + backward
+            t = time.time()
+            m.zero_grad(set_to_none=True)
+            m.training_loss(b, b["itm_labels"]).backward()
+            print(json.dumps({{"leg": tag + "/train", "B": B, "step": i, "sec": time.time() - t}}), flush=True)
+    if "fwd" in LEGS[tag]:
+        m.eval()
+        with torch.no_grad():
+            for i in range(7):                                # the fused-backbone forward of one image-text batch (fiber_module.py:224-367)
+                t = time.time()
+                m.infer(b)
+                print(json.dumps({{"leg": tag + "/fwd", "B": B, "step": i, "sec": time.time() - t}}), flush=True)
+
+
+if "base" in LEGS:
+    run("base", cases.SWIN_B, 384, {batch})
+if "swin_t" in LEGS:
+    run("swin_t", cases.SWIN_T, 224, 4)
 """
 
 
@@ -95,29 +112,39 @@ def _cpu_model():
     return "unknown CPU"
 
 
-def _cpu_run(threads, budget_s, batch):
+def _cpu_run(threads, budget_s, batch, legs):
+    """One child process (killed by PID at its deadline): {leg: (median seconds per iteration, timed iterations, batch)}."""
     import subprocess
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
-    proc = subprocess.Popen([sys.executable, "-c", _CPU_SNIPPET.format(root=ROOT, threads=threads, batch=batch)],
+    proc = subprocess.Popen([sys.executable, "-c", _CPU_SNIPPET.format(root=ROOT, threads=threads, batch=batch, legs=legs)],
                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True)
     try:
         out, _ = proc.communicate(timeout=budget_s)
     except subprocess.TimeoutExpired:
         proc.kill()                                           # the exact child we started
         out, _ = proc.communicate()
-    secs = [json.loads(l)["sec"] for l in out.splitlines() if l.startswith("{")]
-    if not secs:
-        return None, 0
-    timed = sorted(secs[2:]) if len(secs) > 2 else sorted(secs[1:]) if len(secs) > 1 else secs    # 2 warm-ups, median of 5
-    return timed[len(timed) // 2], len(timed)
+    by_leg = {}
+    for line in out.splitlines():
+        if line.startswith("{"):
+            r = json.loads(line)
+            by_leg.setdefault(r["leg"], []).append((r["sec"], r["B"]))
+    res = {}
+    for leg, rows in by_leg.items():
+        secs = [r[0] for r in rows]
+        timed = sorted(secs[2:])                              # SURVEY.md 8d: 2 warm-ups, median of (up to) 5
+        res[leg] = (timed[len(timed) // 2] if timed else None, len(timed), rows[0][1])
+    return res
 
 
-def cpu_baseline(budget_s=80.0, batch=2):
-    """The oracle (CPU restatement of the reference path, fp32 PyTorch) timed on this host's cores: MLM+ITM fwd+bwd at
-    FIBER-Base 384^2 / 40 tokens, B=2 (2 warm-up steps, median of 5).  Two thread counts -- 8 (the survey's container
-    reference point; finishes all 7 steps inside its share of the budget) and every physical core (an oversubscribed B=2 problem:
-    ~5x slower per step, reports the median of what it finished) -- each in a child process with a hard wall-clock budget (killed
-    by PID at the deadline) so the default bench always finishes in minutes; `value` is the better of the two, `cores` its threads."""
+def cpu_baseline(budget_s=130.0, batch=2):
+    """The oracle (CPU restatement of the reference path, fp32 PyTorch) timed on this host's cores, the legs BASELINE.md section 4b
+    names (2 warm-ups, median of 5 each), every child process under a hard wall-clock budget (killed by PID at the deadline) so that
+    the default bench finishes in minutes:
+      8 threads (the survey's container reference point): FIBER-Base 384^2 S=40 B=2 MLM+ITM forward + backward (images/s) and the
+        fused-backbone forward alone (ms / image); Swin-T 224^2 + RoBERTa-base B=4 (BASELINE.json configs[0]) forward + backward;
+      every physical core: the FIBER-Base train leg at B=8 (at B=2 128 threads have no work to share: round 4 measured it 6.5x
+        SLOWER than 8 threads and finished one timed step) -- reported as a median only when at least 3 timed steps finished.
+    `value` is the best FIBER-Base train-step rate, `cores` its thread count."""
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -129,21 +156,41 @@ def cpu_baseline(budget_s=80.0, batch=2):
         phys = max(1, avail // max(1, per_core))
     except OSError:
         pass
-    runs = []
-    for threads, share in ((min(8, avail), 0.6), (phys, 0.4)):
-        if any(r[0] == threads for r in runs):
-            continue
-        best, n = _cpu_run(threads, budget_s * share, batch)
-        runs.append((threads, best, n))
-    done = [(t, b, n) for t, b, n in runs if b]
-    desc = "; ".join(f"{t} threads: " + (f"{batch / b:.3f} images/s (median of {n} timed steps after warm-up)" if b else "no step finished") for t, b, n in runs)
+    t8 = min(8, avail)
+    legs8 = _cpu_run(t8, budget_s * 0.62, batch, {"base": ["train", "fwd"], "swin_t": ["train"]})
+    legs_all = _cpu_run(phys, budget_s * 0.38, 8, {"base": ["train"]}) if phys > t8 else {}
+
+    def rate(entry):                                          # images/s of a (seconds, n, B) entry
+        return entry[2] / entry[0] if entry and entry[0] else None
+
+    parts, cands = [], []
+    e = legs8.get("base/train")
+    if rate(e):
+        parts.append(f"{t8} threads: FIBER-Base 384^2 B={e[2]} train {rate(e):.3f} images/s (median of {e[1]})")
+        cands.append((rate(e), t8))
+    else:
+        parts.append(f"{t8} threads: FIBER-Base train leg did not finish a timed step")
+    e = legs8.get("base/fwd")
+    parts.append(f"fused-backbone forward {1e3 * e[0] / e[2]:.0f} ms/image (median of {e[1]})" if e and e[0] else "forward leg did not finish")
+    e = legs8.get("swin_t/train")
+    parts.append(f"Swin-T 224^2 B=4 (configs[0]) train {rate(e):.2f} images/s (median of {e[1]})" if rate(e) else "Swin-T leg did not finish")
+    if legs_all or phys > t8:
+        e = legs_all.get("base/train")
+        if e and e[0] and e[1] >= 3:
+            parts.append(f"{phys} threads: FIBER-Base 384^2 B={e[2]} train {rate(e):.3f} images/s (median of {e[1]})")
+            cands.append((rate(e), phys))
+        else:
+            parts.append(f"{phys} threads, B=8: did not finish a median of 3 timed steps inside its {budget_s * 0.38:.0f} s")
     base = {"unit": "images/s", "kind": "port",
-            "sample": f"oracle/fiber_ref.py FIBER-Base 384^2 S=40 MLM+ITM fwd+bwd, B={batch}, fp32, on {_cpu_model()} "
-                      f"({avail} logical / {phys} physical cores visible), {budget_s:.0f} s budget: {desc}"}
-    if not done:
-        return dict(base, value=None, cores=runs[-1][0])
-    t, b, _ = min(done, key=lambda r: r[1])
-    return dict(base, value=round(batch / b, 4), cores=t)
+            "sample": f"oracle/fiber_ref.py MLM+ITM, fp32, on {_cpu_model()} ({avail} logical / {phys} physical cores visible), "
+                      f"{budget_s:.0f} s budget, 2 warm-ups + median of up to 5: " + "; ".join(parts)}
+    legs = {k: {"sec_per_iter": v[0], "timed": v[1], "B": v[2], "threads": t8} for k, v in legs8.items()}
+    legs.update({k + f"@{phys}t": {"sec_per_iter": v[0], "timed": v[1], "B": v[2], "threads": phys} for k, v in legs_all.items()})
+    base["legs"] = legs
+    if not cands:
+        return dict(base, value=None, cores=t8)
+    v, t = max(cands)
+    return dict(base, value=round(v, 4), cores=t)
 
 
 def _latest_profile(suffix):

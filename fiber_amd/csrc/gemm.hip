@@ -1218,8 +1218,9 @@ extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bia
   if (act & 0x100) {                                      // fp32 output: the register-staged kernels only
     if (mode != 0 || residual || colpart) return FIBER_EINVAL;
     shape = big >= 192 ? 4 : 5;
-  } else if (v2 && !nowide && force == 0 && wide >= 200 && K >= 128 &&
-             (N % 256 == 0 || (N % 64 == 0 && N > 256 && q8_serves))) shape = 0;   // (only the q8 kernel masks a partial tile column)
+  } else if (v2 && !nowide && force == 0 && wide >= 200 && K >= 128 && !(mode == 2 && !q8_serves) &&
+             (N % 256 == 0 || (N % 64 == 0 && N > 256 && q8_serves))) shape = 0;   // (only the q8 kernel masks a partial tile column; gelu' * aux
+                                                                                    //  with column sums / without q8: the 256x128 ring kernel)
   else if (v2 && ((huge >= 400 && K >= 256 && force == 0) || force == 256)) shape = 1;
   else if (big >= 192 || force == 128) shape = v2 ? 2 : 4;
   else shape = v2 ? 3 : 5;
@@ -1227,11 +1228,12 @@ extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bia
   const bool persist = persist_env && wide >= persist_min;   // (q8 wins from one tile per CU on: 240 tiles 31.5 -> 28.1 us, 97.5 -> 85.1 us at K = 3072)
 #define FIBER_LAUNCH_EPI(EPI, R, RS)                                                                                          \
   do {                                                                                                                        \
-    if (shape == 0 && persist && persist_env == 2) hipLaunchKernelGGL((gemm_nt_wide_persist_kernel<2, 4, EPI, R, RS>), dim3(256), dim3(512), 0, stream, a); \
+    if (shape == 0 && EPI == 2 && !(persist && q8_env && !a.colpart)) return FIBER_EINVAL;   /* (the pre-q8 kernels are not built for gelu' * aux: 104-168 B of scratch) */ \
+    if (shape == 0 && persist && persist_env == 2) hipLaunchKernelGGL((gemm_nt_wide_persist_kernel<2, 4, (EPI == 2 ? 0 : EPI), R, RS>), dim3(256), dim3(512), 0, stream, a); \
     else if (shape == 0 && persist && q8_env && kV4Ok<EPI, R, RS> && !(EPI == 2 && a.colpart)) hipLaunchKernelGGL((gemm_nt_q8_kernel<kV4Ok<EPI, R, RS> ? EPI : 0, kV4Ok<EPI, R, RS> && R, RS>), dim3(256), dim3(512), 0, stream, a); \
     else if (shape == 0 && persist && kV4Ok<EPI, R, RS> && !(EPI == 2 && a.colpart)) hipLaunchKernelGGL((gemm_nt_wide_persist2_kernel<2, 4, kV4Ok<EPI, R, RS> ? EPI : 0, kV4Ok<EPI, R, RS> && R, RS>), dim3(256), dim3(512), 0, stream, a); \
-    else if (shape == 0 && persist) hipLaunchKernelGGL((gemm_nt_wide_persist_kernel<2, 4, EPI, R, RS>), dim3(256), dim3(512), 0, stream, a); \
-    else if (shape == 0) hipLaunchKernelGGL((gemm_nt_wide_kernel<2, 4, EPI, R, RS>), dim3((unsigned)wide), dim3(512), 0, stream, a);   \
+    else if (shape == 0 && persist) hipLaunchKernelGGL((gemm_nt_wide_persist_kernel<2, 4, (EPI == 2 ? 0 : EPI), R, RS>), dim3(256), dim3(512), 0, stream, a); \
+    else if (shape == 0) hipLaunchKernelGGL((gemm_nt_wide_kernel<2, 4, (EPI == 2 ? 0 : EPI), R, RS>), dim3((unsigned)wide), dim3(512), 0, stream, a);   \
     else if (shape == 1) hipLaunchKernelGGL((gemm_nt_glds_kernel<256, 128, 4, 2, 3, EPI, R, RS>), dim3((unsigned)huge), dim3(512), 0, stream, a); \
     else if (shape == 2) hipLaunchKernelGGL((gemm_nt_glds_kernel<128, 128, 2, 2, 2, EPI, R, RS>), dim3((unsigned)big), dim3(256), 0, stream, a);  \
     else hipLaunchKernelGGL((gemm_nt_glds_kernel<64, 64, 2, 2, 2, EPI, R, RS>), dim3((unsigned)small), dim3(256), 0, stream, a);                   \
@@ -1265,7 +1267,12 @@ extern "C" int fiber_gemm_nt_bf16(const void* X, const void* W, const float* bia
   else if (residual && shape == 0 && persist && persist_env == 1 && q8_env) {
     // residual without DropPath (text-layer output projections, blocks with drop_path = 0) on the large-shape path: the q8 instantiation
     // for it spills 120 bytes per lane, the DropPath one does not -- run that one with a one-element scale of 1.0f (x * 1.0f is exact)
-    static const float* one = [] { float* p = nullptr; hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_gemm_one)); return (const float*)p; }();
+    // (a __device__ symbol has one address PER DEVICE: cached per device id, not per process)
+    static const float* one_of[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return FIBER_ELAUNCH;
+    if (one_of[dev] == nullptr) { float* p = nullptr; if (hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_gemm_one)) != hipSuccess) return FIBER_ELAUNCH; one_of[dev] = p; }
+    const float* one = one_of[dev];
     if (one == nullptr) return FIBER_ELAUNCH;
     a.rowscale = one; a.rows_per_sample = a.M;
     FIBER_LAUNCH_EPI(0, true, true);

@@ -310,8 +310,10 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
     else if (nvec <= 64) KERNEL(64, 1, LN_U, __VA_ARGS__);                                  \
     else if (nvec <= 128) KERNEL(64, 2, LN_U2, __VA_ARGS__);                                \
     else if (nvec <= 256) KERNEL(64, 4, 1, __VA_ARGS__);                                    \
-    else if (nvec <= 512) KERNEL(64, 8, 1, __VA_ARGS__);                                    \
-    else return FIBER_EINVAL;                                                               \
+    else if (nvec <= 512) {                                                                 \
+      /* (the PatchMerging forms stop at 4C = 2048, Swin-B's last merge; their 4096-wide instance spilled 52 bytes) */ \
+      if constexpr (MERGE) return FIBER_EINVAL; else KERNEL(64, 8, 1, __VA_ARGS__);         \
+    } else return FIBER_EINVAL;                                                             \
   } while (0)
 
 // rows one wave takes per iteration (row groups in flight x rows per group)

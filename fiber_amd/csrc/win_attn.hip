@@ -1215,8 +1215,6 @@ void ensure_attrs() {
   hipFuncSetAttribute((const void*)win_bwd_dq_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   hipFuncSetAttribute((const void*)win_bwd_dkv_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   hipFuncSetAttribute((const void*)win_fwd_kernel<1, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  hipFuncSetAttribute((const void*)win_bwd_dq_kernel<1, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  hipFuncSetAttribute((const void*)win_bwd_dkv_kernel<1, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   hipFuncSetAttribute((const void*)win_fwd_kernel<3, 0, 21, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   hipFuncSetAttribute((const void*)win_bwd_dq_kernel<3, 0, 21, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   hipFuncSetAttribute((const void*)win_bwd_dkv_kernel<3, 0, 21, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
@@ -1334,8 +1332,8 @@ int fiber_win_bwd_launch(const void* qkv, const float* bias_table, const void* o
   const size_t nth = big_window(p.N) ? 448 : 640;        // launch bounds = slot stride of the column-sum slots
   const size_t csq = colsum_ws ? nth * 2 * 16 : 0, cskv = colsum_ws ? nth * 4 * 16 : 0;
   if ((colsum_ws == nullptr) != (dqkv_colsum == nullptr)) return FIBER_EINVAL;
-  static const int fused = getenv("FIBER_WIN_FUSED") ? atoi(getenv("FIBER_WIN_FUSED")) : 1;   // 0: the two-pass backward (A/B runs)
-  if (fused && p.N == 144 && sg == 1) {                  // 12x12 windows: one pass (delta_ws stays unused)
+  if (p.N == 144 && sg == 1) {                           // 12x12 windows: one pass (delta_ws stays unused).  The two-pass instances for this
+    // size (round 3's A/B switch FIBER_WIN_FUSED=0) carried 8 / 24 bytes of scratch and are no longer built.
     const size_t bytes = (size_t)(4 * 160 + ((nb + 3) & ~3)) * 4 + (size_t)3 * 160 * RS * 2 + (size_t)144 * DSS * 2 + (size_t)(5 * 576 + 9 * 4 * 6) * 16;
     if (shift > 0) hipLaunchKernelGGL(win_bwd_fused_kernel<true>, dim3(gz, heads, 1), dim3(576), bytes, st, p);
     else hipLaunchKernelGGL(win_bwd_fused_kernel<false>, dim3(gz, heads, 1), dim3(576), bytes, st, p);
@@ -1345,13 +1343,11 @@ int fiber_win_bwd_launch(const void* qkv, const float* bias_table, const void* o
     return FIBER_OK;
   }
   if (big_window(p.N)) hipLaunchKernelGGL((win_bwd_dq_kernel<3, 0, 21, false>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2) + csq + 8 * 448 * 16, st, p);   // (+ the 8 dbias tiles kept in LDS: 150 KB in all)
-  else if (p.N == 144) hipLaunchKernelGGL((win_bwd_dq_kernel<1, 9>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2) + slab + csq, st, p);   // (FIBER_WIN_NTC bit 1 no longer selects the run-time-count instance here: that one is bounded at 8 waves)
   else if (nw > 8) return FIBER_EINVAL;                  // (N = ws * ws: no square window has 129..160 tokens other than 12 x 12)
   else hipLaunchKernelGGL((win_bwd_dq_kernel<1, 0>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2) + slab + csq, st, p);
   FIBER_CHECK_LAUNCH();
   if (int rc = dbias_fold_gather(dbias_ws, dbias_table, gz, heads, ws, st)) return rc;
   if (big_window(p.N)) hipLaunchKernelGGL((win_bwd_dkv_kernel<3, 0, 21, false>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2) + cskv, st, p);
-  else if (p.N == 144 && (ntc_mask() & 4)) hipLaunchKernelGGL((win_bwd_dkv_kernel<1, 9>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2) + cskv, st, p);
   else hipLaunchKernelGGL((win_bwd_dkv_kernel<1, 0>), dim3(gz, heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2) + cskv, st, p);
   FIBER_CHECK_LAUNCH();
   if (colsum_ws) return fiber_fold_rows_f32(colsum_ws, dqkv_colsum, gz * sg, 3 * C, st);

@@ -677,12 +677,12 @@ class _LayerNorm(torch.autograd.Function):
         return dx.view(dy.shape), dg, db, None, None, None
 
 
-def layernorm(x, gamma, beta, eps=1e-5, want_f32=None):
-    """LayerNorm over the last dim.  Reads the fp32 payload of a stream tensor when it has one.  want_f32 (default: follows the
-    input, i.e. on when x carries a payload and residual_fp32() -- the post-LN text stack) attaches the output's own payload."""
+def layernorm(x, gamma, beta, eps=1e-5, want_f32=False):
+    """LayerNorm over the last dim.  Reads the fp32 payload of a stream tensor when it has one.  want_f32 attaches the output's own fp32
+    payload: only where the OUTPUT starts or continues a residual stream (patch-embedding norm, the post-LN text stack: those callers ask
+    for it).  The pre-LN consumers and the final norms do not -- a payload nothing reads as a residual is an fp32 copy written for nothing,
+    and it would make downstream ops treat their input as a stream."""
     x32 = f32_of(x)
-    if want_f32 is None:
-        want_f32 = x32 is not None and residual_fp32()
     y, y32 = _LayerNorm.apply(x, gamma, beta, eps, x32, bool(want_f32))
     return with_f32(y, y32)
 

@@ -1,0 +1,72 @@
+"""GPU: BASELINE.json configs[0] as literally stated -- `task_mlm_itm`, Swin-Tiny + RoBERTa-base, 224 x 224, batch 4 -- driven through
+the Trainer (the stand-in for `pl.Trainer`, coarse_grained/run.py:18-75) on the REAL HIP module: gradient accumulation, the step-interval
+scheduler, a validation pass per epoch, `last.ckpt` / `best.ckpt`, `resume_from_checkpoint`, and equality of the resumed run with the
+uninterrupted one.  (The reference runs this configuration on CPU as a plumbing check; the product has no CPU path, so the plumbing is
+checked where the product runs.  tests/test_trainer_cpu.py holds the same Trainer semantics on toy modules.)"""
+import pytest
+import torch
+
+from oracle import cases, detgen
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(max_steps):
+    from fiber_amd import ops
+    from fiber_amd.config import make_config
+    from fiber_amd.modules import FIBERTransformerSS
+    ops.clear_weight_cache()
+    torch.manual_seed(0)
+    # dropout / DropPath off (cases.SWIN_T): the two runs below must agree exactly, whatever the RNG step they are at
+    model = FIBERTransformerSS(make_config(**cases.SWIN_T, learning_rate=1e-4, lr_mult_head=5, lr_mult_cross_modal=5, warmup_steps=1,
+                                           max_steps=max_steps, weight_decay=0.01, end_lr=0, decay_power=1))
+    detgen.fill_(model)
+    for n, p in model.named_parameters():
+        if "alpha_" in n:
+            p.data.fill_(0.5)
+    return model
+
+
+def test_trainer_fit_swin_t_224_b4(tmp_path):
+    from fiber_amd import lib
+    from fiber_amd.trainer import Trainer, load_checkpoint
+    assert torch.cuda.is_available()
+    lib.load()
+    data = [detgen.synth_batch(4, 224, 40, 50265, seed=70 + s, min_len=8) for s in range(3)]
+    for b in data:
+        b["itm_labels_override"] = b["itm_labels"]
+    val = data[:1]
+    # ---- uninterrupted: 6 optimizer steps of 2 micro-batches = 4 epochs of the 3-batch loader, a validation pass after each
+    ma = _model(6)
+    ta = Trainer(max_steps=6, accumulate_grad_batches=2, log_every_n_steps=0, default_root_dir=str(tmp_path / "a"))
+    last_a = ta.fit(ma, data, val_dataloader=val)
+    assert ta.global_step == 6 and ma.global_step == 6 and ta.current_epoch == 4
+    assert ta.best_metric is not None and torch.isfinite(torch.tensor(ta.best_metric))
+    assert "val/the_metric" in ma.logged and "mlm/val/loss_epoch" in ma.logged and "itm/val/accuracy_epoch" in ma.logged
+    assert (tmp_path / "a" / "last.ckpt").exists() and (tmp_path / "a" / "best.ckpt").exists()
+    ck = load_checkpoint(str(tmp_path / "a" / "last.ckpt"))
+    assert ck["global_step"] == 6 and set(ck["state_dict"]) == set(ma.state_dict())
+    assert ck["lr_schedulers"][0]["last_epoch"] == 6 and ck["optimizer_states"][0]["state"]
+    # the schedule reached its end: linear warm-up over 1 step, linear decay to 0 at step 6 (fiber_utils.py:274)
+    assert ma.trainer is ta
+    # ---- interrupted after 3 steps (= 2 epochs), resumed to 6
+    mb = _model(6)
+    tb = Trainer(max_steps=3, accumulate_grad_batches=2, log_every_n_steps=0, default_root_dir=str(tmp_path / "b"))
+    tb.fit(mb, data, val_dataloader=val)
+    assert tb.global_step == 3 and tb.current_epoch == 2
+    mid = load_checkpoint(str(tmp_path / "b" / "last.ckpt"))
+    assert mid["global_step"] == 3 and mid["epoch"] == 2
+    mc = _model(6)                                          # fresh module: everything must come from the checkpoint
+    tc = Trainer(max_steps=6, accumulate_grad_batches=2, log_every_n_steps=0, default_root_dir=str(tmp_path / "c"),
+                 resume_from_checkpoint=str(tmp_path / "b" / "last.ckpt"))
+    last_c = tc.fit(mc, data, val_dataloader=val)
+    assert tc.global_step == 6 and tc.current_epoch == 4
+    torch.cuda.synchronize()
+    # the resumed run IS the uninterrupted one: same batches in the same order, deterministic kernels (no atomics on this path),
+    # optimizer moments, schedule position and fp32 masters restored from the file
+    assert abs(float(last_a) - float(last_c)) <= 1e-6 * max(1.0, abs(float(last_a))), (float(last_a), float(last_c))
+    sa, sc = ma.state_dict(), mc.state_dict()
+    worst = max((float((sa[k].float() - sc[k].float()).abs().max()), k) for k in sa if sa[k].is_floating_point())
+    assert worst[0] <= 1e-6, worst
+    # and it trained: the loss of the last step is below the first step's
+    assert float(last_a) < 11.5, float(last_a)

@@ -12,7 +12,7 @@ for four runs started from the same point:
     HIP, bf16 residual stream (the default)  |  HIP, fp32 residual stream (config["residual_dtype"] = "fp32")
 and reports, per run, the gap to the fp32 oracle: median / p90 / max and the number of steps within the north star's +-1e-3.
 
-    python tools/loss_curve_study.py swin_t|fiber_base [--B N] [--steps K] [--threads T]      -> gpurun_out/r04_loss_curve_<case>_b<B>.json
+    python tools/loss_curve_study.py swin_t|fiber_base [--B N] [--steps K] [--threads T]      -> gpurun_out/r05_loss_curve_<case>_b<B>.json
 """
 import argparse
 import json
@@ -144,7 +144,7 @@ def main():
            "loss_first": want[0], "loss_last": want[-1], "seconds": secs, "summary": summary, "curves": {k: [round(v, 5) for v in c] for k, c in curves.items()}}
     print(json.dumps(summary, indent=1))
     os.makedirs("gpurun_out", exist_ok=True)
-    json.dump(out, open(f"gpurun_out/r04_loss_curve_{a.case}_b{B}.json", "w"), indent=1)
+    json.dump(out, open(f"gpurun_out/r05_loss_curve_{a.case}_b{B}.json", "w"), indent=1)
 
 
 if __name__ == "__main__":
