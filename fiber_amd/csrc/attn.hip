@@ -814,6 +814,10 @@ int fiber_win_bwd_launch(const void* qkv, const float* bias_table, const void* o
                          void* dqkv, float* dbias_table, float* delta_ws, float* dbias_ws, float* dqkv_colsum, float* colsum_ws,
                          int B, int Hres, int Wres, int C, int heads, int ws, int shift, int hmajor, hipStream_t st);
 int fiber_win_colsum_rows(int n_windows, int heads, int N);
+// one-pass backward of image -> text cross attention (attn_x.hip); FIBER_EINVAL = shape not served
+int fiber_i2t_bwd_launch(const void* q, const void* k, const void* v, const float* kmask, const void* o, const void* dout, const float* lse,
+                         void* dq, void* dk, void* dv, int B, int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, int lddo,
+                         int lddq, int lddk, int lddv, float scale, hipStream_t st);
 
 // --------------------------------------------------------------------------------------------------- C ABI
 // Window attention in image-token order.  qkv: [B*Hres*Wres, 3C] bf16 with channel layout [3][heads][32]
@@ -893,6 +897,13 @@ extern "C" int fiber_mha_bwd_bf16(const void* q, const void* k, const void* v, c
   if ((D != 32 && D != 64) || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 7) || (lddo & 7) || (lddq & 3) || (lddk & 3) ||
       (lddv & 3) || Lq <= 0 || Lk <= 0)
     return FIBER_EINVAL;
+  // few keys, head_dim 32, no dropout (image -> text cross attention): one pass with K / V in registers (delta_ws stays unused)
+  static const int onepass = getenv("FIBER_ATTN_I2T_ONEPASS") ? atoi(getenv("FIBER_ATTN_I2T_ONEPASS")) : 1;   // 0: the generic three kernels (A/B runs)
+  if (onepass && D == 32 && Lk <= 48 && p_drop == 0.f && (Lq & 15) == 0 && (heads & 3) == 0 && !(lddq & 7)) {
+    const int rc = fiber_i2t_bwd_launch(q, k, v, kmask, o, dout, lse, dq, dk, dv, B, heads, Lq, Lk, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv,
+                                        scale, stream);
+    if (rc != FIBER_EINVAL) return rc;
+  }
   ensure_attrs();
   AttnP p{};
   p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.o = (bf16*)o; p.lse = (float*)lse;

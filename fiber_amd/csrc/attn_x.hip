@@ -1,0 +1,264 @@
+// Image -> text cross attention (swin_transformer.py:226-259), backward in ONE pass (gfx950 / CDNA4).
+//
+// The generic backward of attn.hip runs three kernels for this site (delta = rowsum(dO . O); a query-strip pass for dQ; a key-strip pass
+// for dK / dV) and reads q, dO, O twice: at 576 queries x 40 text tokens x head_dim 32 it moved its bytes at 1.5-2.1 TB/s (0.19-0.26 of the
+// HBM floor: the family furthest from its roofline in the round-4 step).  Here the text side is tiny -- K and V of one (sample, head) are
+// 40 x 64 B -- so a wave keeps them in REGISTERS (as MFMA operands in both orientations) and streams the query strips once:
+//   * per strip of 16 queries a lane loads 16 bytes of q, dO and O; delta comes out of the dO / O pieces it already holds;
+//   * the scores are formed in BOTH orientations (the matrix pipe is idle anyway): S^T[key][query] (lane = query) feeds dQ^T = K^T . dS^T,
+//     S[query][key] (lane = key) feeds dK^T += Q^T . dS and dV^T += dO^T . P, whose contraction runs over the strip's 16 queries
+//     (K = 16 MFMAs; Q^T / dO^T of the strip are read back transposed from a wave-private 3-KB LDS area);
+//   * dK / dV of the (sample, head) accumulate in registers over the strips a wave walks and are folded once at the end;
+//   * a workgroup is 4 adjacent heads x 2 halves of the strips: the q / dO / O / dQ rows of the four heads are one 256-byte run touched by
+//     four waves at the same time (tools/probes/run_probe.hip: scattered 64-byte runs move at 2.2-3.5 TB/s, neighbours requested together
+//     at 4.2-5.5), and dQ leaves as 16-byte stores.
+// No barrier inside the strip loop.  Conditions (else the generic passes run): head_dim 32, Lk <= 48, Lq % 16 == 0, heads % 4 == 0, no
+// attention dropout (the reference applies none at this site).
+#include "common.h"
+
+namespace {
+
+constexpr int XRS = 48;                                  // LDS row stride in elements: 32 + 16 pad = 96 B (conflict-free for both read kinds)
+
+struct XP {
+  const bf16* q; const bf16* k; const bf16* v; const bf16* o; const bf16* dout;
+  bf16* dq; bf16* dk; bf16* dv;
+  const float* lse; const float* kmask;
+  int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+  int H, Lq, Lk, G;
+  float scale;
+};
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { o[e] = f2bf(a[e]); o[4 + e] = f2bf(b[e]); }
+  return o;
+}
+__device__ __forceinline__ s16x4 pack4(const f32x4& a) {
+  bf16x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = f2bf(a[e]);
+  return __builtin_bit_cast(s16x4, o);
+}
+// transposed MFMA operand out of a row-major [row][32] image: rows {t0*16 + g*4 ..+3} U {t0*16 + 16 + g*4 ..+3}, column d0 + l
+__device__ __forceinline__ bf16x8 trr_frag(const bf16* rm, int d0, int t0, int g, int l) {
+  const bf16* a = rm + (t0 * 16 + g * 4 + (l >> 2)) * XRS + d0 + (l & 3) * 4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + 16 * XRS));
+  return __builtin_bit_cast(bf16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+}
+// the same for ONE 16-row tile (K = 16 operand): [d0 + l][rows g*4 .. +3]
+__device__ __forceinline__ s16x4 tr16(const bf16* rm, int d0, int g, int l) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(rm + (g * 4 + (l >> 2)) * XRS + d0 + (l & 3) * 4));
+}
+__device__ __forceinline__ f32x4 exp2x4(f32x4 a) {
+  return f32x4{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1]), __builtin_amdgcn_exp2f(a[2]), __builtin_amdgcn_exp2f(a[3])};
+}
+// 16-byte row pieces out of the C layout of two 16x16 MFMAs (see win_attn.hip rows4_gather16)
+__device__ __forceinline__ u32x4 rows4_gather16(f32x4 a, f32x4 b) {
+  const bf16x2 alo = {f2bf(a[0]), f2bf(a[1])}, ahi = {f2bf(a[2]), f2bf(a[3])}, blo = {f2bf(b[0]), f2bf(b[1])}, bhi = {f2bf(b[2]), f2bf(b[3])};
+  const unsigned wa[2] = {__builtin_bit_cast(unsigned, alo), __builtin_bit_cast(unsigned, ahi)}, wb[2] = {__builtin_bit_cast(unsigned, blo), __builtin_bit_cast(unsigned, bhi)};
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const auto x = __builtin_amdgcn_permlane32_swap(wa[e], wb[e], false, false);
+    const auto y = __builtin_amdgcn_permlane16_swap((unsigned)x[0], (unsigned)x[1], false, false);
+    o[e] = (unsigned)y[0]; o[2 + e] = (unsigned)y[1];
+  }
+  return o;
+}
+
+constexpr int X_KV = 4 * 64 * XRS * 2;                   // bytes of the K (or V) images of four heads (64 rows each, rows >= Lk zero)
+constexpr int X_STRIP = 16 * XRS * 2;                    // one strip image (Q or dO) of a wave
+constexpr int X_SMEM = 2 * X_KV + 8 * 2 * X_STRIP + 8 * 32 * 4 + 4 * 12 * 64 * 16;
+
+__global__ __launch_bounds__(512) void i2t_bwd_kernel(XP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* Ks = reinterpret_cast<bf16*>(smem);
+  bf16* Vs = reinterpret_cast<bf16*>(smem + X_KV);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int gq = lane >> 4, lq = lane & 15;
+  const int hl = wave & 3, half = wave >> 2;
+  const int b = blockIdx.x, h0 = blockIdx.y * 4, h = h0 + hl;
+  bf16* Qst = reinterpret_cast<bf16*>(smem + 2 * X_KV + wave * 2 * X_STRIP);
+  bf16* dOst = Qst + 16 * XRS;
+  float* stat = reinterpret_cast<float*>(smem + 2 * X_KV + 8 * 2 * X_STRIP) + wave * 32;
+  f32x4* red = reinterpret_cast<f32x4*>(smem + 2 * X_KV + 8 * 2 * X_STRIP + 8 * 32 * 4);
+  // ---- K, V of the four heads: row-major images, rows >= Lk zero
+  for (int idx = tid; idx < 4 * 64 * 4; idx += 512) {
+    const int hh = idx >> 8, r = (idx >> 2) & 63, c = idx & 3;
+    bf16x8 kv, vv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { kv[e] = f2bf(0.f); vv[e] = f2bf(0.f); }
+    if (r < p.Lk) {
+      const size_t row = (size_t)b * p.Lk + r;
+      kv = *reinterpret_cast<const bf16x8*>(p.k + row * p.ldk + (h0 + hh) * 32 + c * 8);
+      vv = *reinterpret_cast<const bf16x8*>(p.v + row * p.ldv + (h0 + hh) * 32 + c * 8);
+    }
+    *reinterpret_cast<bf16x8*>(Ks + (hh * 64 + r) * XRS + c * 8) = kv;
+    *reinterpret_cast<bf16x8*>(Vs + (hh * 64 + r) * XRS + c * 8) = vv;
+  }
+  __syncthreads();
+  const bf16* Kh = Ks + hl * 64 * XRS;
+  const bf16* Vh = Vs + hl * 64 * XRS;
+  bf16x8 kfr[3], vfr[3], ktf[2][2];                      // K, V rows of key tile kt (operand of both orientations); K^T of tile pairs (0,1), (2,3)
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt) {
+    kfr[kt] = *reinterpret_cast<const bf16x8*>(Kh + (kt * 16 + lq) * XRS + gq * 8);
+    vfr[kt] = *reinterpret_cast<const bf16x8*>(Vh + (kt * 16 + lq) * XRS + gq * 8);
+  }
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) ktf[dt][pr] = trr_frag(Kh, dt * 16, 2 * pr, gq, lq);
+  // additive key mask in the log2 domain: lane = query form (keys kt*16 + gq*4 + r) and lane = key form (key kt*16 + lq); -inf past Lk
+  f32x4 mkT[3];
+  float mkS[3];
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kt * 16 + gq * 4 + r;
+      mkT[kt][r] = key < p.Lk ? (p.kmask ? p.kmask[(size_t)b * p.Lk + key] * 1.4426950408889634f : 0.f) : -INFINITY;
+    }
+    const int key = kt * 16 + lq;
+    mkS[kt] = key < p.Lk ? (p.kmask ? p.kmask[(size_t)b * p.Lk + key] * 1.4426950408889634f : 0.f) : -INFINITY;
+  }
+  const float c2 = p.scale * 1.4426950408889634f, inv_c2 = 1.f / c2;
+  f32x4 dkT[3][2], dvT[3][2];                            // dK^T / dV^T[d = dt*16 + gq*4 + r][key = kt*16 + lq], summed over this wave's strips
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) { dkT[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvT[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const int nstrips = p.Lq >> 4;
+  // Strips are requested PD iterations ahead (registers): one iteration ahead left every strip waiting ~3 us for its rows (24 KB in flight
+  // per CU: 2.5 TB/s); the strip arithmetic itself is ~0.4 us.
+  constexpr int PD = 3;
+  bf16x8 qn[PD], don[PD], on[PD];
+  float lsen[PD];
+  auto prefetch = [&](int s, int slot) {
+    const size_t row = (size_t)b * p.Lq + s * 16 + lq;
+    qn[slot] = *reinterpret_cast<const bf16x8*>(p.q + row * p.ldq + h * 32 + gq * 8);
+    don[slot] = *reinterpret_cast<const bf16x8*>(p.dout + row * p.lddo + h * 32 + gq * 8);
+    on[slot] = *reinterpret_cast<const bf16x8*>(p.o + row * p.ldo + h * 32 + gq * 8);
+    lsen[slot] = p.lse[row * p.H + h];
+  };
+#pragma unroll
+  for (int d = 0; d < PD; ++d) {
+    const int s = half + 2 * d;
+    prefetch(s < nstrips ? s : half, d);
+  }
+  for (int s = half; s < nstrips; s += 2) {
+    const bf16x8 qf = qn[0], dof = don[0], of = on[0];
+    const float lse2 = lsen[0] * 1.4426950408889634f;
+    const size_t row = (size_t)b * p.Lq + s * 16 + lq;
+#pragma unroll
+    for (int d = 0; d + 1 < PD; ++d) { qn[d] = qn[d + 1]; don[d] = don[d + 1]; on[d] = on[d + 1]; lsen[d] = lsen[d + 1]; }
+    { const int sn = s + 2 * PD; prefetch(sn < nstrips ? sn : s, PD - 1); }     // (past the end: a row that is resident anyway, never used)
+    // delta[query] = sum_d dO * O: the lane's 8-channel pieces, then the four lanes of the query
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    float dpart = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2)
+      dpart = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, bf16x2{dof[e], dof[e + 1]}), __builtin_bit_cast(bf16x2_t, bf16x2{of[e], of[e + 1]}), dpart, false);
+    const float dlt = rows4_sum(dpart);
+    // the strip's Q / dO rows and its per-query seeds for the lane = key orientation (wave-private LDS: in-order, no barrier)
+    *reinterpret_cast<bf16x8*>(Qst + lq * XRS + gq * 8) = qf;
+    *reinterpret_cast<bf16x8*>(dOst + lq * XRS + gq * 8) = dof;
+    if (gq == 0) { stat[lq] = -lse2 * inv_c2; stat[16 + lq] = -dlt; }
+    // ---- lane = query: S^T[key][query], dS^T -> dQ
+    f32x4 dsT[3];
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+      const f32x4 st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[kt], qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      const f32x4 dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[kt], dof, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      const f32x4 pr = exp2x4(__builtin_elementwise_fma(st, f32x4{c2, c2, c2, c2}, mkT[kt] - lse2));
+      dsT[kt] = pr * (dpt - dlt);
+    }
+    {
+      const bf16x8 d01 = pack8(dsT[0], dsT[1]), d2 = pack8(dsT[2], f32x4{0.f, 0.f, 0.f, 0.f});
+      f32x4 dq[2];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[dt][0], d01, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[dt][1], d2, dq[dt], 0, 0, 0);
+      }
+      *reinterpret_cast<u32x4*>(p.dq + row * p.lddq + h * 32 + gq * 8) = rows4_gather16(dq[0] * p.scale, dq[1] * p.scale);
+    }
+    // ---- lane = key: S[query][key], dS, P -> dK^T, dV^T (contraction over the strip's 16 queries)
+    const f32x4 seedL = *reinterpret_cast<const f32x4*>(stat + gq * 4), seedD = *reinterpret_cast<const f32x4*>(stat + 16 + gq * 4);
+    s16x4 qt[2], dot[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) { qt[dt] = tr16(Qst, dt * 16, gq, lq); dot[dt] = tr16(dOst, dt * 16, gq, lq); }
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+      const f32x4 sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kfr[kt], seedL, 0, 0, 0);       // q.k - lse / (scale log2e)
+      const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, vfr[kt], seedD, 0, 0, 0);      // dP - delta
+      const float mk = mkS[kt];
+      const f32x4 pr = exp2x4(__builtin_elementwise_fma(sv, f32x4{c2, c2, c2, c2}, f32x4{mk, mk, mk, mk}));
+      const s16x4 dsb = pack4(pr * dp), pb = pack4(pr);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        dkT[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qt[dt], dsb, dkT[kt][dt], 0, 0, 0);
+        dvT[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dot[dt], pb, dvT[kt][dt], 0, 0, 0);
+      }
+    }
+  }
+  // ---- fold the two halves of a head and write dK, dV: lane holds [key = kt*16 + lq][d = dt*16 + gq*4 .. +3]
+  f32x4* mine = red + (size_t)hl * 12 * 64 + lane;
+  if (half == 1) {
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) { mine[(kt * 2 + dt) * 64] = dkT[kt][dt]; mine[(6 + kt * 2 + dt) * 64] = dvT[kt][dt]; }
+  }
+  __syncthreads();
+  if (half == 0) {
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+      const int key = kt * 16 + lq;
+      if (key < p.Lk) {
+        const size_t row = (size_t)b * p.Lk + key;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const f32x4 a = (dkT[kt][dt] + mine[(kt * 2 + dt) * 64]) * p.scale, c = dvT[kt][dt] + mine[(6 + kt * 2 + dt) * 64];
+          bf16x4 ok, ov;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { ok[r] = f2bf(a[r]); ov[r] = f2bf(c[r]); }
+          *reinterpret_cast<bf16x4*>(p.dk + row * p.lddk + h * 32 + dt * 16 + gq * 4) = ok;
+          *reinterpret_cast<bf16x4*>(p.dv + row * p.lddv + h * 32 + dt * 16 + gq * 4) = ov;
+        }
+      }
+    }
+  }
+}
+
+bool x_attr = false;
+
+}  // namespace
+
+// One-pass backward of image -> text cross attention; returns FIBER_EINVAL when the shape is not served (the caller then runs the generic
+// passes).  Arguments as fiber_mha_bwd_bf16 (attn.hip); no attention dropout.
+int fiber_i2t_bwd_launch(const void* q, const void* k, const void* v, const float* kmask, const void* o, const void* dout, const float* lse,
+                         void* dq, void* dk, void* dv, int B, int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, int lddo,
+                         int lddq, int lddk, int lddv, float scale, hipStream_t st) {
+  if (Lk > 48 || Lk <= 0 || (Lq & 15) || (heads & 3) || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 7) || (lddo & 7) || (lddq & 7) || (lddk & 3) ||
+      (lddv & 3) || scale <= 0.f)
+    return FIBER_EINVAL;
+  if (!x_attr) { hipFuncSetAttribute((const void*)i2t_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); x_attr = true; }
+  XP p;
+  p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.o = (const bf16*)o; p.dout = (const bf16*)dout;
+  p.dq = (bf16*)dq; p.dk = (bf16*)dk; p.dv = (bf16*)dv; p.lse = lse; p.kmask = kmask;
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
+  p.H = heads; p.Lq = Lq; p.Lk = Lk; p.G = B; p.scale = scale;
+  hipLaunchKernelGGL(i2t_bwd_kernel, dim3(B, heads / 4), dim3(512), X_SMEM, st, p);
+  FIBER_CHECK_LAUNCH();
+  return FIBER_OK;
+}

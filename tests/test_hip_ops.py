@@ -333,6 +333,10 @@ def _mha_ref(q, k, v, kmask, B, heads, scale):
     (2, 32, 144, 40, 32, True), (2, 12, 40, 144, 64, False), (1, 2, 9, 6, 32, True), (2, 4, 50, 324, 64, False),
     # many (head, sample) pairs: the single-chunk key side is staged once per workgroup, which then walks several query strips
     (48, 16, 576, 40, 32, True), (64, 12, 200, 40, 64, True),
+    # the one-pass image -> text backward (attn_x.hip: head_dim 32, <= 48 keys, Lq % 16 == 0, heads % 4 == 0): key-count edges, no mask;
+    # and its neighbours that must fall back to the generic passes (49 keys; 3 heads; a ragged last strip)
+    (2, 8, 64, 48, 32, False), (3, 4, 32, 17, 32, True), (2, 4, 16, 2, 32, False), (2, 4, 64, 49, 32, True), (2, 3, 64, 40, 32, True),
+    (2, 4, 72, 40, 32, True),
 ])
 def test_mha(ops, B, heads, Lq, Lk, D, masked):
     C = heads * D
