@@ -226,8 +226,13 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
   bf16* Ks = S.a0; bf16* Vs = S.a1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gq = lane >> 4, lq = lane & 15;
-  const int h = blockIdx.y, C = p.C, ld = 3 * C;
-  const int qo = chan_q(p, h), ko = chan_k(p, h), vo = chan_v(p, h);
+  const int h = blockIdx.y, C = p.C;
+  // layout 3 = planar: [3 * heads planes][token][32] -- a window row of a head is ONE 768-byte run (tools/probes/run_probe.hip)
+  const bool planar = p.hmajor == 3;
+  const size_t pl = (size_t)p.B * p.Hres * p.Wres * 32;
+  const int ld = planar ? 32 : 3 * C, ldo = planar ? 32 : C;
+  const size_t qo = planar ? h * pl : (size_t)chan_q(p, h), ko = planar ? (p.heads + h) * pl : (size_t)chan_k(p, h),
+               vo = planar ? (2 * p.heads + h) * pl : (size_t)chan_v(p, h), oo = planar ? h * pl : (size_t)h * 32;
   // compile-time for the 12x12 window (guards fold, the 10th tile's code disappears) and for the 21-tile variant (18x18
   // windows fill it; padded tiles of smaller windows carry bias = -inf and zero rows, so running them is only wasted work)
   const int ntile = NTC ? NTC : MT > 10 ? MT : (p.N + 15) >> 4;
@@ -291,11 +296,11 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
       if (sval[c]) {
         const unsigned sc = (tid + c * blockDim.x) & 3;
         const unsigned st = geo.pix(p, spr[c], spc[c]) * ld + sc * 8;
-        kr[c] = *reinterpret_cast<const bf16x8*>(at(base, st + ko));
-        vr[c] = *reinterpret_cast<const bf16x8*>(at(base, st + vo));
+        kr[c] = *reinterpret_cast<const bf16x8*>(at(base + ko, st));
+        vr[c] = *reinterpret_cast<const bf16x8*>(at(base + vo, st));
       }
     }
-    qn = *reinterpret_cast<const bf16x8*>(at(base, qpix * ld + qo + gq * 8));
+    qn = *reinterpret_cast<const bf16x8*>(at(base + qo, qpix * ld + gq * 8));
   };
   prefetch();
 #ifdef FIBER_WIN_TRACE      // tools/win_trace.py fwd: s_memtime ticks per segment and wave into g_win_trace
@@ -424,7 +429,7 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
         bf16x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = f2bf(oacc[dt][r] * inv);
-        *reinterpret_cast<bf16x4*>(at(p.o + oimg * C, opix * C + h * 32 + dt * 16 + gq * 4)) = o;
+        *reinterpret_cast<bf16x4*>(at(p.o + oo + oimg * ldo, opix * ldo + dt * 16 + gq * 4)) = o;
       }
       if (gq == 0) *at(p.lse + oimg * p.heads + (size_t)h * p.Hres * p.Wres, opix) = mx * scale + __logf(sum);
     }
@@ -902,8 +907,13 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
   f32x4* cs_small = db_lds + NL * NTH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gq = lane >> 4, lq = lane & 15;
-  const int h = blockIdx.y, C = p.C, ld = 3 * C;
-  const int qo = chan_q(p, h), ko = chan_k(p, h), vo = chan_v(p, h);
+  const int h = blockIdx.y, C = p.C;
+  // layout 3 = planar [3 * heads planes][token][32] for qkv / dqkv and [heads planes][token][32] for o / dout (see win_fwd_kernel)
+  const bool planar = p.hmajor == 3;
+  const size_t pl = (size_t)p.B * p.Hres * p.Wres * 32;
+  const int ld = planar ? 32 : 3 * C, ldo = planar ? 32 : C;
+  const size_t qo = planar ? h * pl : (size_t)chan_q(p, h), ko = planar ? (p.heads + h) * pl : (size_t)chan_k(p, h),
+               vo = planar ? (2 * p.heads + h) * pl : (size_t)chan_v(p, h), oo = planar ? h * pl : (size_t)h * 32;
   setup<10>(p, S, h, nb, 0, 1.4426950408889634f, -INFINITY);
   {                                                      // zero the three images once: rows 144..159 (tile 9) are never staged
     uint32_t* z = reinterpret_cast<uint32_t*>(Qs);
@@ -955,12 +965,12 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
   auto prefetch = [&]() {
     const bf16* base = p.qkv + kimg * ld;
     const unsigned st = geo.pix(p, spr, spc);
-    qr = *reinterpret_cast<const bf16x8*>(at(base, st * ld + qo + sc * 8));
-    kr = *reinterpret_cast<const bf16x8*>(at(base, st * ld + ko + sc * 8));
-    dr = *reinterpret_cast<const bf16x8*>(at(p.dout + kimg * C, st * C + h * 32 + sc * 8));
-    orr = *reinterpret_cast<const bf16x8*>(at(static_cast<const bf16*>(p.o) + kimg * C, st * C + h * 32 + sc * 8));
+    qr = *reinterpret_cast<const bf16x8*>(at(base + qo, st * ld + sc * 8));
+    kr = *reinterpret_cast<const bf16x8*>(at(base + ko, st * ld + sc * 8));
+    dr = *reinterpret_cast<const bf16x8*>(at(p.dout + oo + kimg * ldo, st * ldo + sc * 8));
+    orr = *reinterpret_cast<const bf16x8*>(at(static_cast<const bf16*>(p.o) + oo + kimg * ldo, st * ldo + sc * 8));
     if (sc == 0) lser = *at(p.lse + kimg * p.heads + (size_t)h * p.Hres * p.Wres, st);
-    vn = *reinterpret_cast<const bf16x8*>(at(base, kpix * ld + vo + gq * 8));
+    vn = *reinterpret_cast<const bf16x8*>(at(base + vo, kpix * ld + gq * 8));
   };
   prefetch();
   // TRACE build (-DFIBER_WIN_TRACE, tools/win_trace.py): s_memtime ticks per segment and wave, summed over the windows of the run, written
@@ -1096,8 +1106,8 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
       bf16x4 ok, ov;
 #pragma unroll
       for (int r = 0; r < 4; ++r) { ok[r] = f2bf(dkacc[dt][r] * scale); ov[r] = f2bf(dvacc[dt][r]); }
-      *reinterpret_cast<bf16x4*>(at(p.dqkv + oimg * ld, opix * ld + ko + dt * 16 + gq * 4)) = ok;
-      *reinterpret_cast<bf16x4*>(at(p.dqkv + oimg * ld, opix * ld + vo + dt * 16 + gq * 4)) = ov;
+      *reinterpret_cast<bf16x4*>(at(p.dqkv + ko + oimg * ld, opix * ld + dt * 16 + gq * 4)) = ok;
+      *reinterpret_cast<bf16x4*>(at(p.dqkv + vo + oimg * ld, opix * ld + dt * 16 + gq * 4)) = ov;
     }
     if (p.colsum_part) {
       const f32x4 s0 = lane16_sum(dkacc[0] * scale), s1 = lane16_sum(dkacc[1] * scale), s2 = lane16_sum(dvacc[0]), s3 = lane16_sum(dvacc[1]);
@@ -1125,7 +1135,7 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
       bf16x4 o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[r] = f2bf(dqacc[dt][r] * scale);
-      *reinterpret_cast<bf16x4*>(at(p.dqkv + oimg * ld, opix * ld + qo + dt * 16 + gq * 4)) = o;
+      *reinterpret_cast<bf16x4*>(at(p.dqkv + qo + oimg * ld, opix * ld + dt * 16 + gq * 4)) = o;
     }
     if (p.colsum_part) {
       const f32x4 s0 = lane16_sum(dqacc[0] * scale), s1 = lane16_sum(dqacc[1] * scale);
@@ -1156,7 +1166,7 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
       const int grp = tid >> 5, c = tid & 31;
       float sum = 0.f;
       for (int w = 0; w < 9; ++w) sum += cs_small[(w * 4 + ((c >> 2) & 3)) * 6 + grp * 2 + (c >> 4)][c & 3];
-      const int chan0 = grp == 0 ? qo : grp == 1 ? ko : vo;
+      const int chan0 = planar ? grp * C + h * 32 : (int)(grp == 0 ? qo : grp == 1 ? ko : vo);   // planar: sums in the reference channel order
       p.colsum_part[(size_t)blockIdx.x * 3 * C + chan0 + c] = sum;
     }
   }
