@@ -818,6 +818,10 @@ int fiber_win_colsum_rows(int n_windows, int heads, int N);
 int fiber_i2t_bwd_launch(const void* q, const void* k, const void* v, const float* kmask, const void* o, const void* dout, const float* lse,
                          void* dq, void* dk, void* dv, int B, int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, int lddo,
                          int lddq, int lddk, int lddv, float scale, hipStream_t st);
+// the same for head_dim 64 and at most 48 queries (text -> image cross attention, text self attention), dropout included
+int fiber_t2i_bwd_launch(const void* q, const void* k, const void* v, const float* kmask, const void* o, const void* dout, const float* lse,
+                         void* dq, void* dk, void* dv, int B, int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, int lddo,
+                         int lddq, int lddk, int lddv, float scale, float p_drop, uint64_t seed, const uint64_t* seed_base, hipStream_t st);
 
 // --------------------------------------------------------------------------------------------------- C ABI
 // Window attention in image-token order.  qkv: [B*Hres*Wres, 3C] bf16 with channel layout [3][heads][32]
@@ -902,6 +906,13 @@ extern "C" int fiber_mha_bwd_bf16(const void* q, const void* k, const void* v, c
   if (onepass && D == 32 && Lk <= 48 && p_drop == 0.f && (Lq & 15) == 0 && (heads & 3) == 0 && !(lddq & 7)) {
     const int rc = fiber_i2t_bwd_launch(q, k, v, kmask, o, dout, lse, dq, dk, dv, B, heads, Lq, Lk, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv,
                                         scale, stream);
+    if (rc != FIBER_EINVAL) return rc;
+  }
+  // few queries, head_dim 64 (text -> image cross attention, text self attention): one pass with Q / dO in registers
+  static const int onepass_t = getenv("FIBER_ATTN_T2I_ONEPASS") ? atoi(getenv("FIBER_ATTN_T2I_ONEPASS")) : 1;
+  if (onepass_t && D == 64 && Lq <= 48) {
+    const int rc = fiber_t2i_bwd_launch(q, k, v, kmask, o, dout, lse, dq, dk, dv, B, heads, Lq, Lk, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv,
+                                        scale, p_drop, seed, seed_base, stream);
     if (rc != FIBER_EINVAL) return rc;
   }
   ensure_attrs();

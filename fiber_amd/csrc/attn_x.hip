@@ -240,6 +240,237 @@ __global__ __launch_bounds__(512) void i2t_bwd_kernel(XP p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Text -> image cross attention (roberta.py:256-326 with encoder_hidden_states = image tokens, 474-483) and text self attention, backward
+// in ONE pass: head_dim 64, at most 48 QUERIES (40 text tokens), any number of keys (576 / 144 image tokens, 40 text tokens).
+//
+// The generic passes read K and V twice (once per pass) plus q / dO per key strip: 40 x 576 x d64 ran at 2.1 TB/s of its algorithmic
+// bytes (0.26 of the floor).  Here the roles of attn_x's i2t kernel are mirrored: the QUERY side is the small one, so Q and dO of a
+// (sample, head) live in registers (MFMA operands) and as LDS images (for the transposed operands), dQ accumulates in registers, and a
+// wave streams 16-key tiles ONCE: K / V rows are loaded straight into MFMA operand registers (a lane = 16 bytes of a key row), two tiles
+// ahead; per tile
+//   S^T[key][query] = K Q^T, dP^T = V dO^T                 (lane = query: 12 MFMAs K = 32)
+//   P, dropout (the forward's (row, key) hash), dS^T        (VALU, once -- the lane = key orientation is NOT recomputed: with dropout the
+//                                                           VALU is the scarce pipe; P^T / dS^T go through a wave-private 3-KB LDS slab as
+//                                                           [query][key] rows and come back transposed by ds_read_b64_tr_b16)
+//   dQ^T[d][query] += K^T dS^T                              (K^T: transposed read of the tile's wave-private LDS image; 12 MFMAs K = 16)
+//   dK^T[d][key] = Q^T dS, dV^T[d][key] = dO^T P_dropped    (contraction over the 48 queries: 24 MFMAs K = 16) -> 16-byte stores
+// No barrier inside the tile loop; a workgroup = one (sample, head) = 4 waves taking every fourth tile; the four dQ partials are summed
+// in a fixed order through LDS at the end (deterministic).
+constexpr int TRS = 80;                                  // LDS row stride of the [row][64] images: 64 + 16 pad (as attn.hip's D + 16)
+constexpr int T_IMG = 48 * TRS * 2;                      // Q (or dO) image
+constexpr int T_KT = 16 * TRS * 2;                       // one wave's K tile image
+constexpr int T_SLAB = 2 * 3 * 512;                      // one wave's P^T / dS^T slab: [tensor][query tile][16 queries][16 keys]
+constexpr int T_MAXK = 1024;                             // keys served (the additive key mask of a sample is tabulated in LDS)
+constexpr int T_FIX = 2 * T_IMG + 2 * 48 * 4 + 4 * T_KT + 4 * T_SLAB;    // 38,272 B; reused as 3 x 12 KB of dQ partials at the end
+constexpr int T_SMEM = T_FIX + T_MAXK * 4;
+static_assert(3 * 12 * 64 * 16 <= T_FIX, "dQ partials must fit the reused LDS");
+
+struct TP {
+  const bf16* q; const bf16* k; const bf16* v; const bf16* o; const bf16* dout;
+  bf16* dq; bf16* dk; bf16* dv;
+  const float* lse; const float* kmask;
+  int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+  int H, Lq, Lk;
+  float scale, p_drop; uint64_t seed; const uint64_t* seed_base;
+};
+__device__ __forceinline__ s16x4 tr16s(const bf16* rm, int stride, int d0, int g, int l) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(rm + (g * 4 + (l >> 2)) * stride + d0 + (l & 3) * 4));
+}
+
+template <typename T>
+__device__ __forceinline__ T* atx(T* base, unsigned elem_off) {        // wave-uniform 64-bit base + 32-bit per-lane offset (win_attn.hip at())
+  using C = std::conditional_t<std::is_const<T>::value, const char, char>;
+  return reinterpret_cast<T*>(reinterpret_cast<C*>(base) + elem_off * (unsigned)sizeof(T));
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(256, 2) void t2i_bwd_kernel(TP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* Qs = reinterpret_cast<bf16*>(smem);
+  bf16* dOs = reinterpret_cast<bf16*>(smem + T_IMG);
+  float* st_lse = reinterpret_cast<float*>(smem + 2 * T_IMG);
+  float* st_dlt = st_lse + 48;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int gq = lane >> 4, lq = lane & 15;
+  const int b = blockIdx.x, h = blockIdx.y;
+  bf16* Kt = reinterpret_cast<bf16*>(smem + 2 * T_IMG + 2 * 48 * 4 + wave * T_KT);
+  bf16* slabP = reinterpret_cast<bf16*>(smem + 2 * T_IMG + 2 * 48 * 4 + 4 * T_KT + wave * T_SLAB);
+  bf16* slabS = slabP + 3 * 256;
+  float* mkl = reinterpret_cast<float*>(smem + T_FIX);
+  for (int j = tid; j < ((p.Lk + 15) & ~15); j += 256)   // additive key mask in the log2 domain, -inf past Lk
+    mkl[j] = j < p.Lk ? (p.kmask ? p.kmask[(size_t)b * p.Lk + j] * 1.4426950408889634f : 0.f) : -INFINITY;
+  // ---- Q, dO images (rows >= Lq zero), delta = rowsum(dO . O), lse in the log2 domain (+inf past Lq: p = 0 there)
+  for (int idx = tid; idx < 48 * 8; idx += 256) {
+    const int r = idx >> 3, c = idx & 7;
+    bf16x8 qv, dv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { qv[e] = f2bf(0.f); dv[e] = f2bf(0.f); }
+    float dpart = 0.f;
+    const size_t row = (size_t)b * p.Lq + (r < p.Lq ? r : 0);
+    if (r < p.Lq) {
+      qv = *reinterpret_cast<const bf16x8*>(p.q + row * p.ldq + h * 64 + c * 8);
+      dv = *reinterpret_cast<const bf16x8*>(p.dout + row * p.lddo + h * 64 + c * 8);
+      const bf16x8 ov = *reinterpret_cast<const bf16x8*>(p.o + row * p.ldo + h * 64 + c * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dpart += bf2f(dv[e]) * bf2f(ov[e]);
+    }
+    *reinterpret_cast<bf16x8*>(Qs + r * TRS + c * 8) = qv;
+    *reinterpret_cast<bf16x8*>(dOs + r * TRS + c * 8) = dv;
+    dpart += __shfl_xor(dpart, 1); dpart += __shfl_xor(dpart, 2); dpart += __shfl_xor(dpart, 4);
+    if (c == 0) { st_dlt[r] = dpart; st_lse[r] = r < p.Lq ? p.lse[row * p.H + h] * 1.4426950408889634f : INFINITY; }
+  }
+  __syncthreads();
+  bf16x8 qf[3][2], dof[3][2];
+  float lse2[3], dlt[3];
+#pragma unroll
+  for (int qt = 0; qt < 3; ++qt) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      qf[qt][ks] = *reinterpret_cast<const bf16x8*>(Qs + (qt * 16 + lq) * TRS + ks * 32 + gq * 8);
+      dof[qt][ks] = *reinterpret_cast<const bf16x8*>(dOs + (qt * 16 + lq) * TRS + ks * 32 + gq * 8);
+    }
+    lse2[qt] = st_lse[qt * 16 + lq]; dlt[qt] = st_dlt[qt * 16 + lq];
+  }
+  f32x4 dqT[4][3];                                       // dQ^T[d = dt*16 + gq*4 + r][query = qt*16 + lq], this wave's key tiles
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int qt = 0; qt < 3; ++qt) dqT[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float c2 = p.scale * 1.4426950408889634f;
+  const uint32_t thresh = DROP ? (uint32_t)((double)p.p_drop * 4294967296.0) : 0u;
+  const uint32_t dseed = DROP ? drop_seed32(p.seed + (p.seed_base ? *p.seed_base : 0ull)) : 0u;
+  const float inv_keep = DROP ? 1.f / (1.f - p.p_drop) : 1.f;
+  const uint32_t drow = (uint32_t)((b * p.H + h) * p.Lq);
+
+  const int ntiles = (p.Lk + 15) >> 4;
+  // K / V rows of a key tile go straight into MFMA operand registers (a lane = 16 bytes of key row kt*16 + lq).  ONE register set: the next
+  // tile is requested as soon as this tile's first MFMAs have read the set, and the PREVIOUS tile's dK / dV rows (held packed in 16
+  // registers) are stored at the same point, so when the loop comes round the only outstanding memory operations are a body old and the
+  // compiler's vmcnt(0) costs nothing.  (A rotating queue of register sets made it wait for the NEWEST request at the top of every
+  // iteration -- 20 k cycles per tile; stores at the end of the body made every iteration wait for its own stores.)
+  const bf16* kbase = p.k + (size_t)b * p.Lk * p.ldk + h * 64 + gq * 8;
+  const bf16* vbase = p.v + (size_t)b * p.Lk * p.ldv + h * 64 + gq * 8;
+  bf16* dkbase = p.dk + (size_t)b * p.Lk * p.lddk + h * 64 + gq * 8;
+  bf16* dvbase = p.dv + (size_t)b * p.Lk * p.lddv + h * 64 + gq * 8;
+  bf16x8 kk[2], vv[2];
+  auto request = [&](int kt) {
+    const unsigned r = (unsigned)min(kt * 16 + lq, p.Lk - 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      kk[ks] = *reinterpret_cast<const bf16x8*>(atx(kbase, r * (unsigned)p.ldk + ks * 32));
+      vv[ks] = *reinterpret_cast<const bf16x8*>(atx(vbase, r * (unsigned)p.ldv + ks * 32));
+    }
+  };
+  u32x4 wk[2], wv[2];                                    // the previous tile's dK / dV rows (16 bytes per lane and half)
+  auto flush = [&](int kt) {
+    const int key = kt * 16 + lq;
+    if (key < p.Lk) {
+#pragma unroll
+      for (int hp = 0; hp < 2; ++hp) {
+        *reinterpret_cast<u32x4*>(atx(dkbase, (unsigned)key * (unsigned)p.lddk + hp * 32)) = wk[hp];
+        *reinterpret_cast<u32x4*>(atx(dvbase, (unsigned)key * (unsigned)p.lddv + hp * 32)) = wv[hp];
+      }
+    }
+  };
+  if (wave < ntiles) request(wave);
+  for (int kt = wave; kt < ntiles; kt += 4) {
+    const bf16x8 kf[2] = {kk[0], kk[1]}, vf[2] = {vv[0], vv[1]};
+    // the tile's K rows as a wave-private image for the transposed operand of dQ (in-order LDS: no barrier)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) *reinterpret_cast<bf16x8*>(Kt + lq * TRS + ks * 32 + gq * 8) = kf[ks];
+    const f32x4 mk = *reinterpret_cast<const f32x4*>(mkl + kt * 16 + gq * 4);   // additive key mask (log2 domain); -inf past Lk
+    f32x4 st[3], dp[3];
+#pragma unroll
+    for (int qt = 0; qt < 3; ++qt) {
+      st[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0], qf[qt][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      st[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1], qf[qt][1], st[qt], 0, 0, 0);
+      dp[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[0], dof[qt][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      dp[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[1], dof[qt][1], dp[qt], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt != wave) flush(kt - 4);
+    request(kt + 4 < ntiles ? kt + 4 : kt);              // (past the end: rows that are resident anyway, never used)
+    __builtin_amdgcn_sched_barrier(0);
+    s16x4 dsb[3];
+#pragma unroll
+    for (int qt = 0; qt < 3; ++qt) {
+      const float nl = -lse2[qt];
+      const f32x4 pr = exp2x4(__builtin_elementwise_fma(st[qt], f32x4{c2, c2, c2, c2}, mk + nl));
+      f32x4 prd = pr, dpe = dp[qt];
+      if constexpr (DROP) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool keep = drop_keep_rk(dseed, drow + (uint32_t)min(qt * 16 + lq, p.Lq - 1), (uint32_t)(kt * 16 + gq * 4 + r), thresh);
+          dpe[r] = keep ? dpe[r] * inv_keep : 0.f;
+          prd[r] = keep ? pr[r] * inv_keep : 0.f;
+        }
+      }
+      const float dl = dlt[qt];
+      dsb[qt] = pack4(pr * (dpe - dl));
+      *reinterpret_cast<s16x4*>(slabP + qt * 256 + lq * 16 + gq * 4) = pack4(prd);
+      *reinterpret_cast<s16x4*>(slabS + qt * 256 + lq * 16 + gq * 4) = dsb[qt];
+    }
+    // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const s16x4 ktT = tr16s(Kt, TRS, dt * 16, gq, lq);
+#pragma unroll
+      for (int qt = 0; qt < 3; ++qt) dqT[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ktT, dsb[qt], dqT[dt][qt], 0, 0, 0);
+    }
+    // dK^T[d][key] = sum_q Q^T[d][q] dS[q][key];  dV^T[d][key] = sum_q dO^T[d][q] P_dropped[q][key]
+    s16x4 pB[3], dB[3];
+#pragma unroll
+    for (int qt = 0; qt < 3; ++qt) { pB[qt] = tr16s(slabP + qt * 256, 16, 0, gq, lq); dB[qt] = tr16s(slabS + qt * 256, 16, 0, gq, lq); }
+    f32x4 dkT[4], dvT[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      dkT[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvT[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int qt = 0; qt < 3; ++qt) {
+        dkT[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(tr16s(Qs + qt * 16 * TRS, TRS, dt * 16, gq, lq), dB[qt], dkT[dt], 0, 0, 0);
+        dvT[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(tr16s(dOs + qt * 16 * TRS, TRS, dt * 16, gq, lq), pB[qt], dvT[dt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int hp = 0; hp < 2; ++hp) {                     // (the permlane swaps run with every lane active; only the stores are guarded)
+      wk[hp] = rows4_gather16(dkT[2 * hp] * p.scale, dkT[2 * hp + 1] * p.scale);
+      wv[hp] = rows4_gather16(dvT[2 * hp], dvT[2 * hp + 1]);
+    }
+  }
+  if (wave < ntiles) flush(wave + ((ntiles - 1 - wave) >> 2) * 4);
+  // ---- dQ: waves 1..3 park their partials in the (now dead) LDS, wave 0 adds them in a fixed order and writes
+  __syncthreads();
+  f32x4* red = reinterpret_cast<f32x4*>(smem);
+  if (wave > 0) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int qt = 0; qt < 3; ++qt) red[((wave - 1) * 12 + dt * 3 + qt) * 64 + lane] = dqT[dt][qt];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int qt = 0; qt < 3; ++qt)
+#pragma unroll
+        for (int w = 0; w < 3; ++w) dqT[dt][qt] += red[(w * 12 + dt * 3 + qt) * 64 + lane];
+#pragma unroll
+    for (int qt = 0; qt < 3; ++qt) {
+      const int qi = qt * 16 + lq;
+      const size_t row = (size_t)b * p.Lq + min(qi, p.Lq - 1);
+#pragma unroll
+      for (int hp = 0; hp < 2; ++hp) {
+        const u32x4 w = rows4_gather16(dqT[2 * hp][qt] * p.scale, dqT[2 * hp + 1][qt] * p.scale);
+        if (qi < p.Lq) *reinterpret_cast<u32x4*>(p.dq + row * p.lddq + h * 64 + hp * 32 + gq * 8) = w;
+      }
+    }
+  }
+}
+
 bool x_attr = false;
 
 }  // namespace
@@ -259,6 +490,24 @@ int fiber_i2t_bwd_launch(const void* q, const void* k, const void* v, const floa
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
   p.H = heads; p.Lq = Lq; p.Lk = Lk; p.G = B; p.scale = scale;
   hipLaunchKernelGGL(i2t_bwd_kernel, dim3(B, heads / 4), dim3(512), X_SMEM, st, p);
+  FIBER_CHECK_LAUNCH();
+  return FIBER_OK;
+}
+
+// One-pass backward for head_dim 64 and at most 48 queries (text -> image cross attention, text self attention), attention dropout
+// included; FIBER_EINVAL when the shape is not served.
+int fiber_t2i_bwd_launch(const void* q, const void* k, const void* v, const float* kmask, const void* o, const void* dout, const float* lse,
+                         void* dq, void* dk, void* dv, int B, int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, int lddo,
+                         int lddq, int lddk, int lddv, float scale, float p_drop, uint64_t seed, const uint64_t* seed_base, hipStream_t st) {
+  if (Lq > 48 || Lq <= 0 || Lk <= 0 || Lk > T_MAXK || (size_t)Lk * (size_t)(ldk | ldv | lddk | lddv) >= (1u << 30) || ((ldq | ldk | ldv | ldo | lddo | lddq | lddk | lddv) & 7) || scale <= 0.f || p_drop < 0.f || p_drop >= 1.f)
+    return FIBER_EINVAL;
+  TP p;
+  p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.o = (const bf16*)o; p.dout = (const bf16*)dout;
+  p.dq = (bf16*)dq; p.dk = (bf16*)dk; p.dv = (bf16*)dv; p.lse = lse; p.kmask = kmask;
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
+  p.H = heads; p.Lq = Lq; p.Lk = Lk; p.scale = scale; p.p_drop = p_drop; p.seed = seed; p.seed_base = seed_base;
+  if (p_drop > 0.f) hipLaunchKernelGGL(t2i_bwd_kernel<true>, dim3(B, heads), dim3(256), T_SMEM, st, p);
+  else hipLaunchKernelGGL(t2i_bwd_kernel<false>, dim3(B, heads), dim3(256), T_SMEM, st, p);
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }

@@ -5,6 +5,8 @@ Tolerances (bf16 compute vs fp32 reference): single block rel-L2 <= 1e-2; full f
 (the reference's own bf16-autocast run deviates 1.3e-2 / 4e-3); losses +-2e-2 absolute here
 (random-init logits, bf16 50k-way vocabulary GEMM), gradient tensors rel-L2 <= 6e-2."""
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -590,6 +592,8 @@ def test_loss_curve_swin_t_224_mlm_itm_50_steps():
     assert summary["gap_max"] < 1.6e-2 and summary["gap_median"] < 4.5e-3, summary
 
 
+@pytest.mark.skipif(os.environ.get("FIBER_SLOW_TESTS", "0") != "1", reason="duplicates the bf16-stream curve above and tools/loss_curve_study.py "
+                    "(~100 s of oracle time on the host cores); run with FIBER_SLOW_TESTS=1")
 def test_loss_curve_swin_t_224_fp32_residual_stream():
     """The same 50-step curve with config["residual_dtype"] = "fp32" (the round-2 review's item 1).  What the mode can and cannot
     do was measured on the oracle first (oracle/precision_study.py, profiles/r03_precision_study_curve_swin_t.json, this very

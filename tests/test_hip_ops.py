@@ -337,6 +337,9 @@ def _mha_ref(q, k, v, kmask, B, heads, scale):
     # and its neighbours that must fall back to the generic passes (49 keys; 3 heads; a ragged last strip)
     (2, 8, 64, 48, 32, False), (3, 4, 32, 17, 32, True), (2, 4, 16, 2, 32, False), (2, 4, 64, 49, 32, True), (2, 3, 64, 40, 32, True),
     (2, 4, 72, 40, 32, True),
+    # the one-pass backward for few queries at head_dim 64 (attn_x.hip t2i_bwd_kernel: Lq <= 48; text -> image cross attention, text self
+    # attention): ragged key / query counts, masks, a key count that leaves waves without a tile; 49 queries fall back to the generic passes
+    (3, 12, 40, 576, 64, True), (2, 2, 48, 33, 64, True), (2, 3, 7, 100, 64, False), (2, 12, 40, 40, 64, True), (1, 1, 49, 64, 64, False),
 ])
 def test_mha(ops, B, heads, Lq, Lk, D, masked):
     C = heads * D
@@ -395,28 +398,32 @@ def test_mha_dropout_adjoint(ops):
     assert rel_l2(acc / n, base) < 0.08
 
 
-def test_mha_dropout_mask_is_the_same_in_all_three_passes(ops):
-    """The keep mask is recomputed from (seed, row, key) in the forward, the dQ pass and the dK/dV pass.  Recover it from a forward with
-    one-hot value rows (o[i, head, j] = P[i, j] * keep[i, j] / (1 - p)), then check dq / dk / dv of a real problem against torch autograd
-    through softmax * mask."""
-    B, heads, L, D, p = 2, 12, 40, 64, 0.1
+@pytest.mark.parametrize("Lq,Lk", [(40, 40), (40, 144), (33, 100), (64, 40)])
+def test_mha_dropout_mask_is_the_same_in_all_three_passes(ops, Lq, Lk):
+    """The keep mask is recomputed from (seed, row, key) in the forward and in the backward (one pass for <= 48 queries, else a dQ pass and a
+    dK/dV pass).  Recover it from forwards with one-hot value rows (o[i, head, j] = P[i, j] * keep[i, j] / (1 - p); 64 keys per forward), then
+    check dq / dk / dv of a real problem against torch autograd through softmax * mask."""
+    B, heads, D, p = 2, 12, 64, 0.1
     C = heads * D
-    q, k, v = (bf(rnd(B * L, C, seed=s)).requires_grad_(True) for s in (0, 1, 2))
+    q, k, v = (bf(rnd(B * L, C, seed=s)).requires_grad_(True) for L, s in ((Lq, 0), (Lk, 1), (Lk, 2)))
     from fiber_amd.ops import _MHA
-    eye = torch.zeros(B, L, heads, D, device=q.device)
-    eye[:, torch.arange(L), :, torch.arange(L)] = 1.0                      # value row j = e_j in every head
-    probe = _MHA.apply(q.detach(), k.detach(), bf(eye.view(B * L, C)), None, B, heads, D ** -0.5, p, 4321)
-    keep = (probe.view(B, L, heads, D)[..., :L] != 0).permute(0, 2, 1, 3).float()          # [B, heads, Lq, Lk]
+    keep = torch.zeros(B, heads, Lq, Lk, device=q.device)
+    for c0 in range(0, Lk, D):
+        n = min(D, Lk - c0)
+        eye = torch.zeros(B, Lk, heads, D, device=q.device)
+        eye[:, c0 + torch.arange(n), :, torch.arange(n)] = 1.0              # value row j = e_(j - c0) in every head
+        probe = _MHA.apply(q.detach(), k.detach(), bf(eye.view(B * Lk, C)), None, B, heads, D ** -0.5, p, 4321)
+        keep[..., c0:c0 + n] = (probe.view(B, Lq, heads, D)[..., :n] != 0).permute(0, 2, 1, 3).float()
     assert 0.85 < keep.mean().item() < 0.95
     o = _MHA.apply(q, k, v, None, B, heads, D ** -0.5, p, 4321)
-    do = bf(rnd(B * L, C, seed=3))
+    do = bf(rnd(B * Lq, C, seed=3))
     o.backward(do)
-    qr, kr, vr = (t.detach().float().view(B, L, heads, D).permute(0, 2, 1, 3).requires_grad_(True) for t in (q, k, v))
+    qr, kr, vr = (t.detach().float().view(B, L, heads, D).permute(0, 2, 1, 3).requires_grad_(True) for t, L in ((q, Lq), (k, Lk), (v, Lk)))
     pr = torch.softmax(qr @ kr.transpose(-1, -2) * D ** -0.5, -1) * keep / (1 - p)
-    oref = (pr @ vr).permute(0, 2, 1, 3).reshape(B * L, C)
+    oref = (pr @ vr).permute(0, 2, 1, 3).reshape(B * Lq, C)
     oref.backward(do.float())
     assert_close("o", o, oref, 1e-2)
-    for name, got, ref in (("dq", q.grad, qr.grad), ("dk", k.grad, kr.grad), ("dv", v.grad, vr.grad)):
+    for name, got, ref, L in (("dq", q.grad, qr.grad, Lq), ("dk", k.grad, kr.grad, Lk), ("dv", v.grad, vr.grad, Lk)):
         assert_close(name, got, ref.permute(0, 2, 1, 3).reshape(B * L, C), 2e-2)
 
 
