@@ -822,6 +822,10 @@ int fiber_i2t_bwd_launch(const void* q, const void* k, const void* v, const floa
 int fiber_t2i_bwd_launch(const void* q, const void* k, const void* v, const float* kmask, const void* o, const void* dout, const float* lse,
                          void* dq, void* dk, void* dv, int B, int heads, int Lq, int Lk, int ldq, int ldk, int ldv, int ldo, int lddo,
                          int lddq, int lddk, int lddv, float scale, float p_drop, uint64_t seed, const uint64_t* seed_base, hipStream_t st);
+int fiber_t2i_fwd_launch(const void* q, const void* k, const void* v, const float* kmask, void* o, float* lse, int B, int heads, int Lq, int Lk,
+                         int ldq, int ldk, int ldv, int ldo, float scale, float p_drop, uint64_t seed, const uint64_t* seed_base, hipStream_t st);
+int fiber_i2t_fwd_launch(const void* q, const void* k, const void* v, const float* kmask, void* o, float* lse, int B, int heads, int Lq, int Lk,
+                         int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st);
 
 // --------------------------------------------------------------------------------------------------- C ABI
 // Window attention in image-token order.  qkv: [B*Hres*Wres, 3C] bf16 with channel layout [3][heads][32]
@@ -884,6 +888,17 @@ extern "C" int fiber_mha_fwd_bf16(const void* q, const void* k, const void* v, c
                                   int B, int heads, int Lq, int Lk, int D, int ldq, int ldk, int ldv, int ldo,
                                   float scale, float p_drop, uint64_t seed, const uint64_t* seed_base, hipStream_t stream) {
   if ((D != 32 && D != 64) || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 3) || Lq <= 0 || Lk <= 0) return FIBER_EINVAL;
+  // few queries, head_dim 64 (text -> image cross attention, text self attention): streaming forward with Q in registers (attn_x.hip)
+  static const int onepass_t = getenv("FIBER_ATTN_T2I_ONEPASS") ? atoi(getenv("FIBER_ATTN_T2I_ONEPASS")) : 1;   // 0: the generic kernel (A/B runs)
+  static const int onepass_i = getenv("FIBER_ATTN_I2T_ONEPASS") ? atoi(getenv("FIBER_ATTN_I2T_ONEPASS")) : 1;
+  if (onepass_i && D == 32 && Lk <= 48 && p_drop == 0.f) {   // few keys, head_dim 32 (image -> text cross attention): K / V in registers
+    const int rc = fiber_i2t_fwd_launch(q, k, v, kmask, o, lse, B, heads, Lq, Lk, ldq, ldk, ldv, ldo, scale, stream);
+    if (rc != FIBER_EINVAL) return rc;
+  }
+  if (onepass_t && D == 64 && Lq <= 48) {
+    const int rc = fiber_t2i_fwd_launch(q, k, v, kmask, o, lse, B, heads, Lq, Lk, ldq, ldk, ldv, ldo, scale, p_drop, seed, seed_base, stream);
+    if (rc != FIBER_EINVAL) return rc;
+  }
   ensure_attrs();
   AttnP p{};
   p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.o = (bf16*)o; p.lse = lse;

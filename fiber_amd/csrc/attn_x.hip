@@ -471,6 +471,269 @@ __global__ __launch_bounds__(256, 2) void t2i_bwd_kernel(TP p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Forward of the same site (head_dim 64, at most 48 queries, any number of keys): a workgroup = one (sample, head), its four waves take
+// every fourth 16-key tile with Q in registers and an ONLINE softmax per wave (running max / sum per query, the O^T accumulators rescaled
+// only when some query's max moved), V^T through a wave-private LDS image; the four partial (max, sum, O^T) triples are merged pairwise
+// through LDS in a fixed order.  K / V rows go from global memory straight into MFMA operand registers, one tile ahead.  The generic
+// forward staged whole key chunks per workgroup behind barriers: 40 x 576 x d64 moved its bytes at 2.7 TB/s.
+constexpr int F_SLAB = 14 * 64 * 16;                     // one wave's partial: 12 O^T tiles + (max, sum) of its three query tiles
+constexpr int F_SMEM = T_MAXK * 4 + 2 * F_SLAB;          // key-mask table + two slabs (the waves' V^T images live in the slab area until the merge)
+static_assert(4 * T_KT <= 2 * F_SLAB, "V^T images must fit the slab area");
+
+struct FP {
+  const bf16* q; const bf16* k; const bf16* v; bf16* o; float* lse; const float* kmask;
+  int ldq, ldk, ldv, ldo;
+  int H, Lq, Lk;
+  float scale, p_drop; uint64_t seed; const uint64_t* seed_base;
+};
+
+template <bool DROP>
+__global__ __launch_bounds__(256, 3) void t2i_fwd_kernel(FP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* mkl = reinterpret_cast<float*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int gq = lane >> 4, lq = lane & 15;
+  const int b = blockIdx.x, h = blockIdx.y;
+  bf16* Vt = reinterpret_cast<bf16*>(smem + T_MAXK * 4 + wave * T_KT);
+  for (int j = tid; j < ((p.Lk + 15) & ~15); j += 256)   // additive key mask in the log2 domain, -inf past Lk
+    mkl[j] = j < p.Lk ? (p.kmask ? p.kmask[(size_t)b * p.Lk + j] * 1.4426950408889634f : 0.f) : -INFINITY;
+  bf16x8 qf[3][2];
+#pragma unroll
+  for (int qt = 0; qt < 3; ++qt) {
+    const size_t row = (size_t)b * p.Lq + min(qt * 16 + lq, p.Lq - 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[qt][ks] = *reinterpret_cast<const bf16x8*>(p.q + row * p.ldq + h * 64 + ks * 32 + gq * 8);
+  }
+  const float c2 = p.scale * 1.4426950408889634f;
+  const uint32_t thresh = DROP ? (uint32_t)((double)p.p_drop * 4294967296.0) : 0u;
+  const uint32_t dseed = DROP ? drop_seed32(p.seed + (p.seed_base ? *p.seed_base : 0ull)) : 0u;
+  const float inv_keep = DROP ? 1.f / (1.f - p.p_drop) : 1.f;
+  const uint32_t drow = (uint32_t)((b * p.H + h) * p.Lq);
+  f32x4 oT[4][3];                                        // O^T[d = dt*16 + gq*4 + r][query = qt*16 + lq], un-normalised
+  float m[3], l[3];                                      // running max (log2 domain) and this LANE's share of the running sum
+#pragma unroll
+  for (int qt = 0; qt < 3; ++qt) {
+    m[qt] = -INFINITY; l[qt] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oT[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();                                       // mask table
+  const int ntiles = (p.Lk + 15) >> 4;
+  const bf16* kbase = p.k + (size_t)b * p.Lk * p.ldk + h * 64 + gq * 8;
+  const bf16* vbase = p.v + (size_t)b * p.Lk * p.ldv + h * 64 + gq * 8;
+  bf16x8 kk[2], vv[2];
+  auto request = [&](int kt) {
+    const unsigned r = (unsigned)min(kt * 16 + lq, p.Lk - 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      kk[ks] = *reinterpret_cast<const bf16x8*>(atx(kbase, r * (unsigned)p.ldk + ks * 32));
+      vv[ks] = *reinterpret_cast<const bf16x8*>(atx(vbase, r * (unsigned)p.ldv + ks * 32));
+    }
+  };
+  if (wave < ntiles) request(wave);
+  for (int kt = wave; kt < ntiles; kt += 4) {
+    const bf16x8 kf[2] = {kk[0], kk[1]};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) *reinterpret_cast<bf16x8*>(Vt + lq * TRS + ks * 32 + gq * 8) = vv[ks];
+    f32x4 st[3];
+#pragma unroll
+    for (int qt = 0; qt < 3; ++qt) {
+      st[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0], qf[qt][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      st[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1], qf[qt][1], st[qt], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    request(kt + 4 < ntiles ? kt + 4 : kt);              // (past the end: rows that are resident anyway, never used)
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x4 mk = *reinterpret_cast<const f32x4*>(mkl + kt * 16 + gq * 4);
+    s16x4 pb[3];
+    bool moved = false;
+    float alpha[3];
+#pragma unroll
+    for (int qt = 0; qt < 3; ++qt) {
+      const f32x4 sv = __builtin_elementwise_fma(st[qt], f32x4{c2, c2, c2, c2}, mk);
+      const float tmax = rows4_max(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])));
+      const float mnew = fmaxf(m[qt], tmax);
+      alpha[qt] = __builtin_amdgcn_exp2f(m[qt] - mnew);  // (first tile: exp2(-inf) = 0)
+      moved |= mnew > m[qt];
+      m[qt] = mnew;
+      const f32x4 pr = exp2x4(sv - mnew);
+      l[qt] = l[qt] * alpha[qt] + (pr[0] + pr[1]) + (pr[2] + pr[3]);
+      f32x4 prd = pr;
+      if constexpr (DROP) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool keep = drop_keep_rk(dseed, drow + (uint32_t)min(qt * 16 + lq, p.Lq - 1), (uint32_t)(kt * 16 + gq * 4 + r), thresh);
+          prd[r] = keep ? pr[r] * inv_keep : 0.f;
+        }
+      }
+      pb[qt] = pack4(prd);
+    }
+    if (__builtin_amdgcn_ballot_w64(moved) != 0) {       // some query's running max moved: rescale (rare after the first tiles)
+#pragma unroll
+      for (int qt = 0; qt < 3; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oT[dt][qt] *= alpha[qt];
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const s16x4 vT = tr16s(Vt, TRS, dt * 16, gq, lq);
+#pragma unroll
+      for (int qt = 0; qt < 3; ++qt) oT[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vT, pb[qt], oT[dt][qt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int qt = 0; qt < 3; ++qt) l[qt] = rows4_sum(l[qt]);
+  // ---- merge the four partials pairwise: (0, 2) and (1, 3), then (0, 1)
+  f32x4* slab = reinterpret_cast<f32x4*>(smem + T_MAXK * 4);
+  auto park = [&](int s_) {
+    f32x4* dst = slab + (size_t)s_ * 14 * 64 + lane;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int qt = 0; qt < 3; ++qt) dst[(dt * 3 + qt) * 64] = oT[dt][qt];
+    dst[12 * 64] = f32x4{m[0], m[1], m[2], 0.f};
+    dst[13 * 64] = f32x4{l[0], l[1], l[2], 0.f};
+  };
+  auto merge = [&](int s_) {
+    const f32x4* src = slab + (size_t)s_ * 14 * 64 + lane;
+    const f32x4 mo = src[12 * 64], lo = src[13 * 64];
+#pragma unroll
+    for (int qt = 0; qt < 3; ++qt) {
+      const float mn = fmaxf(m[qt], mo[qt]);
+      // (a wave without a key tile carries max = -inf, sum = 0, O = 0: its weight is 0, never exp2(-inf + inf))
+      const float a = m[qt] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m[qt] - mn), c = mo[qt] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mo[qt] - mn);
+      m[qt] = mn;
+      l[qt] = l[qt] * a + lo[qt] * c;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) oT[dt][qt] = oT[dt][qt] * a + src[(dt * 3 + qt) * 64] * c;
+    }
+  };
+  __syncthreads();                                       // every wave is done with its V^T image
+  if (wave >= 2) park(wave - 2);
+  __syncthreads();
+  if (wave < 2) merge(wave);
+  __syncthreads();
+  if (wave == 1) park(0);
+  __syncthreads();
+  if (wave == 0) {
+    merge(0);
+#pragma unroll
+    for (int qt = 0; qt < 3; ++qt) {
+      const int qi = qt * 16 + lq;
+      const size_t row = (size_t)b * p.Lq + min(qi, p.Lq - 1);
+      const float inv = 1.f / l[qt];
+#pragma unroll
+      for (int hp = 0; hp < 2; ++hp) {
+        const u32x4 w = rows4_gather16(oT[2 * hp][qt] * inv, oT[2 * hp + 1][qt] * inv);
+        if (qi < p.Lq) *reinterpret_cast<u32x4*>(p.o + row * p.ldo + h * 64 + hp * 32 + gq * 8) = w;
+      }
+      if (qi < p.Lq && gq == 0 && p.lse) p.lse[row * p.H + h] = m[qt] * 0.6931471805599453f + __logf(l[qt]);
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Forward of image -> text cross attention (head_dim 32, at most 48 keys, Lq % 16 == 0, heads % 4 == 0, no dropout): K rows and V^T of a
+// (sample, head) are MFMA operands held in registers for the whole run, a wave streams 16-query strips (q in: 16 bytes per lane; o out: 16
+// bytes per lane), the whole softmax of a strip is in registers (48 keys = three MFMA tiles).  Workgroup = 4 adjacent heads x 2 halves of the
+// strips, as the backward above.  The generic forward moved 576 x 40 x d32 at 2.4 TB/s of its bytes.
+struct XF {
+  const bf16* q; const bf16* k; const bf16* v; bf16* o; float* lse; const float* kmask;
+  int ldq, ldk, ldv, ldo;
+  int H, Lq, Lk;
+  float scale;
+};
+constexpr int XF_SMEM = 2 * X_KV;
+
+__global__ __launch_bounds__(512, 3) void i2t_fwd_kernel(XF p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* Ks = reinterpret_cast<bf16*>(smem);
+  bf16* Vs = reinterpret_cast<bf16*>(smem + X_KV);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int gq = lane >> 4, lq = lane & 15;
+  const int hl = wave & 3, half = wave >> 2;
+  const int b = blockIdx.x, h0 = blockIdx.y * 4, h = h0 + hl;
+  for (int idx = tid; idx < 4 * 64 * 4; idx += 512) {    // K, V of the four heads: row-major images, rows >= Lk zero
+    const int hh = idx >> 8, r = (idx >> 2) & 63, c = idx & 3;
+    bf16x8 kv, vv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { kv[e] = f2bf(0.f); vv[e] = f2bf(0.f); }
+    if (r < p.Lk) {
+      const size_t row = (size_t)b * p.Lk + r;
+      kv = *reinterpret_cast<const bf16x8*>(p.k + row * p.ldk + (h0 + hh) * 32 + c * 8);
+      vv = *reinterpret_cast<const bf16x8*>(p.v + row * p.ldv + (h0 + hh) * 32 + c * 8);
+    }
+    *reinterpret_cast<bf16x8*>(Ks + (hh * 64 + r) * XRS + c * 8) = kv;
+    *reinterpret_cast<bf16x8*>(Vs + (hh * 64 + r) * XRS + c * 8) = vv;
+  }
+  __syncthreads();
+  const bf16* Kh = Ks + hl * 64 * XRS;
+  const bf16* Vh = Vs + hl * 64 * XRS;
+  bf16x8 kfr[3], vtf[2][2];                              // K rows of key tile kt; V^T of the tile pairs (0, 1), (2, zero rows)
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt) kfr[kt] = *reinterpret_cast<const bf16x8*>(Kh + (kt * 16 + lq) * XRS + gq * 8);
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) vtf[dt][pr] = trr_frag(Vh, dt * 16, 2 * pr, gq, lq);
+  f32x4 mkT[3];                                          // additive key mask in the log2 domain (keys kt*16 + gq*4 + r), -inf past Lk
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kt * 16 + gq * 4 + r;
+      mkT[kt][r] = key < p.Lk ? (p.kmask ? p.kmask[(size_t)b * p.Lk + key] * 1.4426950408889634f : 0.f) : -INFINITY;
+    }
+  const float c2 = p.scale * 1.4426950408889634f;
+  const int nstrips = p.Lq >> 4;
+  const bf16* qbase = p.q + (size_t)b * p.Lq * p.ldq + h * 32 + gq * 8;
+  bf16* obase = p.o + (size_t)b * p.Lq * p.ldo + h * 32 + gq * 8;
+  // strips are requested two ahead in two FIXED register sets (loop unrolled twice: no register moves, so the compiler's vmcnt waits stay counted)
+  bf16x8 qa, qb;
+  auto strip = [&](int s_, bf16x8& qreg, int s_next) {
+    const bf16x8 qf = qreg;
+    f32x4 st[3];
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[kt], qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    qreg = *reinterpret_cast<const bf16x8*>(atx(qbase, (unsigned)((s_next < nstrips ? s_next : s_) * 16 + lq) * (unsigned)p.ldq));
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 sv[3];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+      sv[kt] = __builtin_elementwise_fma(st[kt], f32x4{c2, c2, c2, c2}, mkT[kt]);
+      mx = fmaxf(mx, fmaxf(fmaxf(sv[kt][0], sv[kt][1]), fmaxf(sv[kt][2], sv[kt][3])));
+    }
+    mx = rows4_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) { sv[kt] = exp2x4(sv[kt] - mx); sum += (sv[kt][0] + sv[kt][1]) + (sv[kt][2] + sv[kt][3]); }
+    sum = rows4_sum(sum);
+    const bf16x8 p01 = pack8(sv[0], sv[1]), p2 = pack8(sv[2], f32x4{0.f, 0.f, 0.f, 0.f});
+    f32x4 oT[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      oT[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vtf[dt][0], p01, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      oT[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vtf[dt][1], p2, oT[dt], 0, 0, 0);
+    }
+    const float inv = 1.f / sum;
+    *reinterpret_cast<u32x4*>(atx(obase, (unsigned)(s_ * 16 + lq) * (unsigned)p.ldo)) = rows4_gather16(oT[0] * inv, oT[1] * inv);
+    if (gq == 0 && p.lse) p.lse[((size_t)b * p.Lq + s_ * 16 + lq) * p.H + h] = mx * 0.6931471805599453f + __logf(sum);
+  };
+  if (half < nstrips) qa = *reinterpret_cast<const bf16x8*>(atx(qbase, (unsigned)(half * 16 + lq) * (unsigned)p.ldq));
+  if (half + 2 < nstrips) qb = *reinterpret_cast<const bf16x8*>(atx(qbase, (unsigned)((half + 2) * 16 + lq) * (unsigned)p.ldq));
+  for (int s_ = half; s_ < nstrips; s_ += 4) {
+    strip(s_, qa, s_ + 4);
+    if (s_ + 2 < nstrips) strip(s_ + 2, qb, s_ + 6);
+  }
+}
+
 bool x_attr = false;
 
 }  // namespace
@@ -508,6 +771,36 @@ int fiber_t2i_bwd_launch(const void* q, const void* k, const void* v, const floa
   p.H = heads; p.Lq = Lq; p.Lk = Lk; p.scale = scale; p.p_drop = p_drop; p.seed = seed; p.seed_base = seed_base;
   if (p_drop > 0.f) hipLaunchKernelGGL(t2i_bwd_kernel<true>, dim3(B, heads), dim3(256), T_SMEM, st, p);
   else hipLaunchKernelGGL(t2i_bwd_kernel<false>, dim3(B, heads), dim3(256), T_SMEM, st, p);
+  FIBER_CHECK_LAUNCH();
+  return FIBER_OK;
+}
+
+// Forward for head_dim 64 and at most 48 queries (text -> image cross attention, text self attention); FIBER_EINVAL: shape not served.
+int fiber_t2i_fwd_launch(const void* q, const void* k, const void* v, const float* kmask, void* o, float* lse, int B, int heads, int Lq, int Lk,
+                         int ldq, int ldk, int ldv, int ldo, float scale, float p_drop, uint64_t seed, const uint64_t* seed_base, hipStream_t st) {
+  if (Lq > 48 || Lq <= 0 || Lk <= 0 || Lk > T_MAXK || (size_t)Lk * (size_t)(ldk | ldv) >= (1u << 30) || ((ldq | ldk | ldv | ldo) & 7) ||
+      scale <= 0.f || p_drop < 0.f || p_drop >= 1.f)
+    return FIBER_EINVAL;
+  FP p;
+  p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.o = (bf16*)o; p.lse = lse; p.kmask = kmask;
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+  p.H = heads; p.Lq = Lq; p.Lk = Lk; p.scale = scale; p.p_drop = p_drop; p.seed = seed; p.seed_base = seed_base;
+  if (p_drop > 0.f) hipLaunchKernelGGL(t2i_fwd_kernel<true>, dim3(B, heads), dim3(256), F_SMEM, st, p);
+  else hipLaunchKernelGGL(t2i_fwd_kernel<false>, dim3(B, heads), dim3(256), F_SMEM, st, p);
+  FIBER_CHECK_LAUNCH();
+  return FIBER_OK;
+}
+
+// Forward of image -> text cross attention (head_dim 32, <= 48 keys, no dropout); FIBER_EINVAL: shape not served.
+int fiber_i2t_fwd_launch(const void* q, const void* k, const void* v, const float* kmask, void* o, float* lse, int B, int heads, int Lq, int Lk,
+                         int ldq, int ldk, int ldv, int ldo, float scale, hipStream_t st) {
+  if (Lk > 48 || Lk <= 0 || (Lq & 15) || Lq <= 0 || (heads & 3) || ((ldq | ldk | ldv | ldo) & 7) || (size_t)Lq * (size_t)(ldq | ldo) >= (1u << 30) ||
+      scale <= 0.f)
+    return FIBER_EINVAL;
+  XF p;
+  p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.o = (bf16*)o; p.lse = lse; p.kmask = kmask;
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.H = heads; p.Lq = Lq; p.Lk = Lk; p.scale = scale;
+  hipLaunchKernelGGL(i2t_fwd_kernel, dim3(B, heads / 4), dim3(512), XF_SMEM, st, p);
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }

@@ -182,7 +182,8 @@ def main():
         print(f"  {k:34s} {v:8.2f} ms")
     print("top (entry, shape):")
     for r in rows[:28]:
-        extra = f"{r['kind']:22s} {str(r['shape']):24s} {r['TFLOPs']:7.1f} TF/s {r['TBps']:6.3f} TB/s" if "kind" in r else str(r["args"])[:60]
+        extra = (f"{r['kind']:22s} {str(r.get('shape', r.get('bytes', ''))):24s} {r.get('TFLOPs', 0.0):7.1f} TF/s {r.get('TBps', 0.0):6.3f} TB/s" if "kind" in r
+                 else str(r["args"])[:60])
         print(f"  {r['ms_per_step']:7.2f} ms  x{r['calls_per_step']:5.1f}  {r['us_per_call']:8.1f} us  {r['entry'][6:28]:22s} {extra}")
 
 
