@@ -49,10 +49,25 @@ def test_trainer_fit_swin_t_224_b4(tmp_path):
     assert ck["lr_schedulers"][0]["last_epoch"] == 6 and ck["optimizer_states"][0]["state"]
     # the schedule reached its end: linear warm-up over 1 step, linear decay to 0 at step 6 (fiber_utils.py:274)
     assert ma.trainer is ta
-    # ---- interrupted after 3 steps (= 2 epochs), resumed to 6
+    # ---- the same 6-step run (same max_steps: the schedule follows trainer.max_steps, fiber_utils.py:254-259) killed at the start of its
+    # third epoch, i.e. after 3 optimizer steps = 2 epochs and the epoch-end last.ckpt; then resumed to the end.  (An "interrupted" run
+    # made with Trainer(max_steps=3) is a DIFFERENT run: its poly-decay schedule ends at step 3, so its checkpoint carries lr = 0.)
+    class Killed(RuntimeError):
+        pass
+
+    class DiesInEpoch3(list):
+        epochs = 0
+
+        def __iter__(self):
+            self.epochs += 1
+            if self.epochs == 3:
+                raise Killed()
+            return super().__iter__()
+
     mb = _model(6)
-    tb = Trainer(max_steps=3, accumulate_grad_batches=2, log_every_n_steps=0, default_root_dir=str(tmp_path / "b"))
-    tb.fit(mb, data, val_dataloader=val)
+    tb = Trainer(max_steps=6, accumulate_grad_batches=2, log_every_n_steps=0, default_root_dir=str(tmp_path / "b"))
+    with pytest.raises(Killed):
+        tb.fit(mb, DiesInEpoch3(data), val_dataloader=val)
     assert tb.global_step == 3 and tb.current_epoch == 2
     mid = load_checkpoint(str(tmp_path / "b" / "last.ckpt"))
     assert mid["global_step"] == 3 and mid["epoch"] == 2
@@ -62,11 +77,15 @@ def test_trainer_fit_swin_t_224_b4(tmp_path):
     last_c = tc.fit(mc, data, val_dataloader=val)
     assert tc.global_step == 6 and tc.current_epoch == 4
     torch.cuda.synchronize()
-    # the resumed run IS the uninterrupted one: same batches in the same order, deterministic kernels (no atomics on this path),
-    # optimizer moments, schedule position and fp32 masters restored from the file
-    assert abs(float(last_a) - float(last_c)) <= 1e-6 * max(1.0, abs(float(last_a))), (float(last_a), float(last_c))
+    # The resumed run IS the uninterrupted one: same batches in the same order, optimizer moments, schedule position and fp32 masters
+    # restored from the file.  Not bit for bit, though: the path has a few fp32 atomics (embedding-row gradients, the scalar gate gradients),
+    # and two runs of the SAME uninterrupted recipe in one process differ by up to 8e-5 in this loss and 1e-3 in single weights
+    # (tools/probes/trainer_dbg.py: the key biases have a mathematically zero gradient, so Adam turns the last-bit noise of their
+    # gradient into +-lr steps).  Bounds = that spread x 2.5; the failure modes this test is for are orders of magnitude larger (a
+    # restarted warm-up or missing moments: 0.24 in the loss; a repeated epoch: 0.5).
+    assert abs(float(last_a) - float(last_c)) <= 2e-4 * max(1.0, abs(float(last_a))), (float(last_a), float(last_c))
     sa, sc = ma.state_dict(), mc.state_dict()
     worst = max((float((sa[k].float() - sc[k].float()).abs().max()), k) for k in sa if sa[k].is_floating_point())
-    assert worst[0] <= 1e-6, worst
+    assert worst[0] <= 2.5e-3, worst
     # and it trained: the loss of the last step is below the first step's
     assert float(last_a) < 11.5, float(last_a)
