@@ -598,8 +598,9 @@ def test_loss_curve_swin_t_224_mlm_itm_50_steps():
     # Measured (profiles/r02_loss_curve_swin_t.json): loss 11.21 -> 1.34; gap median 1.9e-3, p90 5.4e-3, max 8.5e-3, 12 of 50
     # steps within the north star's 1e-3, step 0 (no training dynamics: forward numerics only) 1.9e-3.  bf16 activations with
     # a 12-token MLM mean at batch 2 do not reach +-1e-3; before the fp32 label-logit correction (objectives._mlm_ce) the same
-    # run read median 2.9e-3 / max 1.5e-2.  Bounds below = 2x the measured values.
-    assert summary["gap_max"] < 1.6e-2 and summary["gap_median"] < 4.5e-3, summary
+    # run read median 2.9e-3 / max 1.5e-2.  Round 5 (profiles/r05_loss_curve_swin_t.json): median 2.2e-3, p90 4.3e-3, max 7.6e-3, 15 of 50.
+    # Bounds = 1.5 x the worst value seen over the rounds (max 8.5e-3, median 2.2e-3).
+    assert summary["gap_max"] < 1.3e-2 and summary["gap_median"] < 3.3e-3, summary
 
 
 @pytest.mark.skipif(os.environ.get("FIBER_SLOW_TESTS", "0") != "1", reason="duplicates the bf16-stream curve above and tools/loss_curve_study.py "
