@@ -634,10 +634,12 @@ def test_loss_curve_swin_t_224_realistic_batch():
     the north star's +-1e-3 (mid-round build: 6.0e-4 / 1.1e-3 / 1.4e-3, 41) -- the oracle under torch.autocast(bf16), the reference's own
     mixed precision, has 41 (median 5.2e-4 / max 1.9e-3); with the fp32 residual stream 3.3e-4 / 1.05e-3, 49 of 50.  FIBER-Base 384^2 at the reference's B = 8, 20
     steps: 1.3e-3 / 3.5e-3 (autocast oracle 1.05e-3 / 2.0e-3), profiles/r04_loss_curve_fiber_base_b8.json.  This test repeats the
-    protocol for 10 steps on this test's own batches (the fp32 oracle's 10 steps at B = 32 cost ~2 minutes of host time).  A 10-step
+    protocol for a few steps on this test's own batches (the fp32 oracle's step at B = 32 costs ~11 s of host time).  A 10-step
     statistic moves with every harmless reordering of a reduction: over the round's builds median 7.5e-4 .. 1.4e-3, max 1.4e-3 .. 2.3e-3,
     5-8 steps within 1e-3 (the 50-step study of the final build: median 3.7e-4, 48 of 50 within 1e-3); bounds = 1.4 x the worst seen."""
-    summary = _loss_curve(dict(cases.SWIN_T), 224, 32, 10, 10, 1, "swin_t_b32")
+    # Round 5: 6 steps instead of 10 (the oracle's B = 32 step is 11 s of host time; the GPU suite has to stay well inside the driver's limit).
+    # The first 6 steps of the round-5 10-step run (profiles/r05_loss_curve_swin_t_b32.json): same statistics to within the spread above.
+    summary = _loss_curve(dict(cases.SWIN_T), 224, 32, 6, 6, 1, "swin_t_b32")
     assert summary["gap_median"] < 2.0e-3 and summary["gap_max"] < 3.2e-3, summary
 
 
