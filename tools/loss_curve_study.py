@@ -48,6 +48,9 @@ def main():
     ap.add_argument("--threads", type=int, default=64)
     ap.add_argument("--lr", type=float, default=2e-5)
     ap.add_argument("--no-autocast", action="store_true")
+    ap.add_argument("--only-autocast", action="store_true",
+                    help="only the autocast-oracle column (per-step losses appended to gpurun_out/<tag>_autocast.log as they come): "
+                         "completes a study whose other columns exist already")
     a = ap.parse_args()
     cfg, size = (dict(cases.SWIN_T), 224) if a.case == "swin_t" else (dict(cases.SWIN_B), 384)
     B = a.B or (32 if a.case == "swin_t" else 8)
@@ -92,7 +95,7 @@ def main():
             group_spec = [{"names": [name_of[id(p)] for p in g["params"]], "weight_decay": g["weight_decay"], "lr": g["initial_lr"]}
                           for g in opt.param_groups]
         t0, ls = time.time(), []
-        for step in range(steps):
+        for step in range(0 if a.only_autocast else steps):
             bd = _to_dev(batches[step], dev)
             bd["itm_labels_override"] = bd["itm_labels"]
             opt.zero_grad(set_to_none=True)
@@ -104,10 +107,12 @@ def main():
         curves[mode], secs[mode] = ls, time.time() - t0
         print(mode, f"{secs[mode]:.0f}s", [round(v, 4) for v in ls], flush=True)
         del model, opt
+        if a.only_autocast:
+            break
         ops.set_residual_dtype("bf16")
         torch.cuda.empty_cache()
     # ---- oracle runs on the host cores
-    for mode in (["oracle_fp32"] + ([] if a.no_autocast else ["oracle_autocast_bf16"])):
+    for mode in (["oracle_autocast_bf16"] if a.only_autocast else ["oracle_fp32"] + ([] if a.no_autocast else ["oracle_autocast_bf16"])):
         ref = fresh_ref()
         rparams = dict(ref.named_parameters())
         groups = [{"params": [rparams[n] for n in g["names"]], "weight_decay": g["weight_decay"], "lr": g["lr"]} for g in group_spec]
@@ -127,10 +132,16 @@ def main():
             ropt.step()
             rsched.step()
             ls.append(rl.item())
+            if a.only_autocast:
+                os.makedirs("gpurun_out", exist_ok=True)
+                with open(f"gpurun_out/r05_loss_curve_{a.case}_b{B}_autocast.log", "a") as fh:
+                    fh.write(f"{step} {rl.item():.6f} {time.time() - t0:.0f}s\n")
             if step == 0:
                 print(f"  {mode}: first step {time.time() - t0:.0f}s", flush=True)
         curves[mode], secs[mode] = ls, time.time() - t0
         print(mode, f"{secs[mode]:.0f}s", [round(v, 4) for v in ls], flush=True)
+    if a.only_autocast:
+        return
     want = curves["oracle_fp32"]
     summary = {}
     for mode, ls in curves.items():
