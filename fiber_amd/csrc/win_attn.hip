@@ -228,11 +228,12 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
   const int gq = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y, C = p.C;
   // layout 3 = planar: [3 * heads planes][token][32] -- a window row of a head is ONE 768-byte run (tools/probes/run_probe.hip)
-  const bool planar = p.hmajor == 3;
+  // layout 4: qkv planar, o in token rows (the probe of what a planar qkv GEMM epilogue ALONE would buy)
+  const bool planar = p.hmajor == 3 || p.hmajor == 4, planar_o = p.hmajor == 3;
   const size_t pl = (size_t)p.B * p.Hres * p.Wres * 32;
-  const int ld = planar ? 32 : 3 * C, ldo = planar ? 32 : C;
+  const int ld = planar ? 32 : 3 * C, ldo = planar_o ? 32 : C;
   const size_t qo = planar ? h * pl : (size_t)chan_q(p, h), ko = planar ? (p.heads + h) * pl : (size_t)chan_k(p, h),
-               vo = planar ? (2 * p.heads + h) * pl : (size_t)chan_v(p, h), oo = planar ? h * pl : (size_t)h * 32;
+               vo = planar ? (2 * p.heads + h) * pl : (size_t)chan_v(p, h), oo = planar_o ? h * pl : (size_t)h * 32;
   // compile-time for the 12x12 window (guards fold, the 10th tile's code disappears) and for the 21-tile variant (18x18
   // windows fill it; padded tiles of smaller windows carry bias = -inf and zero rows, so running them is only wasted work)
   const int ntile = NTC ? NTC : MT > 10 ? MT : (p.N + 15) >> 4;
@@ -909,11 +910,13 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
   const int gq = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y, C = p.C;
   // layout 3 = planar [3 * heads planes][token][32] for qkv / dqkv and [heads planes][token][32] for o / dout (see win_fwd_kernel)
-  const bool planar = p.hmajor == 3;
+  // layout 4: qkv planar; o, dout and dqkv in token rows (dqkv in the reference channel order)
+  const bool planar = p.hmajor == 3 || p.hmajor == 4, planar_o = p.hmajor == 3;
   const size_t pl = (size_t)p.B * p.Hres * p.Wres * 32;
-  const int ld = planar ? 32 : 3 * C, ldo = planar ? 32 : C;
+  const int ld = planar ? 32 : 3 * C, ldo = planar_o ? 32 : C, ldd = p.hmajor == 4 ? 3 * C : ld;
   const size_t qo = planar ? h * pl : (size_t)chan_q(p, h), ko = planar ? (p.heads + h) * pl : (size_t)chan_k(p, h),
-               vo = planar ? (2 * p.heads + h) * pl : (size_t)chan_v(p, h), oo = planar ? h * pl : (size_t)h * 32;
+               vo = planar ? (2 * p.heads + h) * pl : (size_t)chan_v(p, h), oo = planar_o ? h * pl : (size_t)h * 32;
+  const size_t dqo = p.hmajor == 4 ? (size_t)h * 32 : qo, dko = p.hmajor == 4 ? (size_t)C + h * 32 : ko, dvo = p.hmajor == 4 ? (size_t)2 * C + h * 32 : vo;
   setup<10>(p, S, h, nb, 0, 1.4426950408889634f, -INFINITY);
   {                                                      // zero the three images once: rows 144..159 (tile 9) are never staged
     uint32_t* z = reinterpret_cast<uint32_t*>(Qs);
@@ -1106,8 +1109,8 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
       bf16x4 ok, ov;
 #pragma unroll
       for (int r = 0; r < 4; ++r) { ok[r] = f2bf(dkacc[dt][r] * scale); ov[r] = f2bf(dvacc[dt][r]); }
-      *reinterpret_cast<bf16x4*>(at(p.dqkv + ko + oimg * ld, opix * ld + dt * 16 + gq * 4)) = ok;
-      *reinterpret_cast<bf16x4*>(at(p.dqkv + vo + oimg * ld, opix * ld + dt * 16 + gq * 4)) = ov;
+      *reinterpret_cast<bf16x4*>(at(p.dqkv + dko + oimg * ldd, opix * ldd + dt * 16 + gq * 4)) = ok;
+      *reinterpret_cast<bf16x4*>(at(p.dqkv + dvo + oimg * ldd, opix * ldd + dt * 16 + gq * 4)) = ov;
     }
     if (p.colsum_part) {
       const f32x4 s0 = lane16_sum(dkacc[0] * scale), s1 = lane16_sum(dkacc[1] * scale), s2 = lane16_sum(dvacc[0]), s3 = lane16_sum(dvacc[1]);
@@ -1135,7 +1138,7 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
       bf16x4 o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[r] = f2bf(dqacc[dt][r] * scale);
-      *reinterpret_cast<bf16x4*>(at(p.dqkv + qo + oimg * ld, opix * ld + dt * 16 + gq * 4)) = o;
+      *reinterpret_cast<bf16x4*>(at(p.dqkv + dqo + oimg * ldd, opix * ldd + dt * 16 + gq * 4)) = o;
     }
     if (p.colsum_part) {
       const f32x4 s0 = lane16_sum(dqacc[0] * scale), s1 = lane16_sum(dqacc[1] * scale);

@@ -28,9 +28,9 @@ for name, H, C, heads in (("s0", 96, 128, 4), ("s1", 48, 256, 8), ("s2", 24, 512
     delta = torch.empty(M * heads, device="cuda")
     for shift in (0, 6):
         res, line = {}, []
-        for hm in (0, 3):
-            src = qkv if hm == 0 else to_planar(qkv, 3 * heads)
-            dsrc = do if hm == 0 else to_planar(do, heads)
+        for hm in (0, 1, 2, 3, 4):
+            src = qkv if hm < 3 else to_planar(qkv, 3 * heads)     # (layouts 1, 2: timing only, the same bytes read as another channel order)
+            dsrc = do if hm != 3 else to_planar(do, heads)
             o = torch.empty(M * C, device="cuda", dtype=torch.bfloat16)
             lse = torch.empty(M * heads, device="cuda")
             dqkv = torch.empty(M * 3 * C, device="cuda", dtype=torch.bfloat16)
@@ -40,7 +40,8 @@ for name, H, C, heads in (("s0", 96, 128, 4), ("s1", 48, 256, 8), ("s2", 24, 512
                               lib.ptr(delta), lib.ptr(part), lib.ptr(csum), lib.ptr(cs_ws), B, H, H, C, heads, 12, shift, hm)
             tf = timeit(f); tb = timeit(b)
             res[hm] = (o.clone(), lse.clone(), dqkv.clone(), dtab.clone(), csum.clone())
-            line.append(f"layout {hm}: fwd {tf:7.1f} us {(M * 4 * C * 2 + M * heads * 4) / tf / 1e6:5.2f} TB/s  bwd {tb:7.1f} us {(M * 8 * C * 2 + M * heads * 4) / tb / 1e6:5.2f} TB/s")
+            line.append(f"L{hm}: {tf:6.1f} | {tb:6.1f}")
         ok = (torch.equal(from_planar(res[3][0], M), res[0][0].view(M, C)) and torch.equal(res[0][1], res[3][1])
-              and torch.equal(from_planar(res[3][2], M), res[0][2].view(M, 3 * C)) and torch.equal(res[0][3], res[3][3]) and torch.equal(res[0][4], res[3][4]))
+              and torch.equal(from_planar(res[3][2], M), res[0][2].view(M, 3 * C)) and torch.equal(res[0][3], res[3][3]) and torch.equal(res[0][4], res[3][4])
+              and torch.equal(res[4][0], res[0][0]) and torch.equal(res[4][2], res[0][2]) and torch.equal(res[4][3], res[0][3]))
         print(f"{name}/{shift}  " + "   ".join(line) + f"   bit-equal {ok}")
