@@ -362,6 +362,51 @@ def test_mha(ops, B, heads, Lq, Lk, D, masked):
     assert_close("dv", v.grad, vr.grad, 1e-2)
 
 
+def _random_mha_shapes():
+    """48 shapes drawn once (fixed seed) around the one-pass kernels' admission rules (attn_x.hip) and just outside them."""
+    import random
+    r = random.Random(20240929)
+    out = []
+    for i in range(48):
+        if i % 2 == 0:                                   # head_dim 64: <= 48 queries -> t2i kernels; 49.. and > 1024 keys -> generic
+            Lq = r.choice([1, 5, 15, 16, 17, 31, 32, 33, 40, 47, 48, 49, 60])
+            Lk = r.choice([1, 3, 15, 16, 17, 40, 63, 64, 65, 144, 200, 577, 1024, 1030])
+            out.append((r.choice([1, 2, 3]), r.choice([1, 2, 3, 5, 12]), Lq, Lk, 64, r.random() < 0.5))
+        else:                                            # head_dim 32: <= 48 keys, Lq % 16 == 0, heads % 4 == 0 -> i2t kernels
+            Lq = r.choice([16, 32, 48, 80, 144, 150, 9])
+            Lk = r.choice([1, 2, 15, 16, 17, 32, 40, 47, 48, 49, 70])
+            out.append((r.choice([1, 2, 5]), r.choice([4, 8, 16, 3, 6]), Lq, Lk, 32, r.random() < 0.5))
+    return out
+
+
+@pytest.mark.parametrize("B,heads,Lq,Lk,D,masked", _random_mha_shapes())
+def test_mha_random_shapes(ops, B, heads, Lq, Lk, D, masked):
+    """Forward and backward of ops.mha against torch at shapes on both sides of every admission rule of the one-pass kernels: ragged query /
+    key tiles, waves without a tile, more keys than the LDS mask table holds, head counts that are not a multiple of 4, one query, one key."""
+    C = heads * D
+    q, k, v = (bf(rnd(B * L, C, seed=s)).requires_grad_(True) for L, s in ((Lq, 10), (Lk, 11), (Lk, 12)))
+    km = None
+    if masked:
+        lens = torch.randint(1, Lk + 1, (B,), generator=torch.Generator().manual_seed(Lq * 131 + Lk))
+        lens[0] = Lk
+        km = ((torch.arange(Lk)[None] >= lens[:, None]).float() * -10000.0).to(DEV)
+    scale = D ** -0.5
+    o = ops.mha(q, k, v, km, B, heads, scale)
+    qr, kr, vr = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    oref = _mha_ref(qr, kr, vr, km, B, heads, scale)
+    assert torch.isfinite(o.float()).all()
+    assert_close("o", o, oref, 6e-3)
+    do = bf(rnd(B * Lq, C, seed=17))
+    o.backward(do)
+    oref.backward(do.float())
+    for name, got, ref in (("dq", q.grad, qr.grad), ("dk", k.grad, kr.grad), ("dv", v.grad, vr.grad)):
+        assert torch.isfinite(got.float()).all(), name
+        if float(ref.norm()) < 1e-6 * float(do.float().norm()):       # one key: softmax = 1, dq and dk are exactly zero -- what remains
+            assert float(got.float().abs().max()) < 5e-2, name       # is the bf16 rounding of O inside delta = sum(dO * O)
+        else:
+            assert_close(name, got, ref, 1.2e-2)
+
+
 def test_mha_packed_views(ops):
     """K/V as column views of one packed [B*S, 2C] projection (the i2t layout, swin_transformer.py:230-235)."""
     B, heads, Lq, Lk, D = 2, 4, 64, 40, 32
