@@ -1,8 +1,15 @@
-// Image -> text cross attention (swin_transformer.py:226-259), backward in ONE pass (gfx950 / CDNA4).
+// One-pass kernels for the three attention sites of the fused layers whose ONE side is tiny (gfx950 / CDNA4; round 5):
+//   i2t_bwd_kernel / i2t_fwd_kernel   image -> text cross attention (swin_transformer.py:226-259): 576 / 144 queries x 40 text keys, head_dim 32
+//   t2i_bwd_kernel / t2i_fwd_kernel   text -> image cross attention and text self attention (roberta.py:256-326, 474-483): 40 queries x 576 / 144 /
+//                                     40 keys, head_dim 64, attention-probability dropout
+// The generic kernels of attn.hip treat both sides alike (key chunks staged in LDS per workgroup behind barriers; a delta kernel, a query-strip
+// pass and a key-strip pass in the backward, K / V read twice): these sites ran at 1.5-2.7 TB/s of their bytes (0.19-0.34 of the HBM floor).
+// Here the small side of a (sample, head) lives in REGISTERS as MFMA operands (in both orientations where needed) and the large side is streamed
+// through once, 16 rows per step, with no workgroup barrier inside the stream; fiber_mha_fwd_bf16 / fiber_mha_bwd_bf16 dispatch here when the
+// shape fits (FIBER_ATTN_I2T_ONEPASS / FIBER_ATTN_T2I_ONEPASS = 0: the generic kernels, for A/B runs) and fall back otherwise.
 //
-// The generic backward of attn.hip runs three kernels for this site (delta = rowsum(dO . O); a query-strip pass for dQ; a key-strip pass
-// for dK / dV) and reads q, dO, O twice: at 576 queries x 40 text tokens x head_dim 32 it moved its bytes at 1.5-2.1 TB/s (0.19-0.26 of the
-// HBM floor: the family furthest from its roofline in the round-4 step).  Here the text side is tiny -- K and V of one (sample, head) are
+// ---- image -> text, backward ---------------------------------------------------------------------------------------------------------
+// The text side is tiny -- K and V of one (sample, head) are
 // 40 x 64 B -- so a wave keeps them in REGISTERS (as MFMA operands in both orientations) and streams the query strips once:
 //   * per strip of 16 queries a lane loads 16 bytes of q, dO and O; delta comes out of the dO / O pieces it already holds;
 //   * the scores are formed in BOTH orientations (the matrix pipe is idle anyway): S^T[key][query] (lane = query) feeds dQ^T = K^T . dS^T,
@@ -139,7 +146,8 @@ __global__ __launch_bounds__(512) void i2t_bwd_kernel(XP p) {
 
   const int nstrips = p.Lq >> 4;
   // Strips are requested PD iterations ahead (registers): one iteration ahead left every strip waiting ~3 us for its rows (24 KB in flight
-  // per CU: 2.5 TB/s); the strip arithmetic itself is ~0.4 us.
+  // per CU: 2.5 TB/s); the strip arithmetic itself is ~0.4 us.  (The rotating queue below costs part of that distance: hipcc's waitcnt pass
+  // waits for all but the newest one or two requests at the loop top -- see t2i_bwd_kernel for the form that does not; 3.6 TB/s as it is.)
   constexpr int PD = 3;
   bf16x8 qn[PD], don[PD], on[PD];
   float lsen[PD];
