@@ -82,7 +82,7 @@ __device__ __forceinline__ u32x4 rows4_gather16(f32x4 a, f32x4 b) {
 
 constexpr int X_KV = 4 * 64 * XRS * 2;                   // bytes of the K (or V) images of four heads (64 rows each, rows >= Lk zero)
 constexpr int X_STRIP = 16 * XRS * 2;                    // one strip image (Q or dO) of a wave
-constexpr int X_SMEM = 2 * X_KV + 8 * 2 * X_STRIP + 8 * 32 * 4 + 4 * 12 * 64 * 16;
+constexpr int X_SMEM = 2 * X_KV + 8 * 2 * X_STRIP + 8 * 32 * 4 + 4 * 12 * 64 * 16 + 64 * 4;   // (+ the key-mask table)
 
 __global__ __launch_bounds__(512) void i2t_bwd_kernel(XP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -97,6 +97,10 @@ __global__ __launch_bounds__(512) void i2t_bwd_kernel(XP p) {
   bf16* dOst = Qst + 16 * XRS;
   float* stat = reinterpret_cast<float*>(smem + 2 * X_KV + 8 * 2 * X_STRIP) + wave * 32;
   f32x4* red = reinterpret_cast<f32x4*>(smem + 2 * X_KV + 8 * 2 * X_STRIP + 8 * 32 * 4);
+  // additive key mask of the sample in the log2 domain, -inf past Lk: ONE load per thread into an LDS table (as per-lane loads behind
+  // `key < Lk` branches hipcc gave every one of the 15 its own vmcnt(0): fifteen DRAM latencies in a row at the head of every workgroup)
+  float* mkl = reinterpret_cast<float*>(smem + X_SMEM - 64 * 4);
+  if (tid < 64) mkl[tid] = tid < p.Lk ? (p.kmask ? p.kmask[(size_t)b * p.Lk + tid] * 1.4426950408889634f : 0.f) : -INFINITY;
   // ---- K, V of the four heads: row-major images, rows >= Lk zero
   for (int idx = tid; idx < 4 * 64 * 4; idx += 512) {
     const int hh = idx >> 8, r = (idx >> 2) & 63, c = idx & 3;
@@ -129,13 +133,8 @@ __global__ __launch_bounds__(512) void i2t_bwd_kernel(XP p) {
   float mkS[3];
 #pragma unroll
   for (int kt = 0; kt < 3; ++kt) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int key = kt * 16 + gq * 4 + r;
-      mkT[kt][r] = key < p.Lk ? (p.kmask ? p.kmask[(size_t)b * p.Lk + key] * 1.4426950408889634f : 0.f) : -INFINITY;
-    }
-    const int key = kt * 16 + lq;
-    mkS[kt] = key < p.Lk ? (p.kmask ? p.kmask[(size_t)b * p.Lk + key] * 1.4426950408889634f : 0.f) : -INFINITY;
+    mkT[kt] = *reinterpret_cast<const f32x4*>(mkl + kt * 16 + gq * 4);
+    mkS[kt] = mkl[kt * 16 + lq];
   }
   const float c2 = p.scale * 1.4426950408889634f, inv_c2 = 1.f / c2;
   f32x4 dkT[3][2], dvT[3][2];                            // dK^T / dV^T[d = dt*16 + gq*4 + r][key = kt*16 + lq], summed over this wave's strips
@@ -655,7 +654,7 @@ struct XF {
   int H, Lq, Lk;
   float scale;
 };
-constexpr int XF_SMEM = 2 * X_KV;
+constexpr int XF_SMEM = 2 * X_KV + 64 * 4;                 // K / V images of four heads + the key-mask table
 
 __global__ __launch_bounds__(512, 3) void i2t_fwd_kernel(XF p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -666,6 +665,8 @@ __global__ __launch_bounds__(512, 3) void i2t_fwd_kernel(XF p) {
   const int gq = lane >> 4, lq = lane & 15;
   const int hl = wave & 3, half = wave >> 2;
   const int b = blockIdx.x, h0 = blockIdx.y * 4, h = h0 + hl;
+  float* mkl = reinterpret_cast<float*>(smem + 2 * X_KV);     // key mask of the sample (log2 domain, -inf past Lk): one load per thread
+  if (tid < 64) mkl[tid] = tid < p.Lk ? (p.kmask ? p.kmask[(size_t)b * p.Lk + tid] * 1.4426950408889634f : 0.f) : -INFINITY;
   for (int idx = tid; idx < 4 * 64 * 4; idx += 512) {    // K, V of the four heads: row-major images, rows >= Lk zero
     const int hh = idx >> 8, r = (idx >> 2) & 63, c = idx & 3;
     bf16x8 kv, vv;
@@ -691,12 +692,7 @@ __global__ __launch_bounds__(512, 3) void i2t_fwd_kernel(XF p) {
     for (int pr = 0; pr < 2; ++pr) vtf[dt][pr] = trr_frag(Vh, dt * 16, 2 * pr, gq, lq);
   f32x4 mkT[3];                                          // additive key mask in the log2 domain (keys kt*16 + gq*4 + r), -inf past Lk
 #pragma unroll
-  for (int kt = 0; kt < 3; ++kt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int key = kt * 16 + gq * 4 + r;
-      mkT[kt][r] = key < p.Lk ? (p.kmask ? p.kmask[(size_t)b * p.Lk + key] * 1.4426950408889634f : 0.f) : -INFINITY;
-    }
+  for (int kt = 0; kt < 3; ++kt) mkT[kt] = *reinterpret_cast<const f32x4*>(mkl + kt * 16 + gq * 4);
   const float c2 = p.scale * 1.4426950408889634f;
   const int nstrips = p.Lq >> 4;
   const bf16* qbase = p.q + (size_t)b * p.Lq * p.ldq + h * 32 + gq * 8;
