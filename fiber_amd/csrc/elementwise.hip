@@ -323,30 +323,49 @@ __global__ __launch_bounds__(256) void stream_add_bwd_kernel(StreamAddBwdArgs p)
   uint64_t sa = p.seed_a, sb = p.seed_b;
   if (p.seed_base) { sa += *p.seed_base; sb += *p.seed_base; }
   float acc = 0.f;
-  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < p.nvec; i += (size_t)gridDim.x * 256) {
-    const float rs = p.rowscale ? p.rowscale[i / p.vec_per_sample] : 1.f;
-    const bf16x8 dv = reinterpret_cast<const bf16x8*>(p.dy)[i];
-    float g[8];
+  // Four vectors per thread and iteration, every load issued before the first use: with the grid capped at 512 workgroups for the gate's one
+  // atomic per workgroup, one 16-byte load per thread in flight left the kernel at 4.1 TB/s of its bytes (LayerNorm: 5.4).
+  constexpr int U = 4;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i0 = blockIdx.x * (size_t)256 + threadIdx.x; i0 < p.nvec; i0 += stride * U) {
+    bf16x8 dvs[U], bvs[U];
+    float rss[U];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) g[e] = rs * bf2f(dv[e]);
-    if (p.da) {
-      bf16x8 o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        o[e] = f2bf(p.thresh_a ? (drop_keep(sa, i * 8 + e, p.thresh_a) ? g[e] * p.inv_keep_a : 0.f) : g[e]);
-      reinterpret_cast<bf16x8*>(p.da)[i] = o;
-    }
-    if (p.db) {
-      bf16x8 bv;
-      if (p.dalpha) bv = reinterpret_cast<const bf16x8*>(p.b)[i];
-      bf16x8 o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float m = p.thresh_b ? (drop_keep(sb, i * 8 + e, p.thresh_b) ? p.inv_keep_b : 0.f) : 1.f;
-        o[e] = f2bf(al * m * g[e]);
-        if (p.dalpha) acc += g[e] * m * bf2f(bv[e]);
+    for (int u = 0; u < U; ++u) {
+      const size_t i = i0 + u * stride;
+      if (i < p.nvec) {
+        dvs[u] = reinterpret_cast<const bf16x8*>(p.dy)[i];
+        if (p.db && p.dalpha) bvs[u] = reinterpret_cast<const bf16x8*>(p.b)[i];
+        rss[u] = p.rowscale ? p.rowscale[i / p.vec_per_sample] : 1.f;
       }
-      reinterpret_cast<bf16x8*>(p.db)[i] = o;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = i0 + u * stride;
+      if (i >= p.nvec) break;
+      const float rs = rss[u];
+      const bf16x8 dv = dvs[u];
+      float g[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = rs * bf2f(dv[e]);
+      if (p.da) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          o[e] = f2bf(p.thresh_a ? (drop_keep(sa, i * 8 + e, p.thresh_a) ? g[e] * p.inv_keep_a : 0.f) : g[e]);
+        reinterpret_cast<bf16x8*>(p.da)[i] = o;
+      }
+      if (p.db) {
+        const bf16x8 bv = bvs[u];
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float m = p.thresh_b ? (drop_keep(sb, i * 8 + e, p.thresh_b) ? p.inv_keep_b : 0.f) : 1.f;
+          o[e] = f2bf(al * m * g[e]);
+          if (p.dalpha) acc += g[e] * m * bf2f(bv[e]);
+        }
+        reinterpret_cast<bf16x8*>(p.db)[i] = o;
+      }
     }
   }
   if (p.dalpha) {
