@@ -292,7 +292,22 @@ __global__ __launch_bounds__(256) void tn_fold_kernel(const float* ws, const flo
   if (i < nk4) {
     const float4* p = reinterpret_cast<const float4*>(ws) + i;
     float4 t = p[0];
-    for (int s = 1; s < S; ++s) {
+    int s = 1;
+    for (; s + 8 <= S; s += 8) {                          // eight slabs requested before the first add (same summation order)
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(long)(s + u) * nk4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { t.x += v[u].x; t.y += v[u].y; t.z += v[u].z; t.w += v[u].w; }
+    }
+    for (; s + 4 <= S; s += 4) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = p[(long)(s + u) * nk4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { t.x += v[u].x; t.y += v[u].y; t.z += v[u].z; t.w += v[u].w; }
+    }
+    for (; s < S; ++s) {
       const float4 v = p[(long)s * nk4];
       t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
     }
