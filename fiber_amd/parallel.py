@@ -4,6 +4,7 @@ The reference trains with Lightning DDP (`pl.Trainer(accelerator="ddp")`, coarse
 gradient all-reduce overlapped with backward.  The only collective on this path is that all-reduce.
 """
 import os
+from datetime import timedelta
 
 import torch
 import torch.distributed as dist
@@ -17,9 +18,16 @@ def init_distributed(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost", "::1"):
+            # one node: rendezvous and gloo pairs over the loopback interface -- the container hostname may resolve to an
+            # address no local process can reach, and gloo then waits for its full mesh until the group timeout
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
-        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        # bounded rendezvous and collectives (torch's default is 30 minutes: one unlucky rendezvous must not eat a whole run)
+        timeout = timedelta(seconds=int(os.environ.get("FIBER_DIST_TIMEOUT", "120")))
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=timeout, **kw)
     return rank, local, world
 
 

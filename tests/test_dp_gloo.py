@@ -5,13 +5,13 @@ structure hazards as the real one: a parameter that is never used (must be froze
 used twice per step.  Checks: averaged gradients == single-process gradients over the concatenated batch, and weights
 stay identical across ranks after optimizer steps."""
 import os
-import socket
 
 import pytest
 import torch
 import torch.distributed as dist
-import torch.multiprocessing as mp
 import torch.nn as nn
+
+from mp_util import free_port, run_bounded, spawn_bounded
 
 
 class Toy(nn.Module):
@@ -57,12 +57,9 @@ def _worker(rank, world, port, out):
 
 
 def test_ddp_gradients_match_single_process(tmp_path):
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    port = free_port()
     out = str(tmp_path / "r0.pt")
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    spawn_bounded(_worker, (2, port, out), nprocs=2, deadline_s=150)
     res = torch.load(out)
     assert res["same"], "weights diverged across ranks"
     ref = Toy()
@@ -120,12 +117,9 @@ def _worker_collectives(rank, world, port, out):
 
 
 def test_world2_gather_queue_metrics_bf16_hook_no_sync(tmp_path):
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    port = free_port()
     out = str(tmp_path / "r0.pt")
-    mp.spawn(_worker_collectives, args=(2, port, out), nprocs=2, join=True)
+    spawn_bounded(_worker_collectives, (2, port, out), nprocs=2, deadline_s=150)
     res = torch.load(out)
     assert torch.equal(res["gather"], torch.tensor([[1.0] * 3] * 2 + [[2.0] * 3] * 2))
     # 8 samples through a 6-slot queue: pointer (0 + 4 + 4) % 6 = 2, total 8; slots 4,5,0,1 hold round 2 (11,11,12,12), 2,3 round 1 (2,2)
@@ -199,12 +193,9 @@ def _queue_worker(rank, world, port, out):
 def test_itc_queue_all_gather_world2(tmp_path):
     """fiber_module.py:181-222 under 2 ranks: every rank enqueues the all-gathered batch in rank order, so the queues stay
     identical across ranks; queue_ptr wraps, queue_total keeps counting."""
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    port = free_port()
     out = str(tmp_path / "q")
-    mp.spawn(_queue_worker, args=(2, port, out), nprocs=2, join=True)
+    spawn_bounded(_queue_worker, (2, port, out), nprocs=2, deadline_s=150)
     a, b = torch.load(out + ".0"), torch.load(out + ".1")
     for k in a:
         assert torch.equal(a[k], b[k]), k
@@ -222,14 +213,12 @@ def test_itc_queue_all_gather_world2(tmp_path):
     assert torch.equal(a["image_queue"][:, 2:6], torch.cat([feats[(0, 0)], feats[(0, 1)]])[2:6].T)   # survivors of step 0
 
 
-def _run_bench(args, extra_env=None, timeout=600):
-    import subprocess
+def _run_bench(args, extra_env=None, timeout=240):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(extra_env or {})
-    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, cwd=root, env=env, capture_output=True,
-                          text=True, timeout=timeout)
+    return run_bounded([sys.executable, os.path.join(root, "bench.py")] + args, timeout, cwd=root, env=env)
 
 
 def test_bench_gpus_n_spawns_n_ranks_without_a_launcher():

@@ -2,12 +2,12 @@
 (backend gloo, CUDA tensors) -- exercises exactly the wiring bench.py uses at N>1 (frozen unused parameters, static
 reducer, custom autograd Functions feeding DDP's bucket hooks), which cannot be run over RCCL on a 1-GPU box."""
 import os
-import socket
 
 import pytest
 import torch
 import torch.distributed as dist
-import torch.multiprocessing as mp
+
+from mp_util import free_port, run_bounded, spawn_bounded
 
 pytestmark = pytest.mark.gpu
 
@@ -60,12 +60,9 @@ def _worker(rank, world, port, out):
 
 def test_two_rank_ddp_on_one_gpu(tmp_path):
     assert torch.cuda.is_available()
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    port = free_port()
     out = str(tmp_path / "r0.pt")
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    spawn_bounded(_worker, (2, port, out), nprocs=2, deadline_s=180)
     res = torch.load(out)
     assert res["finite"] and all(l == l for l in res["losses"])
     assert res["same"], "parameters diverged across DDP ranks (gradient all-reduce / frozen-parameter wiring is wrong)"
@@ -135,12 +132,9 @@ def _worker_no_sync(rank, world, port, out):
 
 def test_no_sync_gradient_accumulation_real_module(tmp_path):
     assert torch.cuda.is_available()
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    port = free_port()
     out = str(tmp_path / "r0.pt")
-    mp.spawn(_worker_no_sync, args=(2, port, out), nprocs=2, join=True)
+    spawn_bounded(_worker_no_sync, (2, port, out), nprocs=2, deadline_s=180)
     res = torch.load(out)
     assert res["worst"] < 1e-3, res          # identical kernels on identical inputs; only the fp32 summation order differs
 
@@ -150,17 +144,13 @@ def test_bench_contract_two_ranks_one_gpu():
     switched to gloo so that two ranks can share the one visible GPU: rank 0 must print ONE JSON line with the contract keys,
     n_gpus = 2 and a whole-job value."""
     import json
-    import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    port = free_port()
     env = dict(os.environ, FIBER_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8"]
-    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    res = run_bounded(cmd, 240, cwd=root, env=env)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
@@ -179,13 +169,12 @@ def test_bench_self_spawns_two_ranks_one_gpu():
     """`python bench.py --gpus 2` with NO external launcher: bench.py re-executes itself under torch.distributed.run, the two
     ranks share the one visible GPU over gloo, and rank 0 prints the contract line with n_gpus = 2 and the process-group size."""
     import json
-    import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["FIBER_DIST_BACKEND"] = "gloo"
-    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8",
-                          "--no-extras"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    res = run_bounded([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8",
+                       "--no-extras"], 240, cwd=root, env=env)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
