@@ -785,9 +785,9 @@ int launch_bwd(AttnP& p, float* delta, float* dbias_table, float* dbias_ws, int 
   return FIBER_OK;
 }
 
-bool attr_done = false;
+bool attr_done[16] = {};
 void ensure_attrs() {
-  if (attr_done) return;
+  if (!fiber_first_on_device(attr_done)) return;
   const int big = 160 * 1024;
   hipFuncSetAttribute((const void*)attn_fwd_kernel<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   hipFuncSetAttribute((const void*)attn_fwd_kernel<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
@@ -801,7 +801,6 @@ void ensure_attrs() {
   hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  attr_done = true;
 }
 
 }  // namespace
@@ -830,7 +829,7 @@ int fiber_i2t_fwd_launch(const void* q, const void* k, const void* v, const floa
 // --------------------------------------------------------------------------------------------------- C ABI
 // Window attention in image-token order.  qkv: [B*Hres*Wres, 3C] bf16 with channel layout [3][heads][32]
 // (swin_transformer.py:202) or, with head_major = 1, [heads][3][32] (the caller permutes the qkv weight rows: q|k|v of a
-// head become one contiguous 192-byte run per token, which raises cache-line efficiency of the per-head gathers); o: [B*Hres*Wres, C]; bias_table fp32 [(2ws-1)^2, heads]; lse fp32 [B*Hres*Wres, heads].
+// head become one contiguous 192-byte run per token, which raises cache-line efficiency of the per-head gathers); o: [B*Hres*Wres, C]; bias_table fp32 [(2ws-1)^2, heads]; lse: fp32, B*Hres*Wres*heads values whose LAYOUT is private to the path a window size takes -- [image][head][token] for N <= 336 (win_attn.hip), [token][head] for the generic path; forward and backward of one size always take the same path, nothing else may read it.
 // shift = 0 disables the cyclic shift and the region mask.  head_dim must be 32.
 extern "C" int fiber_window_attn_fwd_bf16(const void* qkv, const float* bias_table, void* o, float* lse, int B, int Hres,
                                           int Wres, int C, int heads, int ws, int shift, int head_major, hipStream_t stream) {

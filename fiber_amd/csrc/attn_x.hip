@@ -738,7 +738,7 @@ __global__ __launch_bounds__(512, 3) void i2t_fwd_kernel(XF p) {
   }
 }
 
-bool x_attr = false;
+bool x_attr[16] = {};            // per device: function attributes are per-device state
 
 }  // namespace
 
@@ -750,7 +750,7 @@ int fiber_i2t_bwd_launch(const void* q, const void* k, const void* v, const floa
   if (Lk > 48 || Lk <= 0 || (Lq & 15) || (heads & 3) || (ldq & 7) || (ldk & 7) || (ldv & 7) || (ldo & 7) || (lddo & 7) || (lddq & 7) || (lddk & 3) ||
       (lddv & 3) || scale <= 0.f)
     return FIBER_EINVAL;
-  if (!x_attr) { hipFuncSetAttribute((const void*)i2t_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); x_attr = true; }
+  if (fiber_first_on_device(x_attr)) hipFuncSetAttribute((const void*)i2t_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   XP p;
   p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.o = (const bf16*)o; p.dout = (const bf16*)dout;
   p.dq = (bf16*)dq; p.dk = (bf16*)dk; p.dv = (bf16*)dv; p.lse = lse; p.kmask = kmask;

@@ -20,6 +20,16 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
     if (e__ != hipSuccess) return FIBER_ELAUNCH;      \
   } while (0)
 
+// hipFuncSetAttribute is per-DEVICE state: a launcher's "attributes already set" flag is indexed by the current device.
+// Returns true exactly once per device (and always when the device cannot be identified, which only costs the repeated calls).
+inline bool fiber_first_on_device(bool (&seen)[16]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return true;
+  if (seen[dev]) return false;
+  seen[dev] = true;
+  return true;
+}
+
 __device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
 __device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }
 

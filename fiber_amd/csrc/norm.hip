@@ -310,8 +310,9 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
     else if (nvec <= 64) KERNEL(64, 1, LN_U, __VA_ARGS__);                                  \
     else if (nvec <= 128) KERNEL(64, 2, LN_U2, __VA_ARGS__);                                \
     else if (nvec <= 256) KERNEL(64, 4, 1, __VA_ARGS__);                                    \
+    else if (nvec <= 384) KERNEL(64, 6, 1, __VA_ARGS__);   /* 4C = 3072: Swin-L's last merge */ \
     else if (nvec <= 512) {                                                                 \
-      /* (the PatchMerging forms stop at 4C = 2048, Swin-B's last merge; their 4096-wide instance spilled 52 bytes) */ \
+      /* (the PatchMerging forms stop at 4C = 3072; their 4096-wide instance spilled 52 bytes and no registered model has it) */ \
       if constexpr (MERGE) return FIBER_EINVAL; else KERNEL(64, 8, 1, __VA_ARGS__);         \
     } else return FIBER_EINVAL;                                                             \
   } while (0)

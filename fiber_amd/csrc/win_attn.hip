@@ -1220,9 +1220,9 @@ __global__ __launch_bounds__(256) void win_dbias_gather_kernel(const float* __re
   dtable[(size_t)e * H + h] = s0 + s1;
 }
 
-bool attrs_set = false;
+bool attrs_set[16] = {};
 void ensure_attrs() {
-  if (attrs_set) return;
+  if (!fiber_first_on_device(attrs_set)) return;
   const int big = 160 * 1024;
   hipFuncSetAttribute((const void*)win_fwd_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   hipFuncSetAttribute((const void*)win_bwd_dq_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
@@ -1233,7 +1233,6 @@ void ensure_attrs() {
   hipFuncSetAttribute((const void*)win_bwd_dkv_kernel<3, 0, 21, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   hipFuncSetAttribute((const void*)win_bwd_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   hipFuncSetAttribute((const void*)win_bwd_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  attrs_set = true;
 }
 
 // waves per workgroup / strip groups of the three passes
@@ -1303,6 +1302,8 @@ namespace {
 // Used by attn.hip's C entry points when the window fits the specialised path (head_dim 32, N <= 160).
 int fiber_win_fwd_launch(const void* qkv, const float* bias_table, void* o, float* lse, int B, int Hres, int Wres, int C,
                          int heads, int ws, int shift, int hmajor, hipStream_t st) {
+  // channel layouts 0..2 everywhere; the planar probe layouts 3 / 4 exist only in the 12 x 12 forward and fused backward
+  if (hmajor < 0 || hmajor > 4 || (hmajor >= 3 && ws * ws != 144)) return FIBER_EINVAL;
   ensure_attrs();
   WinP p = make(qkv, B, Hres, Wres, C, heads, ws, shift, hmajor);
   p.o = (bf16*)o; p.lse = lse; p.bias_table = bias_table;
@@ -1332,6 +1333,7 @@ extern "C" int fiber_fold_rows_f32(const float* part, float* out, int rows, int 
 int fiber_win_bwd_launch(const void* qkv, const float* bias_table, const void* o, const void* dout, const float* lse,
                          void* dqkv, float* dbias_table, float* delta_ws, float* dbias_ws, float* dqkv_colsum, float* colsum_ws,
                          int B, int Hres, int Wres, int C, int heads, int ws, int shift, int hmajor, hipStream_t st) {
+  if (hmajor < 0 || hmajor > 4 || (hmajor >= 3 && ws * ws != 144)) return FIBER_EINVAL;
   ensure_attrs();
   WinP p = make(qkv, B, Hres, Wres, C, heads, ws, shift, hmajor);
   p.o = (bf16*)o; p.lse = (float*)lse; p.bias_table = bias_table; p.dout = (const bf16*)dout; p.dqkv = (bf16*)dqkv;

@@ -79,7 +79,10 @@ int fiber_patch_merge_ln_bwd_stream(const void* dy, const void* x, const float* 
 
 /* Swin (shifted) window attention in image-token order: roll + window_partition + WindowAttention self-attn core +
  * window_reverse + roll (swin_transformer.py:99-126, 195-219, 364-387, mask 327-350).  qkv [B*H*W,3C] -> o [B*H*W,C]. */
-/* head_major: 0 = reference channel layout [3][heads][32]; 1 = [heads][3][32] (qkv weight rows permuted by the caller) */
+/* head_major: 0 = reference channel layout [3][heads][32]; 1 = [heads][3][32] (qkv weight rows permuted by the caller);
+ * 2 = [heads][q | k v] line layout; 3, 4 = planar probe layouts, 12 x 12 windows only (anything else -> FIBER_EINVAL).
+ * lse: B*Hres*Wres*heads fp32 values saved by the forward for the backward of the SAME call shape; its layout is private
+ * ([image][head][token] for windows of <= 336 tokens, [token][head] above) -- no other consumer may interpret it. */
 int fiber_window_attn_fwd_bf16(const void* qkv, const float* bias_table, void* o, float* lse, int B, int Hres, int Wres, int C,
                                int heads, int ws, int shift, int head_major, fiber_stream_t stream);
 int fiber_window_attn_bwd_slices(int n_windows, int heads);

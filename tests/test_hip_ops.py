@@ -100,7 +100,7 @@ def test_gemm_large_tiles(ops, M, N, K, mode):
         assert_close("colsum", e1, y1.float().sum(0), 2e-3)
 
 
-@pytest.mark.parametrize("rows,C", [(1000, 128), (77, 32), (513, 96), (1280, 768), (300, 2048), (9216, 256)])
+@pytest.mark.parametrize("rows,C", [(1000, 128), (77, 32), (513, 96), (1280, 768), (300, 2048), (9216, 256), (100, 3072), (100, 4096)])
 def test_layernorm(ops, rows, C):
     x = bf(rnd(rows, C) * 1.5 + 0.3).requires_grad_(True)
     g, b = (1 + 0.1 * rnd(C)).to(DEV).requires_grad_(True), (0.1 * rnd(C, seed=1)).to(DEV).requires_grad_(True)
@@ -117,7 +117,8 @@ def test_layernorm(ops, rows, C):
     assert_close("dbeta", b.grad, br.grad, 3e-3)
 
 
-@pytest.mark.parametrize("B,H,W,C", [(2, 8, 8, 32), (1, 24, 24, 512), (3, 12, 12, 96)])
+# (2, 14, 14, 768): 4C = 3072, Swin-L's last PatchMerging (swin_large_patch4_window7_224 / window12_384 are registered factories)
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 8, 32), (1, 24, 24, 512), (3, 12, 12, 96), (2, 14, 14, 768)])
 def test_patch_merge_ln(ops, B, H, W, C):
     x = bf(rnd(B, H * W, C)).requires_grad_(True)
     g, b = (1 + 0.1 * rnd(4 * C)).to(DEV).requires_grad_(True), (0.1 * rnd(4 * C, seed=1)).to(DEV).requires_grad_(True)
