@@ -138,8 +138,9 @@ class SwinTransformerBlock(nn.Module):
         u, x = ops.layernorm_res(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         rv = 1.0 / (1.0 - dp) if dp > 0.0 else None
         x = self.attn(u, (H, W), self.shift_size, shortcut=x, y=y, y_mask=y_mask, rowscale=s1, rowscale_value=rv)
-        v, x = ops.layernorm_res(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        return ops.mlp(v, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=x, rowscale=s2, rowscale_value=rv)
+        # norm2 -> Mlp -> DropPath -> residual (swin_transformer.py:391): one kernel per direction at C = 128 / 256 (csrc/mlp_rows.hip)
+        return ops.ln_mlp(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, self.mlp.fc1.weight, self.mlp.fc1.bias,
+                          self.mlp.fc2.weight, self.mlp.fc2.bias, rowscale=s2, rowscale_value=rv)
 
 
 class PatchMerging(nn.Module):

@@ -621,6 +621,115 @@ def mlp(x, w1, b1, w2, b2, residual=None, rowscale=None, rowscale_value=None):
     return with_f32(y, y32)
 
 
+# ---- LayerNorm + Mlp + DropPath + residual as one kernel per direction (csrc/mlp_rows.hip; Swin stages with C = 128 / 256) -------------
+_LN_MLP = os.environ.get("FIBER_LN_MLP", "1") != "0"          # A/B switch: 0 = layernorm_res + mlp (separate kernels)
+_fa_perms = {}
+
+
+def _fa_perm(K, device):
+    """Column order of the kernel's weight copies: position p holds logical index p with bits 2 and 3 swapped (mlp_rows.hip)."""
+    key = (K, device)
+    if key not in _fa_perms:
+        i = torch.arange(K, device=device)
+        _fa_perms[key] = (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1)
+    return _fa_perms[key]
+
+
+def _fa(m16):
+    return m16[:, _fa_perm(m16.shape[1], m16.device)].contiguous()
+
+
+def _ln_mlp_weights(gamma, beta, w1, b1, w2):
+    """(w1p, b1p, w2p, w2tp, w1tp): LayerNorm's affine part folded into fc1 (W1' = W1 diag(gamma), b1' = b1 + W1 beta, formed in
+    fp32, ONE bf16 rounding); the copies whose K dimension is the hidden one (w2p, w1tp) in the kernel's K order; rebuilt when any of
+    the five parameters changes."""
+    key = ("LNMLP", id(w1))
+    stamp = tuple(_stamp(t) for t in (gamma, beta, w1, b1, w2))
+    hit = _cache_get(key, w1)
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    with torch.no_grad():
+        w1f = w1.detach().float()
+        w1p16 = (w1f * gamma.detach().float()[None, :]).to(BF16)
+        b1p = torch.addmv(b1.detach().float(), w1f, beta.detach().float()).contiguous()
+        w2_16 = w2.detach().to(BF16)
+        val = (w1p16.contiguous(), b1p, _fa(w2_16), w2_16.t().contiguous(), _fa(w1p16.t()))
+    _cache_put(key, stamp, val, w1)
+    return val
+
+
+# widths the fused kernels are USED at (they exist for 128 and 256; FIBER_LN_MLP_WIDTHS=128,256 for A/B runs).  Measured at 512 images,
+# forward + backward (tools/lnmlp_bench.py, gpurun_out/r06_lnmlp_bench_5.log): C = 128 9.24 ms against 11.11 ms for the separate kernels,
+# C = 256 6.68 against 6.12 (one wave per SIMD at that width: nothing runs under its GELU arithmetic) -- so 128 only.
+_LN_MLP_WIDTHS = tuple(int(v) for v in os.environ.get("FIBER_LN_MLP_WIDTHS", "128").split(",") if v)
+
+
+def ln_mlp_eligible(x, C):
+    return _LN_MLP and C in _LN_MLP_WIDTHS and C in (128, 256) and x.is_cuda and x.dtype == BF16 and f32_of(x) is None
+
+
+class _LnMlp(torch.autograd.Function):
+    """y = x + rowscale * Mlp(LN(x))  (swin_transformer.py:391) on csrc/mlp_rows.hip: the forward reads x, writes y and (when a
+    backward will follow) gelu(H) -- no LayerNorm output, no pre-activation in HBM; the backward recomputes the pre-activation from
+    x, returns dx (LayerNorm backward and residual gradient included) and hands dH / xhat to the fc1 weight-gradient GEMM.
+    The LayerNorm's gamma / beta ride in the fc1 weight copy, so their gradients come out of dW1' and db1:
+    dW1 = dW1' diag(gamma) + db1 (x) beta, dgamma = colsum(dW1' * W1), dbeta = W1^T db1."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, w1, b1, w2, b2, rowscale, rs_value):
+        shp = x.shape
+        C = shp[-1]
+        x2 = _c(x).view(-1, C)
+        M = x2.shape[0]
+        w1p, b1p, w2p, _, _ = _ln_mlp_weights(gamma, beta, w1, b1, w2)
+        y = torch.empty_like(x2)
+        need_bwd = any(ctx.needs_input_grad[:8])
+        g = torch.empty((M, 4 * C), dtype=BF16, device=x2.device) if need_bwd else None    # gelu(H): the fc2 weight gradient's operand
+        rps = M // rowscale.numel() if rowscale is not None else 0
+        lib.call("fiber_ln_mlp_fwd_bf16", lib.ptr(x2), lib.ptr(w1p), lib.ptr(b1p), lib.ptr(w2p), lib.ptr(b2.detach()), lib.ptr(rowscale),
+                 lib.ptr(y), lib.ptr(g), M, C, rps, float(eps))
+        if need_bwd:
+            ctx.save_for_backward(x2, gamma, beta, w1, b1, w2, rowscale, g)
+        ctx.eps, ctx.shp, ctx.rs_value = float(eps), shp, rs_value
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, gamma, beta, w1, b1, w2, rowscale, g = ctx.saved_tensors
+        M, C = x2.shape
+        H = 4 * C
+        dy2 = _c(dy).view(M, C)
+        w1p, b1p, _, w2tp, w1tp = _ln_mlp_weights(gamma, beta, w1, b1, w2)
+        dx = torch.empty_like(x2)
+        dh = torch.empty((M, H), dtype=BF16, device=x2.device)
+        xhat = torch.empty_like(x2)
+        rps = M // rowscale.numel() if rowscale is not None else 0
+        lib.call("fiber_ln_mlp_bwd_bf16", lib.ptr(x2), lib.ptr(dy2), lib.ptr(w1p), lib.ptr(b1p), lib.ptr(w2tp), lib.ptr(w1tp),
+                 lib.ptr(rowscale), lib.ptr(dx), lib.ptr(dh), lib.ptr(xhat), M, C, rps, ctx.eps)
+        dw1p, db1 = wgrad(dh, xhat, want_bias=True)
+        del dh, xhat
+        if rowscale is None:
+            dw2, db2 = wgrad(dy2, g, want_bias=True)
+        elif droppath_foldable(M, rowscale, ctx.rs_value):
+            dw2, db2 = wgrad(dy2, g, want_bias=True, row_mask=rowscale, scale=ctx.rs_value)
+        else:
+            dys, db2 = rowscale_colsum(dy2, rowscale)
+            dw2 = wgrad(dys, g)
+        w1f, gf = w1.detach().float(), gamma.detach().float()
+        dgamma = (dw1p * w1f).sum(0)
+        dbeta = torch.mv(w1f.t(), db1)
+        dw1 = torch.addcmul(torch.outer(db1, beta.detach().float()), dw1p, gf[None, :])    # xn = xhat gamma + beta feeds fc1
+        return dx.view(ctx.shp), dgamma, dbeta, None, dw1, db1, dw2, db2, None, None
+
+
+def ln_mlp(x, gamma, beta, eps, w1, b1, w2, b2, rowscale=None, rowscale_value=None):
+    """x + DropPath(Mlp(LayerNorm(x))) of a Swin block; the fused kernels when ln_mlp_eligible(x, C), else layernorm_res + mlp."""
+    if ln_mlp_eligible(x, x.shape[-1]) and w1.shape[0] == 4 * x.shape[-1]:
+        return _LnMlp.apply(x, gamma, beta, eps, w1, b1, w2, b2, rowscale, rowscale_value)
+    v, r = layernorm_res(x, gamma, beta, eps)
+    return mlp(v, w1, b1, w2, b2, residual=r, rowscale=rowscale, rowscale_value=rowscale_value)
+
+
 def _ln_fwd(x2, x32, gamma, beta, eps, want_f32):
     """LayerNorm rows of x2 (bf16) or of its fp32 payload x32 -> (y bf16, y32 or None, mean, rstd)."""
     rows, C = x2.shape

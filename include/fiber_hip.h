@@ -77,6 +77,22 @@ int fiber_patch_merge_ln_bwd_stream(const void* dy, const void* x, const float* 
                                     void* dx, float* dgamma, float* dbeta, float* workspace, int B, int H, int W, int C, int flags,
                                     fiber_stream_t stream);
 
+/* LayerNorm + Mlp + DropPath + residual of a Swin block as one kernel per direction (csrc/mlp_rows.hip), C in {128, 256}:
+ *   y = x + rowscale[row / rows_per_sample] * (fc2(gelu(fc1(LN(x)))) + b2)
+ * replaces norm2 -> timm Mlp -> drop_path -> residual add of SwinTransformerBlock.forward (swin_transformer.py:391; Mlp :325,
+ * LayerNorm :320).  The LayerNorm's affine part arrives folded into fc1 (w1p = bf16(W1 diag(gamma)) [4C, C], b1p = b1 + W1 beta
+ * [4C], fp32); w2p = FA(W2) [C, 4C]; FA(.) = bf16 copy whose K columns are stored in the order "bits 2 and 3 of the index
+ * swapped".  The pre-activation stays on chip; g (optional, bf16 [M, 4C]) receives gelu(H) for the backward.  rowscale NULL = no
+ * DropPath. */
+int fiber_ln_mlp_fwd_bf16(const void* x, const void* w1p, const float* b1p, const void* w2p, const float* b2, const float* rowscale,
+                          void* y, void* g, int M, int C, int rows_per_sample, float eps, fiber_stream_t stream);
+/* backward from x and dy (the pre-activation is recomputed): dx [M, C] = dy + LayerNorm-backward of the branch gradient, plus the
+ * operands of the fc1 weight-gradient GEMM (fiber_gemm_tn_bf16): dh = rowscale (dy W2) gelu'(H) [M, 4C], xhat = (x - mean) rstd
+ * [M, C], bf16.  w2tp = bf16(W2^T) [4C, C], w1tp = FA((W1 diag(gamma))^T) [C, 4C]. */
+int fiber_ln_mlp_bwd_bf16(const void* x, const void* dy, const void* w1p, const float* b1p, const void* w2tp, const void* w1tp,
+                          const float* rowscale, void* dx, void* dh, void* xhat, int M, int C, int rows_per_sample, float eps,
+                          fiber_stream_t stream);
+
 /* Swin (shifted) window attention in image-token order: roll + window_partition + WindowAttention self-attn core +
  * window_reverse + roll (swin_transformer.py:99-126, 195-219, 364-387, mask 327-350).  qkv [B*H*W,3C] -> o [B*H*W,C]. */
 /* head_major: 0 = reference channel layout [3][heads][32]; 1 = [heads][3][32] (qkv weight rows permuted by the caller);

@@ -100,6 +100,68 @@ def test_gemm_large_tiles(ops, M, N, K, mode):
         assert_close("colsum", e1, y1.float().sum(0), 2e-3)
 
 
+def _ln_mlp_ref(x, g, b, w1, b1, w2, b2, scale_rows):
+    xn = F.layer_norm(x, (x.shape[-1],), g, b, 1e-5)
+    br = F.linear(F.gelu(F.linear(xn, w1, b1)), w2, b2)
+    return x + (br * scale_rows[:, None] if scale_rows is not None else br)
+
+
+# (B, L, C, DropPath): rows that are a multiple of the kernel's 128-row tile and rows that are not (ragged last tile, rows of one
+# strip in two samples), both channel widths, with / without DropPath (one sample dropped), samples whose rows are / are not whole
+# 64-row tiles (the weight-gradient kernel's DropPath fold applies only to the former)
+@pytest.mark.parametrize("B,L,C,dp", [(2, 576, 128, False), (3, 144, 128, True), (2, 2304, 256, True), (5, 49, 256, False),
+                                      (4, 196, 128, True), (1, 9216, 128, False)])
+def test_ln_mlp_fused(ops, B, L, C, dp):
+    """LayerNorm -> fc1 -> GELU -> fc2 -> DropPath -> residual as ONE kernel per direction (csrc/mlp_rows.hip; reference
+    swin_transformer.py:391 with timm Mlp :325) against the fp32 formulation; gradients of x, both LayerNorm parameters (which ride
+    folded in the fc1 weight copy), fc1 and fc2."""
+    H = 4 * C
+    x = bf(rnd(B, L, C) * 1.3 + 0.2).requires_grad_(True)
+    g = (1 + 0.2 * rnd(C, seed=1)).to(DEV).requires_grad_(True)
+    b = (0.2 * rnd(C, seed=2)).to(DEV).requires_grad_(True)
+    w1 = bf(rnd(H, C, std=C ** -0.5, seed=3)).float().requires_grad_(True)
+    b1 = (0.1 * rnd(H, seed=4)).to(DEV).requires_grad_(True)
+    w2 = bf(rnd(C, H, std=H ** -0.5, seed=5)).float().requires_grad_(True)
+    b2 = (0.1 * rnd(C, seed=6)).to(DEV).requires_grad_(True)
+    rs, rv = None, None
+    if dp:
+        rv = 1.25
+        rs = torch.full((B,), rv, device=DEV)
+        rs[B // 2] = 0.0
+    y = ops._LnMlp.apply(x, g, b, 1e-5, w1, b1, w2, b2, rs, rv)           # (the kernels themselves, whatever widths ops.ln_mlp routes to them)
+    ref_in = [t.detach().float().clone().requires_grad_(True) for t in (x, g, b, w1, b1, w2, b2)]
+    scale_rows = rs.repeat_interleave(L) if rs is not None else None
+    yr = _ln_mlp_ref(ref_in[0].view(-1, C), *ref_in[1:], scale_rows).view(B, L, C)
+    assert_close("y", y, yr, 4e-3)
+    dy = bf(rnd(B, L, C, seed=7))
+    y.backward(dy)
+    yr.backward(dy.float())
+    assert_close("dx", x.grad, ref_in[0].grad, 8e-3)
+    for name, t, r in zip(("dgamma", "dbeta", "dw1", "db1", "dw2", "db2"), (g, b, w1, b1, w2, b2), ref_in[1:]):
+        assert_close(name, t.grad, r.grad, 1.2e-2)
+
+
+def test_ln_mlp_fused_matches_separate_kernels(ops):
+    """The fused op against the separate-kernel path it replaces (layernorm_res + mlp) on the same inputs: outputs and input gradients
+    agree to bf16 rounding; both are the same function."""
+    B, L, C = 2, 1152, 128
+    H = 4 * C
+    mk = lambda: [bf(rnd(B, L, C)).requires_grad_(True), (1 + 0.1 * rnd(C, seed=1)).to(DEV).requires_grad_(True),
+                  (0.1 * rnd(C, seed=2)).to(DEV).requires_grad_(True), bf(rnd(H, C, std=C ** -0.5, seed=3)).float().requires_grad_(True),
+                  (0.1 * rnd(H, seed=4)).to(DEV).requires_grad_(True), bf(rnd(C, H, std=H ** -0.5, seed=5)).float().requires_grad_(True),
+                  (0.1 * rnd(C, seed=6)).to(DEV).requires_grad_(True)]
+    a, c = mk(), mk()
+    ya = ops._LnMlp.apply(a[0], a[1], a[2], 1e-5, *a[3:], None, None)
+    v, r = ops.layernorm_res(c[0], c[1], c[2], 1e-5)
+    yc = ops.mlp(v, *c[3:], residual=r)
+    assert_close("y", ya, yc, 6e-3)
+    dy = bf(rnd(B, L, C, seed=7))
+    ya.backward(dy)
+    yc.backward(dy)
+    for i, name in enumerate(("dx", "dgamma", "dbeta", "dw1", "db1", "dw2", "db2")):
+        assert_close(name, a[i].grad, c[i].grad, 1.2e-2)
+
+
 @pytest.mark.parametrize("rows,C", [(1000, 128), (77, 32), (513, 96), (1280, 768), (300, 2048), (9216, 256), (100, 3072), (100, 4096)])
 def test_layernorm(ops, rows, C):
     x = bf(rnd(rows, C) * 1.5 + 0.3).requires_grad_(True)
