@@ -81,7 +81,7 @@ def run(tag, cfg, size, B):
             p.data.fill_(0.5)
     b = detgen.synth_batch(B, size, 40, 50265, seed=0)
     if "train" in LEGS[tag]:
-        for i in range(7):                                    # SURVEY.md 8d: 2 warm-ups + 5 timed, MLM + ITM forward + backward
+        for i in range({warm} + {timed}):                     # SURVEY.md 8d: warm-ups + timed steps, MLM + ITM forward + backward
             t = time.time()
             m.zero_grad(set_to_none=True)
             m.training_loss(b, b["itm_labels"]).backward()
@@ -89,7 +89,7 @@ def run(tag, cfg, size, B):
     if "fwd" in LEGS[tag]:
         m.eval()
         with torch.no_grad():
-            for i in range(7):                                # the fused-backbone forward of one image-text batch (fiber_module.py:224-367)
+            for i in range({warm} + {timed}):                 # the fused-backbone forward of one image-text batch (fiber_module.py:224-367)
                 t = time.time()
                 m.infer(b)
                 print(json.dumps({{"leg": tag + "/fwd", "B": B, "step": i, "sec": time.time() - t}}), flush=True)
@@ -112,11 +112,11 @@ def _cpu_model():
     return "unknown CPU"
 
 
-def _cpu_run(threads, budget_s, batch, legs):
+def _cpu_run(threads, budget_s, batch, legs, warm=2, timed=5):
     """One child process (killed by PID at its deadline): {leg: (median seconds per iteration, timed iterations, batch)}."""
     import subprocess
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
-    proc = subprocess.Popen([sys.executable, "-c", _CPU_SNIPPET.format(root=ROOT, threads=threads, batch=batch, legs=legs)],
+    proc = subprocess.Popen([sys.executable, "-c", _CPU_SNIPPET.format(root=ROOT, threads=threads, batch=batch, legs=legs, warm=warm, timed=timed)],
                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True)
     try:
         out, _ = proc.communicate(timeout=budget_s)
@@ -131,19 +131,21 @@ def _cpu_run(threads, budget_s, batch, legs):
     res = {}
     for leg, rows in by_leg.items():
         secs = [r[0] for r in rows]
-        timed = sorted(secs[2:])                              # 2 warm-ups, median of (up to) 5
-        res[leg] = (timed[len(timed) // 2] if timed else None, len(timed), rows[0][1])
+        done = sorted(secs[warm:])                            # warm-ups dropped, median of the timed steps that finished
+        res[leg] = (done[len(done) // 2] if done else None, len(done), rows[0][1])
     return res
 
 
-def cpu_baseline(budget_s=130.0, batch=2):
+def cpu_baseline(budget_s=280.0, batch=2):
     """The oracle (CPU restatement of the reference path, fp32 PyTorch) timed on this host's cores, the legs BASELINE.md section 4b
     names (2 warm-ups, median of 5 each), every child process under a hard wall-clock budget (killed by PID at the deadline) so that
     the default bench finishes in minutes:
       8 threads (the survey's container reference point): FIBER-Base 384^2 S=40 B=2 MLM+ITM forward + backward (images/s) and the
         fused-backbone forward alone (ms / image); Swin-T 224^2 + RoBERTa-base B=4 (BASELINE.json configs[0]) forward + backward;
-      every physical core: the FIBER-Base train leg at B=8 (at B=2 128 threads have no work to share: round 4 measured it 6.5x
-        SLOWER than 8 threads and finished one timed step) -- reported as a median only when at least 3 timed steps finished.
+      every physical core, run FIRST with a budget of its own (200 s): the FIBER-Base train leg at B=8, 1 warm-up + 2 timed steps.  On the
+        round-6 box (2 x EPYC 9575F, 128 cores; tools/probes/cpu_threads_probe.py) one such step takes 47 s on 128 threads, 21 s on 64,
+        12 s on 32 -- the oracle's many small ops get SLOWER with more threads (8 threads at B=2: 3 s per step = the best rate) -- so
+        this leg is 3 x 47 s + 40 s of set-up; rounds 4-5 gave it 49 s and it never finished.  Reported when both timed steps finished.
     `value` is the best FIBER-Base train-step rate, `cores` its thread count."""
     try:
         avail = len(os.sched_getaffinity(0))
@@ -157,8 +159,9 @@ def cpu_baseline(budget_s=130.0, batch=2):
     except OSError:
         pass
     t8 = min(8, avail)
-    legs8 = _cpu_run(t8, budget_s * 0.62, batch, {"base": ["train", "fwd"], "swin_t": ["train"]})
-    legs_all = _cpu_run(phys, budget_s * 0.38, 8, {"base": ["train"]}) if phys > t8 else {}
+    all_budget = min(200.0, budget_s * 0.72)
+    legs_all = _cpu_run(phys, all_budget, 8, {"base": ["train"]}, warm=1, timed=2) if phys > t8 else {}
+    legs8 = _cpu_run(t8, budget_s - (all_budget if phys > t8 else 0.0), batch, {"base": ["train", "fwd"], "swin_t": ["train"]})
 
     def rate(entry):                                          # images/s of a (seconds, n, B) entry
         return entry[2] / entry[0] if entry and entry[0] else None
@@ -176,11 +179,11 @@ def cpu_baseline(budget_s=130.0, batch=2):
     parts.append(f"Swin-T 224^2 B=4 (configs[0]) train {rate(e):.2f} images/s (median of {e[1]})" if rate(e) else "Swin-T leg did not finish")
     if legs_all or phys > t8:
         e = legs_all.get("base/train")
-        if e and e[0] and e[1] >= 3:
+        if e and e[0] and e[1] >= 2:
             parts.append(f"{phys} threads: FIBER-Base 384^2 B={e[2]} train {rate(e):.3f} images/s (median of {e[1]})")
             cands.append((rate(e), phys))
         else:
-            parts.append(f"{phys} threads, B=8: did not finish a median of 3 timed steps inside its {budget_s * 0.38:.0f} s")
+            parts.append(f"{phys} threads, B=8: did not finish 1 warm-up + 2 timed steps inside its {all_budget:.0f} s")
     base = {"unit": "images/s", "kind": "port",
             "sample": f"oracle/fiber_ref.py MLM+ITM, fp32, on {_cpu_model()} ({avail} logical / {phys} physical cores visible), "
                       f"{budget_s:.0f} s budget, 2 warm-ups + median of up to 5: " + "; ".join(parts)}
@@ -539,6 +542,35 @@ def main():
         if args.task == "mlm_itm" and not args.no_extras:
             res["roofline"]["dominant_kernel"] = time_dominant_kernel(args.batch, device)
             res["roofline"]["traffic"] = res["roofline"]["dominant_kernel"]["traffic"]
+        if world == 1 and args.task == "mlm_itm" and not args.no_extras and not use_graph:
+            # SURVEY.md section 8d names per-GPU batches 8 (the reference README's example), 16 and 32: the same model and optimizer,
+            # 3 warm-up + 10 timed eager steps each, after (and outside) the headline's timed region
+            sweep = {}
+            for b in (8, 16, 32):
+                if b >= args.batch:
+                    continue
+                sb = synth_batch(b, cfg["image_size"], cfg["max_text_len"], cfg["vocab_size"], device, seed=1000 + b)
+
+                def sstep():
+                    ops.set_rng_step(model.global_step)
+                    out = net(sb)
+                    sum(v for k, v in out.items() if "loss" in k).backward()
+                    opt.step()
+                    sched["scheduler"].step()
+                    opt.zero_grad(set_to_none=True)
+                    model.global_step += 1
+                for _ in range(3):
+                    sstep()
+                torch.cuda.synchronize()
+                ts = time.perf_counter()
+                for _ in range(10):
+                    sstep()
+                torch.cuda.synchronize()
+                sec = (time.perf_counter() - ts) / 10
+                sweep[str(b)] = {"images_per_s": round(b / sec, 1), "ms_per_step": round(sec * 1e3, 2),
+                                 "frac_of_mfma_peak": round(b / sec * flop_img / 1e12 / PEAK_BF16_TFLOPS, 4)}
+            res["extra"] = {"batch_sweep": sweep, "batch_sweep_note": "per-GPU batches of SURVEY.md 8d (8 = coarse_grained/README.md:35), "
+                            "same process, 3 warm-up + 10 timed eager steps each, wall clock around a device synchronise"}
         if world == 1 and not args.no_cpu_baseline and args.task == "mlm_itm":
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

@@ -337,10 +337,22 @@ __global__ __launch_bounds__(64 * NW) void ln_mlp_fwd_kernel(MlpP p) {
 
   // (the raw x fragments stay in registers for the residual; the wave's region is the staging image of G during the loop)
   bf16* bank1 = banks + UPP * UNIT;
+  // G rows of a chunk (whole 128-byte rows out of the staging image, 8 per instruction).  Every barrier is preceded by vmcnt(0), which
+  // on this target counts stores too: the rows of chunk j - 1 leave at the START of phase 2j, the long one (a product and the GELU to
+  // drain under), not in the short phase 2j - 1 (measured: + 0.5 ms per call at stage 0 there).
+  auto g_rows_out = [&](int jc) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int rr = q * 8 + (lane >> 3), c = (lane & 7) ^ (rr & 7);
+      const bf16x8 vg = *reinterpret_cast<const bf16x8*>(reg + q * 512 + lane * 8);
+      if (row0 + rr < p.M) *reinterpret_cast<bf16x8*>(p.g + (size_t)(row0 + rr) * HID + jc * 64 + c * 8) = vg;
+    }
+  };
   for (int j = 0; j < NCH; ++j) {
     // ---- phase 2j: H^T chunk from bank 0, GELU; W2 units of the chunk requested into bank 1
 #pragma unroll
     for (int s = 0; s < UPP; ++s) dma_unit<NW>(bank1 + s * UNIT, p.w2p + (size_t)(s * 64) * HID + j * 64, HID, wave, lane);
+    if (p.g && j > 0) g_rows_out(j - 1);
     bf16x8 gf[2][2];
     {
       f32x16 hacc[2];
@@ -372,23 +384,15 @@ __global__ __launch_bounds__(64 * NW) void ln_mlp_fwd_kernel(MlpP p) {
         }
     }
     phase_sync();
-    // ---- phase 2j + 1: next chunk's W1' units into bank 0; G rows out (whole 128-byte rows, 8 per instruction: they have the
-    // product below to drain before the next vmcnt(0)); Y^T += W2 chunk . G^T from bank 1
+    // ---- phase 2j + 1: next chunk's W1' units into bank 0; Y^T += W2 chunk . G^T from bank 1
     if (j + 1 < NCH) {
 #pragma unroll
       for (int s = 0; s < UPP; ++s) dma_unit<NW>(banks + s * UNIT, p.w1p + (size_t)((j + 1) * 64) * C + s * 64, C, wave, lane);
     }
-    if (p.g) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int rr = q * 8 + (lane >> 3), c = (lane & 7) ^ (rr & 7);
-        const bf16x8 vg = *reinterpret_cast<const bf16x8*>(reg + q * 512 + lane * 8);
-        if (row0 + rr < p.M) *reinterpret_cast<bf16x8*>(p.g + (size_t)(row0 + rr) * HID + j * 64 + c * 8) = vg;
-      }
-    }
     product_k_h<MT>(bank1, gf, yacc, n, h);
     phase_sync();
   }
+  if (p.g) g_rows_out(NCH - 1);
 
   // ---- y = x + s (Y + b2) on the C layout's 8-byte pieces (x of those channels out of the B fragments by a lane-pair exchange), through
   // the wave's region, whole rows out
@@ -465,9 +469,19 @@ __global__ __launch_bounds__(64 * NW) void ln_mlp_bwd_kernel(MlpP p) {
     for (int r = 0; r < 16; ++r) dxacc[mt][r] = 0.f;
 
   // phase 2j: H^T and dG^T from bank A, dH / G out; phase 2j + 1: dXhat^T from bank B.  Each phase requests the other bank's next units.
+  auto dh_rows_out = [&](int jc) {                        // (see the forward's g_rows_out for the placement)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int rr = q * 8 + (lane >> 3), c = (lane & 7) ^ (rr & 7);
+      const bf16x8 vd = *reinterpret_cast<const bf16x8*>(reg + q * 512 + lane * 8);
+      if (row0 + rr < p.M) *reinterpret_cast<bf16x8*>(p.dh + (size_t)(row0 + rr) * HID + jc * 64 + c * 8) = vd;
+      pin();
+    }
+  };
   for (int j = 0; j < NCH; ++j) {
 #pragma unroll
     for (int sl = 0; sl < UPP; ++sl) dma_unit<NW>(bankB + sl * UNIT, p.w1tp + (size_t)(sl * 64) * HID + j * 64, HID, wave, lane);
+    if (j > 0) dh_rows_out(j - 1);
     bf16x8 hf[2][2];
     // dH pieces go through a staging image [32 rows][64 hidden] in the wave's region (128-byte rows, 16-byte pieces XOR (row & 7))
 #pragma unroll
@@ -491,8 +505,7 @@ __global__ __launch_bounds__(64 * NW) void ln_mlp_bwd_kernel(MlpP p) {
       }
     }
     phase_sync();
-    // ---- phase 2j + 1: request W1' / W2^T units of the next chunk into bank A; dH rows out (whole 128-byte rows, 8 per instruction:
-    // they have the product below to drain before the next vmcnt(0)); dXhat^T += W1'^T chunk . dH^T
+    // ---- phase 2j + 1: request W1' / W2^T units of the next chunk into bank A; dXhat^T += W1'^T chunk . dH^T
     if (j + 1 < NCH) {
 #pragma unroll
       for (int sl = 0; sl < UPP; ++sl) {
@@ -500,16 +513,10 @@ __global__ __launch_bounds__(64 * NW) void ln_mlp_bwd_kernel(MlpP p) {
         dma_unit<NW>(bankA + (UPP + sl) * UNIT, p.w2tp + (size_t)((j + 1) * 64) * C + sl * 64, C, wave, lane);
       }
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int rr = q * 8 + (lane >> 3), c = (lane & 7) ^ (rr & 7);
-      const bf16x8 vd = *reinterpret_cast<const bf16x8*>(reg + q * 512 + lane * 8);
-      if (row0 + rr < p.M) *reinterpret_cast<bf16x8*>(p.dh + (size_t)(row0 + rr) * HID + j * 64 + c * 8) = vd;
-      pin();
-    }
     product_k_h<MT, (C > 128)>(bankB, hf, dxacc, n, h);
     phase_sync();
   }
+  dh_rows_out(NCH - 1);
 
   // ---- LayerNorm backward (no affine part here) + residual gradient: dx = dy + rstd (a - mean_c(a) - xhat mean_c(a xhat)), on the C
   // layout's pieces; xhat and dy of those channels come out of the B fragments by a lane-pair exchange
