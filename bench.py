@@ -418,6 +418,7 @@ def main():
             p.data.fill_(0.5)          # reference init is 0: fusion branches would carry no signal
     parallel.freeze_unused(model, model.unused_parameter_names())   # never touched on the fused MLM+ITM path
     model.to(device).train()
+    ops.enable_wgrad_stream(model)                          # weight-gradient GEMMs + gradient accumulation on a second stream (before DDP)
     fiber_utils.set_task(model)
     (opt,), (sched,) = model.configure_optimizers()
     net = parallel.wrap_ddp(model, device)

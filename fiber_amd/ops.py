@@ -394,12 +394,73 @@ def lib_linear(x, w, b=None):
     return _LibLinear.apply(x, w, b)
 
 
-def wgrad(dh, x2, want_bias=False, row_mask=None, scale=1.0):
+# Weight-gradient GEMMs on a stream of their own: an EXPERIMENT, off unless FIBER_WGRAD_STREAM=1 (ops.enable_wgrad_stream(model) is
+# called by bench.py and is a no-op without the variable).  dW is needed by nobody before the optimizer step (or DDP's bucket hook),
+# while the next layer's backward only needs dX, so the TN kernel of layer l could share the GPU with the LayerNorm / attention
+# backward of layer l - 1.  Round-6 result at B = 256, same box, interleaved: 265.1 / 266.7 ms with the second stream against 259.8 /
+# 259.8 without -- the kernels contend more than they fill each other's gaps.  (A first, racy version read 239-246 ms: its garbage
+# gradients turned every tensor into NaN after one optimizer step, and a GPU multiplying NaNs draws less power and clocks higher.)
+# Who reads dW first is autograd's AccumulateGrad node: for gradients that come out of a Python Function it CLONES them (it never
+# steals them: tools/probes/wgrad_stream_dbg5.py), on the stream that was current when the parameter's accumulator node was created.
+# So the accumulator nodes of the model's parameters are created under the weight-gradient stream and kept alive (as DDP's reducer
+# keeps them): the clone -- or the add into an existing .grad -- then runs on that stream, in order behind the TN kernel, the engine
+# makes that stream wait for whatever produced the other gradients, and at the end of backward() the caller's stream waits for it.
+_WGRAD_STREAM = [False]
+_wg_streams = {}
+_wg_pending = set()
+_wg_accumulators = {}                # id(parameter) -> (weakref to it, its AccumulateGrad node)
+
+
+def wgrad_stream(device):
+    st = _wg_streams.get(device)
+    if st is None:
+        st = _wg_streams[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def enable_wgrad_stream(module, on=True):
+    """Route the weight-gradient GEMMs of `module`'s parameters (and the accumulation of ALL its gradients) to a second stream.
+    Call it after module.to(device) and BEFORE the first forward / DistributedDataParallel wrap: an accumulator node that already
+    exists keeps the stream it was created on.  enable_wgrad_stream(module, False) switches the routing of the GEMMs off again."""
+    _WGRAD_STREAM[0] = bool(on) and os.environ.get("FIBER_WGRAD_STREAM", "0") == "1"
+    if not _WGRAD_STREAM[0]:
+        return False
+    for p_ in module.parameters():
+        if not (p_.requires_grad and p_.is_cuda) or id(p_) in _wg_accumulators:
+            continue
+        with torch.cuda.stream(wgrad_stream(p_.device)):
+            node = p_.view_as(p_).grad_fn.next_functions[0][0]      # the AccumulateGrad node: created here, on this stream
+        _wg_accumulators[id(p_)] = (weakref.ref(p_, lambda _r, k=id(p_): _wg_accumulators.pop(k, None)), node)
+    return True
+
+
+def wgrad_stream_active(t):
+    """inside a backward pass (grad mode off), not during graph capture, for GEMMs worth a hand-over"""
+    return (_WGRAD_STREAM[0] and t.is_cuda and t.shape[0] >= 4096 and not torch.is_grad_enabled()
+            and not torch.cuda.is_current_stream_capturing())
+
+
+def set_wgrad_stream(on):
+    """Raw switch (tests / probes): routes the GEMMs without touching any accumulator node."""
+    _WGRAD_STREAM[0] = bool(on)
+
+
+def join_wgrad_stream():
+    """The current stream of every device with weight gradients in flight waits for them (DDP bucket hook; the autograd engine itself
+    joins the accumulation streams at the end of backward())."""
+    for dev in list(_wg_pending):
+        torch.cuda.current_stream(dev).wait_stream(_wg_streams[dev])
+    _wg_pending.clear()
+
+
+def wgrad(dh, x2, want_bias=False, row_mask=None, scale=1.0, post=None):
     """dW[N,K] = dh[M,N]^T . x2[M,K] in fp32 on the hand-written TN kernel (csrc/gemm_tn.hip): both operands are read as
     they lie (row-major, M slow) and transposed on the LDS -> register path; the M reduction is split inside the launch
     (fp32 slabs + one fold).  want_bias: also return the column sums of dh (the bias gradient) from the same pass.
     row_mask / scale: DropPath backward folded in -- samples whose factor in `row_mask` is 0 are skipped, the result is
-    multiplied by `scale` (= 1/keep); see droppath_foldable()."""
+    multiplied by `scale` (= 1/keep); see droppath_foldable().
+    post(dw, db): anything the caller computes FROM the result (row permutations, reshapes, the LayerNorm unfolding of ops._LnMlp)
+    -- it runs on the stream the kernel ran on, and its return value is returned instead of (dw, db)."""
     M, N = dh.shape
     K = x2.shape[1]
     assert dh.dtype == BF16 and x2.dtype == BF16 and dh.stride(1) == 1 and x2.stride(1) == 1 and x2.shape[0] == M
@@ -408,9 +469,25 @@ def wgrad(dh, x2, want_bias=False, row_mask=None, scale=1.0):
     S = lib.plain("fiber_gemm_tn_splits", M, N, K)
     ws = torch.empty(S * (N * K + N), dtype=torch.float32, device=dh.device) if S > 1 else None
     rps = (M // row_mask.numel()) if row_mask is not None else 0
-    lib.call("fiber_gemm_tn_bf16", lib.ptr(dh), lib.ptr(x2), lib.ptr(dw), lib.ptr(db), lib.ptr(ws), M, N, K, dh.stride(0), x2.stride(0),
-             lib.ptr(row_mask), rps, float(scale))
-    return (dw, db) if want_bias else dw
+    args = (lib.ptr(dh), lib.ptr(x2), lib.ptr(dw), lib.ptr(db), lib.ptr(ws), M, N, K, dh.stride(0), x2.stride(0), lib.ptr(row_mask), rps,
+            float(scale))
+    finish = (lambda: post(dw, db)) if post is not None else (lambda: (dw, db) if want_bias else dw)
+    if wgrad_stream_active(dh):
+        cur = torch.cuda.current_stream(dh.device)
+        side = wgrad_stream(dh.device)
+        side.wait_stream(cur)                               # the operands' producers
+        with torch.cuda.stream(side):
+            lib.call("fiber_gemm_tn_bf16", *args)
+            out = finish()
+        for t in (dh, x2, row_mask, ws, dw, db):            # memory handed back on `cur` must not be reused under the side stream
+            if t is not None:
+                t.record_stream(side)
+        if not _wg_pending:
+            torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)    # end of this backward pass
+        _wg_pending.add(dh.device)
+        return out
+    lib.call("fiber_gemm_tn_bf16", *args)
+    return finish()
 
 
 def droppath_foldable(rows, rowscale, rs_value):
@@ -706,7 +783,11 @@ class _LnMlp(torch.autograd.Function):
         rps = M // rowscale.numel() if rowscale is not None else 0
         lib.call("fiber_ln_mlp_bwd_bf16", lib.ptr(x2), lib.ptr(dy2), lib.ptr(w1p), lib.ptr(b1p), lib.ptr(w2tp), lib.ptr(w1tp),
                  lib.ptr(rowscale), lib.ptr(dx), lib.ptr(dh), lib.ptr(xhat), M, C, rps, ctx.eps)
-        dw1p, db1 = wgrad(dh, xhat, want_bias=True)
+        w1f, gf, bf_ = w1.detach().float(), gamma.detach().float(), beta.detach().float()
+
+        def unfold(dw1p, db1):      # gradients of LayerNorm's gamma / beta and of W1 out of dW1' (xn = xhat gamma + beta feeds fc1)
+            return (dw1p * w1f).sum(0), torch.mv(w1f.t(), db1), torch.addcmul(torch.outer(db1, bf_), dw1p, gf[None, :]), db1
+        dgamma, dbeta, dw1, db1 = wgrad(dh, xhat, want_bias=True, post=unfold)
         del dh, xhat
         if rowscale is None:
             dw2, db2 = wgrad(dy2, g, want_bias=True)
@@ -715,10 +796,6 @@ class _LnMlp(torch.autograd.Function):
         else:
             dys, db2 = rowscale_colsum(dy2, rowscale)
             dw2 = wgrad(dys, g)
-        w1f, gf = w1.detach().float(), gamma.detach().float()
-        dgamma = (dw1p * w1f).sum(0)
-        dbeta = torch.mv(w1f.t(), db1)
-        dw1 = torch.addcmul(torch.outer(db1, beta.detach().float()), dw1p, gf[None, :])    # xn = xhat gamma + beta feeds fc1
         return dx.view(ctx.shp), dgamma, dbeta, None, dw1, db1, dw2, db2, None, None
 
 
@@ -964,10 +1041,9 @@ class _LinearQKVHeadMajor(torch.autograd.Function):
         wp, _, wpt = _wcache[("HM", id(weight))][1]
         dx = gemm_nt(dy2, wpt)[0].view(ctx.shp)
         if hint is not None:
-            dw, db = wgrad(dy2, x2)[inv], hint[inv]
+            dw, db = wgrad(dy2, x2, post=lambda w_, _b: w_[inv]), hint[inv]
         else:
-            dw, db = wgrad(dy2, x2, want_bias=True)
-            dw, db = dw[inv], db[inv]
+            dw, db = wgrad(dy2, x2, want_bias=True, post=lambda w_, b_: (w_[inv], b_[inv]))
         return dx, dw, db, None
 
 
@@ -1503,8 +1579,8 @@ class _PatchEmbedProj(torch.autograd.Function):
     def backward(ctx, dy):
         (cols,) = ctx.saved_tensors
         dy2 = _c(dy).view(-1, dy.shape[-1])
-        dw, db = wgrad(dy2, cols, want_bias=True)
-        return None, dw[:, :48].reshape(ctx.wshape), db
+        dw, db = wgrad(dy2, cols, want_bias=True, post=lambda w_, b_: (w_[:, :48].reshape(ctx.wshape), b_))
+        return None, dw, db
 
 
 def patch_embed_proj(img, weight, bias):
@@ -1595,11 +1671,8 @@ class _DeformConv(torch.autograd.Function):
                 dx = dxf.to(BF16)
         need_db = ctx.has_bias and ctx.needs_input_grad[4]
         if ctx.needs_input_grad[3]:
-            dw = wgrad(dy2, cols, want_bias=need_db)
-            if need_db:
-                dw, db = dw
-                db = db[:Cout]
-            dw = dw[:Cout].view(Cout, kh, kw, C).permute(0, 3, 1, 2).contiguous()
+            dw, db = wgrad(dy2, cols, want_bias=need_db, post=lambda w_, b_: (
+                w_[:Cout].view(Cout, kh, kw, C).permute(0, 3, 1, 2).contiguous(), b_[:Cout] if b_ is not None else None))
         elif need_db:
             db = colsum(dy2)[:Cout]
         return dx, doff, dmask, dw, db, None, None, None

@@ -70,6 +70,8 @@ def wrap_ddp(model, device=None, bucket_cap_mb=64, bf16_grads=None):
         # on two streams, while the reducer orders the all-reduce only behind the stream of the LAST gradient that arrived.
         # Every gradient of a ready bucket has been enqueued by now: wait for both streams' tails before the collective.
         if on_gpu:
+            from . import ops
+            ops.join_wgrad_stream()                          # (weight gradients on their own stream, FIBER_WGRAD_STREAM=1)
             cur = torch.cuda.current_stream()
             for st in (getattr(model, "_side_stream", None), getattr(model, "_main_stream", None)):
                 if st is not None and st != cur:

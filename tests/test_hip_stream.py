@@ -210,3 +210,48 @@ def test_fused_path_forward_gap_fp32_stream(case):
     assert max(g32) < 3e-3 and sum(g32) / len(g32) < 1.5e-3, (g32, l32)
     assert max(g16) < 6e-3 and sum(g16) / len(g16) < 2.5e-3, (g16, l16)
     assert sum(g32) <= sum(g16) + 2e-3, "the fp32 stream must not be further from the oracle than the bf16 stream"
+
+
+def test_weight_gradients_on_their_own_stream_are_the_same_gradients():
+    """ops.enable_wgrad_stream(model): the TN weight-gradient GEMMs (and whatever the callers derive from their results) run on a second
+    stream, autograd accumulates every gradient of the model on that stream, and backward() joins it.  Same kernels, same inputs: every parameter gradient must be BITWISE the
+    one of the single-stream run (a consumer that read a gradient before the side stream had written it would show up here), three
+    times in a row, on a path that has every kind of caller (head-major qkv permutation, packed projections, patch embedding,
+    the fused LayerNorm-Mlp unfolding at C = 128)."""
+    from fiber_amd import ops
+    from fiber_amd.config import make_config
+    from fiber_amd.modules import FIBERTransformerSS, fiber_utils
+    from oracle import cases, detgen
+    cfg = dict(cases.SWIN_B)
+    torch.manual_seed(0)
+    model = FIBERTransformerSS(make_config(**cfg)).eval()           # eval: no dropout / DropPath draws, both runs compute the same function
+    for n, p in model.named_parameters():
+        if "alpha_" in n:
+            p.data.fill_(0.5)
+    model.to("cuda")
+    fiber_utils.set_task(model)
+    b = detgen.synth_batch(8, 384, 40, 50265, seed=5, min_len=8)
+    bd = {k: (v.to("cuda") if isinstance(v, torch.Tensor) else [t.to("cuda") for t in v] if isinstance(v, list) and isinstance(v[0], torch.Tensor) else v)
+          for k, v in b.items()}
+    bd["itm_labels_override"] = bd["itm_labels"]
+
+    ops.enable_wgrad_stream(model)                           # accumulator nodes on the weight-gradient stream (before the first forward)
+
+    def grads(on):
+        ops.set_wgrad_stream(on)
+        try:
+            model.zero_grad(set_to_none=True)
+            out = model(bd)
+            sum(v for k, v in out.items() if "loss" in k).backward()
+            torch.cuda.synchronize()
+            return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        finally:
+            ops.set_wgrad_stream(False)
+    ref = grads(False)
+    for rep in range(3):
+        got = grads(True)
+        assert got.keys() == ref.keys()
+        bad = [n for n in ref if not torch.equal(ref[n], got[n])]
+        # (fp32 atomics: embedding rows and the gates are summed in an order that differs from run to run -- compare those by value)
+        really = [n for n in bad if (ref[n].float() - got[n].float()).abs().max() > 1e-3 * (ref[n].float().abs().max() + 1e-6)]
+        assert not really, (rep, really[:8])
