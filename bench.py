@@ -545,9 +545,11 @@ def main():
             res["roofline"]["traffic"] = res["roofline"]["dominant_kernel"]["traffic"]
         if world == 1 and args.task == "mlm_itm" and not args.no_extras and not use_graph:
             # SURVEY.md section 8d names per-GPU batches 8 (the reference README's example), 16 and 32: the same model and optimizer,
-            # 3 warm-up + 10 timed eager steps each, after (and outside) the headline's timed region
+            # 8 warm-up + 10 timed eager steps each, after (and outside) the headline's timed region
             sweep = {}
+            batch = None                                     # (release the headline batch)
             for b in (8, 16, 32):
+                torch.cuda.empty_cache()                     # (the headline's 170-GB block cache makes small-batch steps 30 % slower)
                 if b >= args.batch:
                     continue
                 sb = synth_batch(b, cfg["image_size"], cfg["max_text_len"], cfg["vocab_size"], device, seed=1000 + b)
@@ -560,7 +562,7 @@ def main():
                     sched["scheduler"].step()
                     opt.zero_grad(set_to_none=True)
                     model.global_step += 1
-                for _ in range(3):
+                for _ in range(8):
                     sstep()
                 torch.cuda.synchronize()
                 ts = time.perf_counter()
@@ -571,7 +573,7 @@ def main():
                 sweep[str(b)] = {"images_per_s": round(b / sec, 1), "ms_per_step": round(sec * 1e3, 2),
                                  "frac_of_mfma_peak": round(b / sec * flop_img / 1e12 / PEAK_BF16_TFLOPS, 4)}
             res["extra"] = {"batch_sweep": sweep, "batch_sweep_note": "per-GPU batches of SURVEY.md 8d (8 = coarse_grained/README.md:35), "
-                            "same process, 3 warm-up + 10 timed eager steps each, wall clock around a device synchronise"}
+                            "same process after torch.cuda.empty_cache(), 8 warm-up + 10 timed eager steps each, wall clock around a device synchronise"}
         if world == 1 and not args.no_cpu_baseline and args.task == "mlm_itm":
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
