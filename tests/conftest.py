@@ -19,9 +19,18 @@ os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
 os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
 os.environ.setdefault("FIBER_DIST_TIMEOUT", "120")
 
+# torch imports sympy (torch.fx.experimental.symbolic_shapes) lazily inside the first Tensor.backward(gradient) of a process.  On a box
+# whose image is still paging in that import alone has taken minutes (round 6: it ran into the per-test alarm below, was left half
+# imported, and every later backward failed with "module 'sympy' has no attribute 'printing'"): pay for it here, at collection time.
+try:
+    import torch  # noqa: F401
+    import torch.fx.experimental.symbolic_shapes  # noqa: F401
+except Exception:                                          # (a CPU-only or trimmed install: nothing to pre-load)
+    pass
+
 # No single test may take longer than this (seconds).  SIGALRM fails the test and the run goes on; a test stuck inside native
 # code that never returns to the interpreter is ended by faulthandler (stack dump + exit) a little later.
-TEST_LIMIT_S = int(os.environ.get("FIBER_TEST_LIMIT", "300"))
+TEST_LIMIT_S = int(os.environ.get("FIBER_TEST_LIMIT", "420"))
 
 # Collection order of the GPU files: the hot path (ops -> blocks / path -> streams -> trainer) first, the
 # (f)-row files after it, multi-process tests last -- a problem in an out-of-core-scope file cannot hide a hot-path result.

@@ -42,7 +42,7 @@ def main():
             rv = 1 / 0.95 if dp else None
 
             def fused(bwd):
-                y = ops.ln_mlp(x, g, b, 1e-5, w1, b1, w2, b2, rowscale=rs, rowscale_value=rv)
+                y = ops._LnMlp.apply(x, g, b, 1e-5, w1, b1, w2, b2, rs, rv)       # (the kernels, whatever widths ops.ln_mlp routes to them)
                 if bwd:
                     y.backward(dy)
 
