@@ -419,6 +419,8 @@ def main():
     parallel.freeze_unused(model, model.unused_parameter_names())   # never touched on the fused MLM+ITM path
     model.to(device).train()
     ops.enable_wgrad_stream(model)                          # weight-gradient GEMMs + gradient accumulation on a second stream (before DDP)
+    if os.environ.get("FIBER_WGRAD_STREAM") == "2" and world == 1:
+        ops.set_wgrad_stream(True)                          # (experiment: the GEMMs alone, gradients taken over by autograd without a copy)
     fiber_utils.set_task(model)
     (opt,), (sched,) = model.configure_optimizers()
     net = parallel.wrap_ddp(model, device)

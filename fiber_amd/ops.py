@@ -1579,7 +1579,11 @@ class _PatchEmbedProj(torch.autograd.Function):
     def backward(ctx, dy):
         (cols,) = ctx.saved_tensors
         dy2 = _c(dy).view(-1, dy.shape[-1])
-        dw, db = wgrad(dy2, cols, want_bias=True, post=lambda w_, b_: (w_[:, :48].reshape(ctx.wshape), b_))
+        def crop(w_, b_):                                   # a fresh tensor, not a view of a temporary: autograd takes it over as .grad
+            out = torch.empty(ctx.wshape, dtype=w_.dtype, device=w_.device)
+            out.view(w_.shape[0], 48).copy_(w_[:, :48])
+            return out, b_
+        dw, db = wgrad(dy2, cols, want_bias=True, post=crop)
         return None, dw, db
 
 
