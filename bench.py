@@ -418,6 +418,7 @@ def main():
             p.data.fill_(0.5)          # reference init is 0: fusion branches would carry no signal
     parallel.freeze_unused(model, model.unused_parameter_names())   # never touched on the fused MLM+ITM path
     model.to(device).train()
+    ops.set_fold_defer(world == 1)                          # slabs of the split weight-gradient GEMMs folded in one launch at the end of backward()
     ops.enable_wgrad_stream(model)                          # weight-gradient GEMMs + gradient accumulation on a second stream (before DDP)
     if os.environ.get("FIBER_WGRAD_STREAM") == "2" and world == 1:
         ops.set_wgrad_stream(True)                          # (experiment: the GEMMs alone, gradients taken over by autograd without a copy)

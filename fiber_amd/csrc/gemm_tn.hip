@@ -287,8 +287,7 @@ __global__ __launch_bounds__(TS * 2) void gemm_tn_kernel(TnArgs a) {
 }
 
 // out[i] = sum_s slab[s][i] over the N*K tile elements (float4) and, optionally, the N column sums
-__global__ __launch_bounds__(256) void tn_fold_kernel(const float* ws, const float* ws_cs, float* out, float* cs, int S, long nk4, int N) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void tn_fold_item(const float* ws, const float* ws_cs, float* out, float* cs, int S, long nk4, int N, long i) {
   if (i < nk4) {
     const float4* p = reinterpret_cast<const float4*>(ws) + i;
     float4 t = p[0];
@@ -318,6 +317,25 @@ __global__ __launch_bounds__(256) void tn_fold_kernel(const float* ws, const flo
     for (int s = 0; s < S; ++s) t += ws_cs[(long)s * N + n];
     cs[n] = t;
   }
+}
+
+__global__ __launch_bounds__(256) void tn_fold_kernel(const float* ws, const float* ws_cs, float* out, float* cs, int S, long nk4, int N) {
+  tn_fold_item(ws, ws_cs, out, cs, S, nk4, N, (long)blockIdx.x * 256 + threadIdx.x);
+}
+
+// The folds of MANY weight gradients in one launch (ops.py defers them to the end of the backward pass: 187 launches of ~14 us per
+// step at the bench batch, more than the folds' own bytes cost).  Same per-element summation order as tn_fold_kernel: same bits.
+struct FoldDesc { const float* ws; float* out; float* cs; int S, N, nk4, block0; };   // 40 bytes (cs: NULL = no bias sums)
+
+__global__ __launch_bounds__(256) void tn_fold_multi_kernel(const FoldDesc* __restrict__ table, int ndesc) {
+  int lo = 0, hi = ndesc - 1;                              // descriptor whose block range holds blockIdx.x (block0 ascending)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const FoldDesc d = table[lo];
+  const long i = (long)(blockIdx.x - d.block0) * 256 + threadIdx.x;
+  tn_fold_item(d.ws, d.ws + (size_t)d.S * d.nk4 * 4, d.out, d.cs, d.S, d.nk4, d.N, i);
 }
 
 struct TnPlan { int ts, bkm, tiles_n, tiles_k, S, kt_per_split, nk_total; };
@@ -358,9 +376,8 @@ extern "C" int fiber_gemm_tn_splits(int M, int N, int K) {
 // sum of dY rows.  row_mask (nullable): fp32 [M / rows_per_sample], sample b is kept iff row_mask[b] != 0 (the DropPath factors
 // of the branch: pass 1/keep as `scale`); rows_per_sample must be a multiple of 64 then.  Without a mask every row counts.
 // N % 8 == 0, K % 8 == 0, lddy % 8 == 0, ldx % 8 == 0, 16-byte aligned bases.
-extern "C" int fiber_gemm_tn_bf16(const void* dY, const void* X, float* dW, float* dbias, float* workspace, int M, int N, int K,
-                                  int lddy, int ldx, const float* row_mask, int rows_per_sample, float scale,
-                                  hipStream_t stream) {
+static int tn_launch(const void* dY, const void* X, float* dW, float* dbias, float* workspace, int M, int N, int K, int lddy, int ldx,
+                     const float* row_mask, int rows_per_sample, float scale, bool fold, hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0) return FIBER_OK;
   if ((N & 7) || (K & 7) || (lddy & 7) || (ldx & 7)) return FIBER_EINVAL;
   if (row_mask && (rows_per_sample <= 0 || (rows_per_sample & 63))) return FIBER_EINVAL;
@@ -377,12 +394,35 @@ extern "C" int fiber_gemm_tn_bf16(const void* dY, const void* X, float* dW, floa
   if (p.ts == 256) hipLaunchKernelGGL((gemm_tn_kernel<256, 64, 2, true>), dim3(grid), dim3(512), 0, stream, a);
   else hipLaunchKernelGGL((gemm_tn_kernel<128, 32, 4, false>), dim3(grid), dim3(256), 0, stream, a);
   FIBER_CHECK_LAUNCH();
-  if (p.S > 1) {
+  if (p.S > 1 && fold) {
     const long nk4 = (long)N * K / 4;
     const long total = nk4 + (dbias ? N : 0);
     hipLaunchKernelGGL(tn_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, workspace,
                        workspace + (size_t)p.S * N * K, dW, dbias, p.S, nk4, N);
     FIBER_CHECK_LAUNCH();
   }
+  return FIBER_OK;
+}
+
+extern "C" int fiber_gemm_tn_bf16(const void* dY, const void* X, float* dW, float* dbias, float* workspace, int M, int N, int K,
+                                  int lddy, int ldx, const float* row_mask, int rows_per_sample, float scale,
+                                  hipStream_t stream) {
+  return tn_launch(dY, X, dW, dbias, workspace, M, N, K, lddy, ldx, row_mask, rows_per_sample, scale, true, stream);
+}
+
+// The same without the fold when the M reduction is split (fiber_gemm_tn_splits > 1): the slabs stay in `workspace` (S*(N*K) floats of
+// weight slabs followed by S*N floats of bias slabs) for fiber_tn_fold_multi; dW / dbias are not written.  With one split it is the call above.
+extern "C" int fiber_gemm_tn_slabs_bf16(const void* dY, const void* X, float* dW, float* dbias, float* workspace, int M, int N, int K,
+                                        int lddy, int ldx, const float* row_mask, int rows_per_sample, float scale,
+                                        hipStream_t stream) {
+  return tn_launch(dY, X, dW, dbias, workspace, M, N, K, lddy, ldx, row_mask, rows_per_sample, scale, false, stream);
+}
+
+// table: device array of ndesc 40-byte records {ws, out, cs (8-byte pointers; cs NULL = no bias sums), int32 S, N, nk4 = N*K/4, block0},
+// block0 ascending from 0, blocks of a record = ceil((nk4 + (cs ? N : 0)) / 256); nblocks = their total.
+extern "C" int fiber_tn_fold_multi(const void* table, int ndesc, int nblocks, hipStream_t stream) {
+  if (ndesc <= 0 || nblocks <= 0) return FIBER_OK;
+  hipLaunchKernelGGL(tn_fold_multi_kernel, dim3((unsigned)nblocks), dim3(256), 0, stream, (const FoldDesc*)table, ndesc);
+  FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }

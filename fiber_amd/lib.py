@@ -17,6 +17,8 @@ P, I, F, L, U64 = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_uint64
 SIGNATURES = {
     "fiber_gemm_nt_bf16": [P, P, P, P, P, P, P, I, P, I, P, I, I, I, I, I, I, I, I],
     "fiber_gemm_tn_bf16": [P, P, P, P, P, I, I, I, I, I, P, I, F],
+    "fiber_gemm_tn_slabs_bf16": [P, P, P, P, P, I, I, I, I, I, P, I, F],
+    "fiber_tn_fold_multi": [P, I, I],
     "fiber_ln_mlp_fwd_bf16": [P, P, P, P, P, P, P, P, I, I, I, F],
     "fiber_ln_mlp_bwd_bf16": [P, P, P, P, P, P, P, P, P, P, I, I, I, F],
     "fiber_layernorm_fwd_bf16": [P, P, P, P, P, P, I, I, F],

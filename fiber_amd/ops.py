@@ -453,6 +453,54 @@ def join_wgrad_stream():
     _wg_pending.clear()
 
 
+# ---- deferred folds -----------------------------------------------------------------------------------------------------------------------
+# The TN kernel splits its M reduction into S slabs and a small fold kernel sums them: 187 fold launches of ~14 us per step at the bench
+# batch.  With ops.set_fold_defer(True) a weight gradient whose value nobody needs before the end of backward() (no `post`) leaves its
+# slabs in the workspace and ONE multi-tensor launch folds them all from the autograd engine's end-of-backward callback.  Only valid
+# when autograd takes the returned tensor over as .grad without reading it (zero_grad(set_to_none=True), one process: an existing .grad
+# would be added to -- and DDP's reducer would copy it -- before the fold has run), hence opt-in (bench.py, Trainer).
+_FOLD_DEFER = [False]
+_fold_pending = {}                   # device -> [(ws, dw, db, S, N, K, stream)]
+_fold_cb = [False]                   # an end-of-backward callback is queued
+
+
+def set_fold_defer(on):
+    _FOLD_DEFER[0] = bool(on) and os.environ.get("FIBER_TN_FOLD_DEFER", "1") != "0"
+
+
+def _fold_defer_active(t):
+    if not (_FOLD_DEFER[0] and t.is_cuda) or torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing():
+        return False
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+
+def flush_folds():
+    """Fold every pending weight gradient (one launch per device) on the current stream, behind the streams their GEMMs ran on.
+    Runs as the autograd engine's end-of-backward callback; the optimizer calls it as well (a backward that raised never ran its callbacks)."""
+    _fold_cb[0] = False
+    for dev, items in list(_fold_pending.items()):
+        if not items:
+            continue
+        with torch.cuda.device(dev):
+            cur = torch.cuda.current_stream(dev)
+            rows, block0 = [], 0
+            for ws, dw, db, S, N, K, st in items:
+                if st != cur:
+                    cur.wait_stream(st)
+                    ws.record_stream(cur)
+                    dw.record_stream(cur)
+                    if db is not None:
+                        db.record_stream(cur)
+                nk4 = N * K // 4
+                rows.append((ws.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else 0, S | (N << 32), nk4 | (block0 << 32)))
+                block0 += -(-(nk4 + (N if db is not None else 0)) // 256)
+            table = torch.tensor(rows, dtype=torch.int64).to(dev, non_blocking=True)
+            lib.call("fiber_tn_fold_multi", lib.ptr(table), len(rows), block0)
+        items.clear()
+    _fold_pending.clear()
+
+
 def wgrad(dh, x2, want_bias=False, row_mask=None, scale=1.0, post=None):
     """dW[N,K] = dh[M,N]^T . x2[M,K] in fp32 on the hand-written TN kernel (csrc/gemm_tn.hip): both operands are read as
     they lie (row-major, M slow) and transposed on the LDS -> register path; the M reduction is split inside the launch
@@ -486,6 +534,13 @@ def wgrad(dh, x2, want_bias=False, row_mask=None, scale=1.0, post=None):
             torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)    # end of this backward pass
         _wg_pending.add(dh.device)
         return out
+    if S > 1 and post is None and _fold_defer_active(dh):
+        lib.call("fiber_gemm_tn_slabs_bf16", *args)
+        if not _fold_cb[0]:
+            torch.autograd.Variable._execution_engine.queue_callback(flush_folds)          # end of this backward pass
+            _fold_cb[0] = True
+        _fold_pending.setdefault(dh.device, []).append((ws, dw, db, S, N, K, torch.cuda.current_stream(dh.device)))
+        return finish()
     lib.call("fiber_gemm_tn_bf16", *args)
     return finish()
 

@@ -115,6 +115,7 @@ class FiberAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        ops.flush_folds()                                    # (no-op unless a backward pass died before its end-of-backward callback)
         if self._chunk is None:
             self._chunk = lib.plain("fiber_adamw_chunk")
         cached = ops.bf16_copy_if_cached

@@ -210,6 +210,11 @@ class Trainer:
             from . import ops
             ops.set_collate_counter(self._resume_collate_ctr)
         net = parallel.wrap_ddp(model, device)
+        if device.type == "cuda":
+            from . import ops as _ops
+            # one launch folds the split weight gradients at the end of backward(): valid when every backward starts from .grad = None
+            # in one process (ops.set_fold_defer)
+            _ops.set_fold_defer(world == 1 and self.accumulate_grad_batches == 1)
         opt.zero_grad(set_to_none=True)
         micro, t0, last, step0 = 0, time.time(), None, self.global_step
 

@@ -45,6 +45,14 @@ int fiber_gemm_row_tile(int M, int N, int K);
 int fiber_gemm_tn_splits(int M, int N, int K);
 int fiber_gemm_tn_bf16(const void* dY, const void* X, float* dW, float* dbias, float* workspace, int M, int N, int K, int lddy,
                        int ldx, const float* row_mask, int rows_per_sample, float scale, fiber_stream_t stream);
+/* The same GEMM WITHOUT the fold of its M splits: with fiber_gemm_tn_splits(M,N,K) = S > 1 the S weight slabs (S*N*K floats) and the S
+ * bias slabs (S*N floats) stay in `workspace`, dW / dbias are not written; with S = 1 it is the call above. */
+int fiber_gemm_tn_slabs_bf16(const void* dY, const void* X, float* dW, float* dbias, float* workspace, int M, int N, int K, int lddy,
+                       int ldx, const float* row_mask, int rows_per_sample, float scale, fiber_stream_t stream);
+/* Folds the slabs of MANY such GEMMs in one launch (ops.py defers them to the end of the backward pass).  table: device array of ndesc
+ * 40-byte records {const float* ws; float* dW; float* dbias (NULL = none); int32 S, N, nk4 = N*K/4, block0}, block0 ascending from 0, a
+ * record owns ceil((nk4 + (dbias ? N : 0)) / 256) blocks; nblocks = their total.  Same summation order as fiber_gemm_tn_bf16's fold. */
+int fiber_tn_fold_multi(const void* table, int ndesc, int nblocks, fiber_stream_t stream);
 
 /* nn.LayerNorm over the last dim (C%8==0, C<=4096); saves mean/rstd.  replaces swin_transformer.py:362,391,244; roberta.py:485,422 */
 int fiber_layernorm_fwd_bf16(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int rows,

@@ -260,3 +260,48 @@ def test_weight_gradients_on_their_own_stream_are_the_same_gradients():
         # (fp32 atomics: embedding rows and the gates are summed in an order that differs from run to run -- compare those by value)
         really = [n for n in bad if (ref[n].float() - got[n].float()).abs().max() > 1e-3 * (ref[n].float().abs().max() + 1e-6)]
         assert not really, (rep, really[:8])
+
+
+def test_deferred_folds_give_the_same_gradients_bitwise():
+    """ops.set_fold_defer(True): the slabs of the split weight-gradient GEMMs are folded by ONE multi-tensor launch at the end of
+    backward() instead of one small launch per GEMM -- the same per-element summation order, so every gradient must be bitwise the one
+    of the immediate folds (fp32-atomic gradients -- embedding rows, gates -- compared by value), twice in a row, optimizer step included
+    (the second run starts from weights the first run's deferred gradients produced)."""
+    from fiber_amd import ops, parallel
+    from fiber_amd.config import make_config
+    from fiber_amd.modules import FIBERTransformerSS, fiber_utils
+    from oracle import cases, detgen
+    b = detgen.synth_batch(4, 224, 40, 50265, seed=6, min_len=8)
+    bd = {k: (v.to("cuda") if isinstance(v, torch.Tensor) else [t.to("cuda") for t in v] if isinstance(v, list) and isinstance(v[0], torch.Tensor) else v)
+          for k, v in b.items()}
+    bd["itm_labels_override"] = bd["itm_labels"]
+
+    def run(defer):
+        torch.manual_seed(0)
+        model = FIBERTransformerSS(make_config(**dict(cases.SWIN_T), learning_rate=1e-4, warmup_steps=0, max_steps=100)).eval()
+        for n, p in model.named_parameters():
+            if "alpha_" in n:
+                p.data.fill_(0.5)
+        model.to("cuda")
+        fiber_utils.set_task(model)
+        parallel.freeze_unused(model, model.unused_parameter_names())
+        (opt,), _ = model.configure_optimizers()
+        ops.set_fold_defer(defer)
+        try:
+            out = []
+            for _ in range(2):
+                opt.zero_grad(set_to_none=True)
+                o = model(bd)
+                sum(v for k, v in o.items() if "loss" in k).backward()
+                torch.cuda.synchronize()
+                out.append({n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+                opt.step()
+            return out
+        finally:
+            ops.set_fold_defer(False)
+    ref, got = run(False), run(True)
+    for step in range(2):
+        assert ref[step].keys() == got[step].keys()
+        bad = [n for n in ref[step] if not torch.equal(ref[step][n], got[step][n])]
+        really = [n for n in bad if (ref[step][n].float() - got[step][n].float()).abs().max() > 1e-3 * (ref[step][n].float().abs().max() + 1e-6)]
+        assert not really, (step, really[:8])
