@@ -458,14 +458,18 @@ def join_wgrad_stream():
 # batch.  With ops.set_fold_defer(True) a weight gradient whose value nobody needs before the end of backward() (no `post`) leaves its
 # slabs in the workspace and ONE multi-tensor launch folds them all from the autograd engine's end-of-backward callback.  Only valid
 # when autograd takes the returned tensor over as .grad without reading it (zero_grad(set_to_none=True), one process: an existing .grad
-# would be added to -- and DDP's reducer would copy it -- before the fold has run), hence opt-in (bench.py, Trainer).
+# would be added to -- and DDP's reducer would copy it -- before the fold has run), hence opt-in.
+# Round-6 result (same box, interleaved, B = 256): 267.2 / 262.0 ms per step deferred against 261.0 / 259.6 immediate -- a fold that runs
+# right behind its GEMM reads the slabs out of the 256-MB Infinity Cache, the one launch at the end reads all 4 GB of them from HBM; at
+# B = 32 (48.5-49.7 against 48.8-48.9 ms) the step is not launch-bound either.  So bench.py / Trainer call set_fold_defer, which stays a
+# no-op unless FIBER_TN_FOLD_DEFER=1.
 _FOLD_DEFER = [False]
-_fold_pending = {}                   # device -> [(ws, dw, db, S, N, K, stream)]
+_fold_pending = {}                   # device -> [(ws, dW pointer, db pointer, storage weak refs, S, N, K, stream)]
 _fold_cb = [False]                   # an end-of-backward callback is queued
 
 
 def set_fold_defer(on):
-    _FOLD_DEFER[0] = bool(on) and os.environ.get("FIBER_TN_FOLD_DEFER", "1") != "0"
+    _FOLD_DEFER[0] = bool(on) and os.environ.get("FIBER_TN_FOLD_DEFER", "0") == "1"
 
 
 def _fold_defer_active(t):
@@ -485,17 +489,19 @@ def flush_folds():
         with torch.cuda.device(dev):
             cur = torch.cuda.current_stream(dev)
             rows, block0 = [], 0
-            for ws, dw, db, S, N, K, st in items:
+            for ws, dwp, dbp, alive, S, N, K, st in items:
+                # the outputs are NOT held here (a second reference would make autograd copy them instead of taking them over as .grad);
+                # their storages must still be alive -- a gradient that was copied after all has been freed by now
+                if any(w_.expired() for w_ in alive):
+                    raise lib.FiberHipError("a weight gradient with a deferred fold was copied, not taken over, by autograd "
+                                            "(ops.set_fold_defer needs .grad = None before backward, one process, no gradient hooks)")
                 if st != cur:
                     cur.wait_stream(st)
                     ws.record_stream(cur)
-                    dw.record_stream(cur)
-                    if db is not None:
-                        db.record_stream(cur)
                 nk4 = N * K // 4
-                rows.append((ws.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else 0, S | (N << 32), nk4 | (block0 << 32)))
-                block0 += -(-(nk4 + (N if db is not None else 0)) // 256)
-            table = torch.tensor(rows, dtype=torch.int64).to(dev, non_blocking=True)
+                rows.append((ws.data_ptr(), dwp, dbp, S | (N << 32), nk4 | (block0 << 32)))
+                block0 += -(-(nk4 + (N if dbp else 0)) // 256)
+            table = torch.tensor(rows, dtype=torch.int64).to(dev)      # (blocking: the host staging tensor dies with this statement)
             lib.call("fiber_tn_fold_multi", lib.ptr(table), len(rows), block0)
         items.clear()
     _fold_pending.clear()
@@ -539,7 +545,10 @@ def wgrad(dh, x2, want_bias=False, row_mask=None, scale=1.0, post=None):
         if not _fold_cb[0]:
             torch.autograd.Variable._execution_engine.queue_callback(flush_folds)          # end of this backward pass
             _fold_cb[0] = True
-        _fold_pending.setdefault(dh.device, []).append((ws, dw, db, S, N, K, torch.cuda.current_stream(dh.device)))
+        from torch.multiprocessing.reductions import StorageWeakRef
+        alive = [StorageWeakRef(t.untyped_storage()) for t in (dw, db) if t is not None]
+        _fold_pending.setdefault(dh.device, []).append((ws, dw.data_ptr(), db.data_ptr() if db is not None else 0, alive, S, N, K,
+                                                        torch.cuda.current_stream(dh.device)))
         return finish()
     lib.call("fiber_gemm_tn_bf16", *args)
     return finish()
