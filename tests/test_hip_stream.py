@@ -217,7 +217,7 @@ def test_fused_path_forward_gap_fp32_stream(case):
     assert sum(g32) <= sum(g16) + 2e-3, "the fp32 stream must not be further from the oracle than the bf16 stream"
 
 
-def test_weight_gradients_on_their_own_stream_are_the_same_gradients():
+def test_weight_gradients_on_their_own_stream_are_the_same_gradients(monkeypatch):
     """ops.enable_wgrad_stream(model): the TN weight-gradient GEMMs (and whatever the callers derive from their results) run on a second
     stream, autograd accumulates every gradient of the model on that stream, and backward() joins it.  Same kernels, same inputs: every parameter gradient must be BITWISE the
     one of the single-stream run (a consumer that read a gradient before the side stream had written it would show up here), three
@@ -240,6 +240,7 @@ def test_weight_gradients_on_their_own_stream_are_the_same_gradients():
           for k, v in b.items()}
     bd["itm_labels_override"] = bd["itm_labels"]
 
+    monkeypatch.setenv("FIBER_WGRAD_STREAM", "1")            # (the switch is an experiment: off unless the variable is set)
     ops.enable_wgrad_stream(model)                           # accumulator nodes on the weight-gradient stream (before the first forward)
 
     def grads(on):
@@ -262,7 +263,7 @@ def test_weight_gradients_on_their_own_stream_are_the_same_gradients():
         assert not really, (rep, really[:8])
 
 
-def test_deferred_folds_give_the_same_gradients_bitwise():
+def test_deferred_folds_give_the_same_gradients_bitwise(monkeypatch):
     """ops.set_fold_defer(True): the slabs of the split weight-gradient GEMMs are folded by ONE multi-tensor launch at the end of
     backward() instead of one small launch per GEMM -- the same per-element summation order, so every gradient must be bitwise the one
     of the immediate folds (fp32-atomic gradients -- embedding rows, gates -- compared by value), twice in a row, optimizer step included
@@ -271,6 +272,7 @@ def test_deferred_folds_give_the_same_gradients_bitwise():
     from fiber_amd.config import make_config
     from fiber_amd.modules import FIBERTransformerSS, fiber_utils
     from oracle import cases, detgen
+    monkeypatch.setenv("FIBER_TN_FOLD_DEFER", "1")           # (the switch is an experiment: off unless the variable is set)
     b = detgen.synth_batch(4, 224, 40, 50265, seed=6, min_len=8)
     bd = {k: (v.to("cuda") if isinstance(v, torch.Tensor) else [t.to("cuda") for t in v] if isinstance(v, list) and isinstance(v[0], torch.Tensor) else v)
           for k, v in b.items()}
