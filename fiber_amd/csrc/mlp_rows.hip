@@ -29,6 +29,11 @@
 //     gelu'(H), dXhat^T += W1'^T . dH^T, applies the LayerNorm backward and the residual gradient in registers, and writes dx.  It also
 //     writes dH and xhat (bf16) -- with the forward's G the operands of the two weight-gradient GEMMs (gemm_tn.hip), which stay separate
 //     kernels: their contraction runs over ALL rows, a row-owning wave cannot hold a [4C, C] accumulator.
+//
+// Measured and not shipped (profiles/r06_summary.md section 3): the two wave groups of the workgroup half a chunk apart (one wave of a SIMD in its MFMA
+// block while the other is in its GELU block: 2279 us against 2180 at stage 0), and a chunk loop skewed by one chunk so that the MFMAs of product 1 of
+// chunk j + 1 are issued between slices of GELU(chunk j) (tools/experiments/mlp_rows_skewed_fwd.hip.inc: 3135 us against 2662).  The counters say the
+// vector pipe is busy 46 % and the matrix pipe 25 % of the forward kernel at C = 128, one after the other.
 #include <stdlib.h>
 
 #include "common.h"

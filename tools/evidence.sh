@@ -1,7 +1,7 @@
 #!/bin/bash
 # Evidence collection for one round on one MI355X (tools/evidence.sh r04; the round-3 run is kept as tools/pmc_r03.sh): per-stage and per-shape breakdowns, kernel-trace stats of the bench step, per-kernel
 # MFMA-busy / HBM summary (tools/pmc_step.sh), FETCH_SIZE / WRITE_SIZE + kernel-trace passes on the dominant kernel.
-TAG=${1:-r04}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 python tools/stage_breakdown.py 256 5 > gpurun_out/${TAG}_stage_breakdown.md 2> gpurun_out/${TAG}_stage_breakdown.err
@@ -53,3 +53,6 @@ python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out
 for b in 8 16 32 64; do
   python bench.py --batch $b --steps 30 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import json,sys; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print($b, d['value'], d['ms_per_step'])"
 done > gpurun_out/${TAG}_batch_sweep.log 2>&1
+# round 6: the fused LayerNorm-Mlp kernels (csrc/mlp_rows.hip) against the separate kernels they replace, and their SQ counters
+python tools/lnmlp_bench.py 512 > gpurun_out/${TAG}_lnmlp_bench.log 2>&1
+bash tools/pmc_lnmlp.sh ${TAG}_lnmlp > gpurun_out/${TAG}_pmc_lnmlp.log 2>&1

@@ -71,6 +71,11 @@ def stream_row(name, sc, nn):
         if name.endswith("fwd_bf16"):
             return 4.0 * Bn * heads * Lq * Lk * D, e * (2 * Lq + 2 * Lk), f"attention fwd {Lq}x{Lk} d{D}"
         return 10.0 * Bn * heads * Lq * Lk * D, e * (4 * Lq + 4 * Lk), f"attention bwd {Lq}x{Lk} d{D}"
+    if name in ("fiber_ln_mlp_fwd_bf16", "fiber_ln_mlp_bwd_bf16"):
+        M, C = sc[0], sc[1]
+        if name.endswith("fwd_bf16"):                      # x in, y out, G out (when a backward follows: nn[7]); two products
+            return 2.0 * M * C * 4 * C * 2, 2 * (2 * M * C + (4 * M * C if nn[7] else 0)), f"LN+MLP fused fwd [{M}, {C}]"
+        return 2.0 * M * C * 4 * C * 3, 2 * (4 * M * C + 4 * M * C), f"LN+MLP fused bwd [{M}, {C}]"    # x, dy in; dx, xhat, dh out
     if name == "fiber_stream_add":
         n, res_kind = sc[-1], sc[0]
         by = (2 if res_kind == 1 else 4 if res_kind == 2 else 0) + 2 + (2 if nn[2] else 0) + (4 if nn[6] else 0) + (2 if nn[7] else 0)
@@ -150,7 +155,7 @@ def main():
             prev = e
             if name.startswith("fiber_mha_"):
                 sc = sc[:-1] + (0,)                  # the dropout seed differs per call: not part of the shape
-            key = (name, sc, nn if name in ("fiber_layernorm_bwd_bf16", "fiber_stream_add", "fiber_stream_add_bwd") else ())
+            key = (name, sc, nn if name in ("fiber_layernorm_bwd_bf16", "fiber_stream_add", "fiber_stream_add_bwd", "fiber_ln_mlp_fwd_bf16") else ())
             a = agg.setdefault(key, [0.0, 0])
             a[0] += ms / steps
             a[1] += 1
