@@ -47,7 +47,7 @@ def oracle_curve(cfg, size, batch, steps, nb, warm, ref=None, frozen=()):
     fused path never touches; they get no gradient here either, so listing them changes nothing but the bookkeeping)."""
     from fiber_amd.modules import fiber_utils           # name -> group rule and the schedule: host-side Python, no kernels
     from fiber_amd.optim import HFAdamW                  # plain-torch statement of transformers 4.6.0 AdamW
-    torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))    # (more threads make the many small ops slower: r06_summary.md section 6)
     ref = build_ref(cfg) if ref is None else ref
     lr, wd = HYPER["learning_rate"], HYPER["weight_decay"]
     mult = [1, 1, HYPER["lr_mult_head"], HYPER["lr_mult_head"], HYPER["lr_mult_cross_modal"], HYPER["lr_mult_cross_modal"]]
@@ -70,3 +70,38 @@ def oracle_curve(cfg, size, batch, steps, nb, warm, ref=None, frozen=()):
         sched.step()
         out.append(loss.item())
     return out
+
+
+# The small fixed-batch curve of tests/test_hip_modules.py::test_loss_curve_tracks_oracle_over_optimizer_steps: cases.TINY, ONE batch
+# (synth_batch(4, 96, 12, 1000, seed=11, min_len=6)) for 8 steps at the constant group rates of lr = 1e-4 (no warm-up, no decay step taken),
+# gates at detgen's values.
+TINY_SPEC = {"cases": "TINY", "batch": [4, 96, 12, 1000, 11, 6], "steps": 8, "lr": 1e-4, "lr_mult_head": 5, "lr_mult_cross_modal": 5,
+             "weight_decay": 0.01}
+
+
+def oracle_curve_tiny(ref=None, frozen=()):
+    from fiber_amd.modules import fiber_utils
+    from fiber_amd.optim import HFAdamW
+    from . import cases
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))    # (more threads make the many small ops slower: r06_summary.md section 6)
+    if ref is None:
+        ref = detgen.fill_(R.FiberRef(dict(cases.TINY)).train())
+    lr, wd = TINY_SPEC["lr"], TINY_SPEC["weight_decay"]
+    mult = [1, 1, TINY_SPEC["lr_mult_head"], TINY_SPEC["lr_mult_head"], TINY_SPEC["lr_mult_cross_modal"], TINY_SPEC["lr_mult_cross_modal"]]
+    groups = [{"params": [], "weight_decay": wd if i % 2 == 0 else 0.0, "lr": lr * mult[i]} for i in range(6)]
+    frozen = set(frozen)
+    for n, p in ref.named_parameters():
+        gi = fiber_utils.param_group_index(n)
+        if gi is not None and n not in frozen and not n.startswith("rank_output."):
+            groups[gi]["params"].append(p)
+    opt = HFAdamW(groups, lr=lr, eps=1e-8, betas=(0.9, 0.98))
+    b = detgen.synth_batch(*TINY_SPEC["batch"][:4], seed=TINY_SPEC["batch"][4], min_len=TINY_SPEC["batch"][5])
+    out = []
+    for _ in range(TINY_SPEC["steps"]):
+        opt.zero_grad(set_to_none=True)
+        loss = ref.training_loss(b, b["itm_labels"])
+        loss.backward()
+        opt.step()
+        out.append(loss.item())
+    return out
+

@@ -28,6 +28,14 @@ try:
 except Exception:                                          # (a CPU-only or trimmed install: nothing to pre-load)
     pass
 
+# The oracle's many small CPU ops get SLOWER with more threads (profiles/r06_summary.md section 6: one FIBER-Base step 12 s on 32 threads,
+# 21 s on 64, 47 s on 128): on a many-core GPU host the suite's oracle work runs on 16.
+try:
+    if (os.cpu_count() or 1) > 16 and "OMP_NUM_THREADS" not in os.environ:
+        torch.set_num_threads(16)
+except Exception:
+    pass
+
 # No single test may take longer than this (seconds).  SIGALRM fails the test and the run goes on; a test stuck inside native
 # code that never returns to the interpreter is ended by faulthandler (stack dump + exit) a little later.
 TEST_LIMIT_S = int(os.environ.get("FIBER_TEST_LIMIT", "420"))
