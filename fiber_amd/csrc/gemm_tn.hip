@@ -46,6 +46,7 @@ struct TnArgs {
   const float* row_mask;   // optional fp32 [M / rows_per_sample]: rows of samples whose entry is 0 do not contribute
   int rows_per_sample;     // (a multiple of the K-tile depth: a K tile never straddles two samples)
   float scale;             // the result (and the bias sums) are multiplied by this
+  const int* row_map;      // optional int32 [N]: output row n (and bias entry n) is written at row_map[n] (a permutation)
 };
 
 __device__ __attribute__((aligned(16))) unsigned g_tn_zeros[128];   // 512 zero bytes: the source of dY rows past M
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(TS * 2) void gemm_tn_kernel(TnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int n = nb + (r & 3) + 8 * (r >> 2);
-          if (n < a.N) outp[(size_t)n * a.K + kk] = acc[t][u][r] * a.scale;
+          if (n < a.N) outp[(size_t)(a.row_map ? a.row_map[n] : n) * a.K + kk] = acc[t][u][r] * a.scale;
         }
       }
     }
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(TS * 2) void gemm_tn_kernel(TnArgs a) {
     float* csp = a.cs + (size_t)s * a.N;
     const float v = (csa + __shfl_xor(csa, 32)) * a.scale;
     const int n = n0 + wa * WTA + wb * 32 + (lane & 31);
-    if (lane < 32 && n < a.N) csp[n] = v;
+    if (lane < 32 && n < a.N) csp[a.row_map ? a.row_map[n] : n] = v;
   }
 }
 
@@ -377,7 +378,7 @@ extern "C" int fiber_gemm_tn_splits(int M, int N, int K) {
 // of the branch: pass 1/keep as `scale`); rows_per_sample must be a multiple of 64 then.  Without a mask every row counts.
 // N % 8 == 0, K % 8 == 0, lddy % 8 == 0, ldx % 8 == 0, 16-byte aligned bases.
 static int tn_launch(const void* dY, const void* X, float* dW, float* dbias, float* workspace, int M, int N, int K, int lddy, int ldx,
-                     const float* row_mask, int rows_per_sample, float scale, bool fold, hipStream_t stream) {
+                     const float* row_mask, int rows_per_sample, float scale, bool fold, const int* row_map, hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0) return FIBER_OK;
   if ((N & 7) || (K & 7) || (lddy & 7) || (ldx & 7)) return FIBER_EINVAL;
   if (row_mask && (rows_per_sample <= 0 || (rows_per_sample & 63))) return FIBER_EINVAL;
@@ -389,7 +390,7 @@ static int tn_launch(const void* dY, const void* X, float* dW, float* dbias, flo
   a.cs = dbias ? (p.S > 1 ? workspace + (size_t)p.S * N * K : dbias) : nullptr;
   a.M = M; a.N = N; a.K = K; a.lda = lddy; a.ldb = ldx;
   a.S = p.S; a.tiles_n = p.tiles_n; a.tiles_k = p.tiles_k; a.kt_per_split = p.kt_per_split; a.nk_total = p.nk_total;
-  a.row_mask = row_mask; a.rows_per_sample = rows_per_sample; a.scale = scale;
+  a.row_mask = row_mask; a.rows_per_sample = rows_per_sample; a.scale = scale; a.row_map = row_map;
   const unsigned grid = (unsigned)(p.tiles_n * p.tiles_k * p.S);
   if (p.ts == 256) hipLaunchKernelGGL((gemm_tn_kernel<256, 64, 2, true>), dim3(grid), dim3(512), 0, stream, a);
   else hipLaunchKernelGGL((gemm_tn_kernel<128, 32, 4, false>), dim3(grid), dim3(256), 0, stream, a);
@@ -407,7 +408,7 @@ static int tn_launch(const void* dY, const void* X, float* dW, float* dbias, flo
 extern "C" int fiber_gemm_tn_bf16(const void* dY, const void* X, float* dW, float* dbias, float* workspace, int M, int N, int K,
                                   int lddy, int ldx, const float* row_mask, int rows_per_sample, float scale,
                                   hipStream_t stream) {
-  return tn_launch(dY, X, dW, dbias, workspace, M, N, K, lddy, ldx, row_mask, rows_per_sample, scale, true, stream);
+  return tn_launch(dY, X, dW, dbias, workspace, M, N, K, lddy, ldx, row_mask, rows_per_sample, scale, true, nullptr, stream);
 }
 
 // The same without the fold when the M reduction is split (fiber_gemm_tn_splits > 1): the slabs stay in `workspace` (S*(N*K) floats of
@@ -415,7 +416,7 @@ extern "C" int fiber_gemm_tn_bf16(const void* dY, const void* X, float* dW, floa
 extern "C" int fiber_gemm_tn_slabs_bf16(const void* dY, const void* X, float* dW, float* dbias, float* workspace, int M, int N, int K,
                                         int lddy, int ldx, const float* row_mask, int rows_per_sample, float scale,
                                         hipStream_t stream) {
-  return tn_launch(dY, X, dW, dbias, workspace, M, N, K, lddy, ldx, row_mask, rows_per_sample, scale, false, stream);
+  return tn_launch(dY, X, dW, dbias, workspace, M, N, K, lddy, ldx, row_mask, rows_per_sample, scale, false, nullptr, stream);
 }
 
 // table: device array of ndesc 40-byte records {ws, out, cs (8-byte pointers; cs NULL = no bias sums), int32 S, N, nk4 = N*K/4, block0},
@@ -426,3 +427,13 @@ extern "C" int fiber_tn_fold_multi(const void* table, int ndesc, int nblocks, hi
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }
+
+// fiber_gemm_tn_bf16 with its output rows permuted on the way out: row n of dW (and entry n of dbias) is written at row_map[n] (int32 [N], a
+// permutation; the head-major qkv projection of ops.py trains a weight whose rows are stored in another order than the kernel computes them:
+// three index kernels per Swin block and step otherwise).
+extern "C" int fiber_gemm_tn_rowmap_bf16(const void* dY, const void* X, float* dW, float* dbias, float* workspace, int M, int N, int K,
+                                         int lddy, int ldx, const float* row_mask, int rows_per_sample, float scale, const int* row_map,
+                                         hipStream_t stream) {
+  return tn_launch(dY, X, dW, dbias, workspace, M, N, K, lddy, ldx, row_mask, rows_per_sample, scale, true, row_map, stream);
+}
+

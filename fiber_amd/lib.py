@@ -18,6 +18,7 @@ SIGNATURES = {
     "fiber_gemm_nt_bf16": [P, P, P, P, P, P, P, I, P, I, P, I, I, I, I, I, I, I, I],
     "fiber_gemm_tn_bf16": [P, P, P, P, P, I, I, I, I, I, P, I, F],
     "fiber_gemm_tn_slabs_bf16": [P, P, P, P, P, I, I, I, I, I, P, I, F],
+    "fiber_gemm_tn_rowmap_bf16": [P, P, P, P, P, I, I, I, I, I, P, I, F, P],
     "fiber_tn_fold_multi": [P, I, I],
     "fiber_ln_mlp_fwd_bf16": [P, P, P, P, P, P, P, P, I, I, I, F],
     "fiber_ln_mlp_bwd_bf16": [P, P, P, P, P, P, P, P, P, P, I, I, I, F],

@@ -507,14 +507,15 @@ def flush_folds():
     _fold_pending.clear()
 
 
-def wgrad(dh, x2, want_bias=False, row_mask=None, scale=1.0, post=None):
+def wgrad(dh, x2, want_bias=False, row_mask=None, scale=1.0, post=None, row_map=None):
     """dW[N,K] = dh[M,N]^T . x2[M,K] in fp32 on the hand-written TN kernel (csrc/gemm_tn.hip): both operands are read as
     they lie (row-major, M slow) and transposed on the LDS -> register path; the M reduction is split inside the launch
     (fp32 slabs + one fold).  want_bias: also return the column sums of dh (the bias gradient) from the same pass.
     row_mask / scale: DropPath backward folded in -- samples whose factor in `row_mask` is 0 are skipped, the result is
     multiplied by `scale` (= 1/keep); see droppath_foldable().
     post(dw, db): anything the caller computes FROM the result (row permutations, reshapes, the LayerNorm unfolding of ops._LnMlp)
-    -- it runs on the stream the kernel ran on, and its return value is returned instead of (dw, db)."""
+    -- it runs on the stream the kernel ran on, and its return value is returned instead of (dw, db).
+    row_map (int32 [N], a permutation): row n of the result (entry n of the bias sums) is written at row_map[n]."""
     M, N = dh.shape
     K = x2.shape[1]
     assert dh.dtype == BF16 and x2.dtype == BF16 and dh.stride(1) == 1 and x2.stride(1) == 1 and x2.shape[0] == M
@@ -531,7 +532,10 @@ def wgrad(dh, x2, want_bias=False, row_mask=None, scale=1.0, post=None):
         side = wgrad_stream(dh.device)
         side.wait_stream(cur)                               # the operands' producers
         with torch.cuda.stream(side):
-            lib.call("fiber_gemm_tn_bf16", *args)
+            if row_map is not None:
+                lib.call("fiber_gemm_tn_rowmap_bf16", *args, lib.ptr(row_map))
+            else:
+                lib.call("fiber_gemm_tn_bf16", *args)
             out = finish()
         for t in (dh, x2, row_mask, ws, dw, db):            # memory handed back on `cur` must not be reused under the side stream
             if t is not None:
@@ -540,7 +544,7 @@ def wgrad(dh, x2, want_bias=False, row_mask=None, scale=1.0, post=None):
             torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)    # end of this backward pass
         _wg_pending.add(dh.device)
         return out
-    if S > 1 and post is None and _fold_defer_active(dh):
+    if S > 1 and post is None and row_map is None and _fold_defer_active(dh):
         lib.call("fiber_gemm_tn_slabs_bf16", *args)
         if not _fold_cb[0]:
             torch.autograd.Variable._execution_engine.queue_callback(flush_folds)          # end of this backward pass
@@ -550,7 +554,10 @@ def wgrad(dh, x2, want_bias=False, row_mask=None, scale=1.0, post=None):
         _fold_pending.setdefault(dh.device, []).append((ws, dw.data_ptr(), db.data_ptr() if db is not None else 0, alive, S, N, K,
                                                         torch.cuda.current_stream(dh.device)))
         return finish()
-    lib.call("fiber_gemm_tn_bf16", *args)
+    if row_map is not None:
+        lib.call("fiber_gemm_tn_rowmap_bf16", *args, lib.ptr(row_map))
+    else:
+        lib.call("fiber_gemm_tn_bf16", *args)
     return finish()
 
 
@@ -1074,6 +1081,16 @@ def _qkv_perm(C, heads, device):
     return _perm_cache[key]
 
 
+_TN_ROWMAP = os.environ.get("FIBER_TN_ROWMAP", "1") != "0"
+
+
+def _qkv_perm32(C, heads, device):
+    key = ("i32", C, heads, str(device))
+    if key not in _perm_cache:
+        _perm_cache[key] = _qkv_perm(C, heads, device)[0].to(torch.int32).contiguous()
+    return _perm_cache[key]
+
+
 class _LinearQKVHeadMajor(torch.autograd.Function):
     """qkv = x . W^T + b with the OUTPUT channels reordered to [heads][3][32]: q|k|v of one head become one contiguous
     192-byte run per token, so the per-head gathers of the window-attention kernels use 3/4 of every cache line they touch
@@ -1104,7 +1121,13 @@ class _LinearQKVHeadMajor(torch.autograd.Function):
         perm, inv = _qkv_perm(weight.shape[1], ctx.heads, dy.device)
         wp, _, wpt = _wcache[("HM", id(weight))][1]
         dx = gemm_nt(dy2, wpt)[0].view(ctx.shp)
-        if hint is not None:
+        if _TN_ROWMAP:                                      # row r' of the head-major gradient is written at row perm[r'] by the kernel
+            pmap = _qkv_perm32(weight.shape[1], ctx.heads, dy.device)
+            if hint is not None:
+                dw, db = wgrad(dy2, x2, row_map=pmap), hint[inv]
+            else:
+                dw, db = wgrad(dy2, x2, want_bias=True, row_map=pmap)
+        elif hint is not None:                             # (A/B: FIBER_TN_ROWMAP=0 -- index kernels behind the GEMM)
             dw, db = wgrad(dy2, x2, post=lambda w_, _b: w_[inv]), hint[inv]
         else:
             dw, db = wgrad(dy2, x2, want_bias=True, post=lambda w_, b_: (w_[inv], b_[inv]))

@@ -49,6 +49,11 @@ int fiber_gemm_tn_bf16(const void* dY, const void* X, float* dW, float* dbias, f
  * bias slabs (S*N floats) stay in `workspace`, dW / dbias are not written; with S = 1 it is the call above. */
 int fiber_gemm_tn_slabs_bf16(const void* dY, const void* X, float* dW, float* dbias, float* workspace, int M, int N, int K, int lddy,
                        int ldx, const float* row_mask, int rows_per_sample, float scale, fiber_stream_t stream);
+/* fiber_gemm_tn_bf16 with its output rows permuted on the way out: row n of dW (entry n of dbias) is written at row_map[n] (int32 [N], a
+ * permutation) -- the gradient of a weight whose working copy has its rows in another order (the head-major qkv projection). */
+int fiber_gemm_tn_rowmap_bf16(const void* dY, const void* X, float* dW, float* dbias, float* workspace, int M, int N, int K, int lddy,
+                              int ldx, const float* row_mask, int rows_per_sample, float scale, const int* row_map,
+                              fiber_stream_t stream);
 /* Folds the slabs of MANY such GEMMs in one launch (ops.py defers them to the end of the backward pass).  table: device array of ndesc
  * 40-byte records {const float* ws; float* dW; float* dbias (NULL = none); int32 S, N, nk4 = N*K/4, block0}, block0 ascending from 0, a
  * record owns ceil((nk4 + (dbias ? N : 0)) / 256) blocks; nblocks = their total.  Same summation order as fiber_gemm_tn_bf16's fold. */
