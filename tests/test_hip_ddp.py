@@ -62,7 +62,7 @@ def test_two_rank_ddp_on_one_gpu(tmp_path):
     assert torch.cuda.is_available()
     port = free_port()
     out = str(tmp_path / "r0.pt")
-    spawn_bounded(_worker, (2, port, out), nprocs=2, deadline_s=180)
+    spawn_bounded(_worker, (2, port, out), nprocs=2, deadline_s=300)
     res = torch.load(out)
     assert res["finite"] and all(l == l for l in res["losses"])
     assert res["same"], "parameters diverged across DDP ranks (gradient all-reduce / frozen-parameter wiring is wrong)"
@@ -134,7 +134,7 @@ def test_no_sync_gradient_accumulation_real_module(tmp_path):
     assert torch.cuda.is_available()
     port = free_port()
     out = str(tmp_path / "r0.pt")
-    spawn_bounded(_worker_no_sync, (2, port, out), nprocs=2, deadline_s=180)
+    spawn_bounded(_worker_no_sync, (2, port, out), nprocs=2, deadline_s=300)
     res = torch.load(out)
     assert res["worst"] < 1e-3, res          # identical kernels on identical inputs; only the fp32 summation order differs
 
