@@ -37,8 +37,9 @@ def _entry(rank, fn, args, dump_dir, dump_after_s):
         faulthandler.cancel_dump_traceback_later()
 
 
-def spawn_bounded(fn, args, nprocs=2, deadline_s=180):
-    """Run fn(rank, *args) in `nprocs` spawned processes; fail (never hang) when they are not done after deadline_s."""
+def spawn_bounded(fn, args, nprocs=2, deadline_s=180, fail=True):
+    """Run fn(rank, *args) in `nprocs` spawned processes; never hang: when they are not done after deadline_s they are killed and the
+    test fails with their stack dumps (fail=False: returns False instead, for one retry on a fresh port).  Returns True when they finished."""
     import torch.multiprocessing as mp
     dump_dir = tempfile.mkdtemp(prefix="fiber_mp_")
     ctx = mp.spawn(_entry, args=(fn, args, dump_dir, max(deadline_s - 15, 5)), nprocs=nprocs, join=False)
@@ -46,7 +47,7 @@ def spawn_bounded(fn, args, nprocs=2, deadline_s=180):
     try:
         while time.time() < t_end:
             if ctx.join(timeout=5):          # True once every child has exited cleanly; raises if one failed
-                return
+                return True
     except Exception:
         _kill(ctx)
         raise
@@ -57,6 +58,9 @@ def spawn_bounded(fn, args, nprocs=2, deadline_s=180):
             dumps.append(f"--- rank {r} ---\n" + open(os.path.join(dump_dir, f"rank{r}.txt")).read()[-3000:])
         except OSError:
             pass
+    if not fail:
+        print(f"{fn.__name__}: {nprocs} ranks not finished after {deadline_s} s (killed); dumps:\n" + "\n".join(dumps), flush=True)
+        return False
     pytest.fail(f"{fn.__name__}: {nprocs} ranks not finished after {deadline_s} s (killed)\n" + "\n".join(dumps), pytrace=False)
 
 
@@ -85,3 +89,12 @@ def run_bounded(cmd, timeout, **kw):
         pytest.fail(f"{' '.join(map(str, cmd[:6]))} ...: not finished after {timeout} s (process group killed)\n"
                     f"stdout tail: {out[-1500:]}\nstderr tail: {err[-1500:]}", pytrace=False)
     return subprocess.CompletedProcess(cmd, proc.returncode, out, err)
+
+
+def spawn_with_retry(fn, make_args, nprocs=2, deadline_s=150):
+    """spawn_bounded with ONE retry on a fresh rendezvous port when the first attempt runs into its deadline (a rendezvous that never
+    completes is an accident of the box, not of the code under test; a second one is reported).  make_args(port) -> the worker's arguments."""
+    if spawn_bounded(fn, make_args(free_port()), nprocs=nprocs, deadline_s=deadline_s, fail=False):
+        return
+    spawn_bounded(fn, make_args(free_port()), nprocs=nprocs, deadline_s=deadline_s, fail=True)
+
