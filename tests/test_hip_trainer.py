@@ -81,11 +81,13 @@ def test_trainer_fit_swin_t_224_b4(tmp_path):
     # restored from the file.  Not bit for bit, though: the path has a few fp32 atomics (embedding-row gradients, the scalar gate gradients),
     # and two runs of the SAME uninterrupted recipe in one process differ by up to 8e-5 in this loss and 1e-3 in single weights
     # (tools/probes/trainer_dbg.py: the key biases have a mathematically zero gradient, so Adam turns the last-bit noise of their
-    # gradient into +-lr steps).  Bounds = that spread x 2.5; the failure modes this test is for are orders of magnitude larger (a
-    # restarted warm-up or missing moments: 0.24 in the loss; a repeated epoch: 0.5).
-    assert abs(float(last_a) - float(last_c)) <= 2e-4 * max(1.0, abs(float(last_a))), (float(last_a), float(last_c))
+    # gradient into +-lr steps).  Round 6: one run of the suite read 2.4e-4 relative (9e-4 absolute) where the round-5 bound was 2e-4 --
+    # a noise bound set at 2.5 x the spread seen in a handful of runs is a coin waiting to land.  Bounds = 1e-3 relative in the loss, 6e-3 in
+    # single weights: still 60 x below the smallest failure this test is for (a restarted warm-up or missing moments: 0.24 in the
+    # loss; a repeated epoch: 0.5).
+    assert abs(float(last_a) - float(last_c)) <= 1e-3 * max(1.0, abs(float(last_a))), (float(last_a), float(last_c))
     sa, sc = ma.state_dict(), mc.state_dict()
     worst = max((float((sa[k].float() - sc[k].float()).abs().max()), k) for k in sa if sa[k].is_floating_point())
-    assert worst[0] <= 2.5e-3, worst
+    assert worst[0] <= 6e-3, worst
     # and it trained: the loss of the last step is below the first step's
     assert float(last_a) < 11.5, float(last_a)
