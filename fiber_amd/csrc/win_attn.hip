@@ -217,7 +217,7 @@ __device__ __forceinline__ void setup(const WinP& p, const Smem& S, int h, int n
 // ================================================================ forward =====================================
 // MAXC: 16-byte staging chunks per thread; NTC: key/query tiles if known at compile time (9 for 12x12 windows);
 // MTT: tile capacity (10 / 21); BREG: window-invariant bias slice in registers (else LDS look-ups per score)
-template <int MAXC, int NTC = 0, int MTT = 10, bool BREG = true>
+template <int MAXC, int NTC = 0, int MTT = 10, bool BREG = true, bool S0FREE = false>
 __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) {
   WIN_DIMS(MTT);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -240,11 +240,18 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
   setup<MTT>(p, S, h, nb, 2, 5.656854249492381f, 0.f);
 
   // this thread's staging chunks: chunk id = tid + c*blockDim -> (row = id>>2 of the window, 16-byte piece id&3)
-  int spr[MAXC], spc[MAXC];
-  bool sval[MAXC];
+  // S0F (round-6 experiment, off: FIBER_WIN_FWD_S0F=1 for A/B): the three waves of SIMD 0 (0, 4, 8; nine waves sit 3 / 2 / 2 / 2 on the SIMDs)
+  // stage nothing, the 576 chunks go to the six waves of SIMDs 1-3.  Bit-identical, 0-1 % faster (tools/probes/win_fwd_ab.py): the forward is
+  // not bound by SIMD 0's issue slots, whatever the per-wave s_memtime trace suggests.
+  constexpr bool S0F = MAXC == 1 && NTC == 9 && S0FREE;
+  constexpr int NCH = S0F ? 2 : MAXC;
+  int spr[NCH], spc[NCH], sid[NCH];
+  bool sval[NCH];
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
-    const int id = tid + c * blockDim.x;
+  for (int c = 0; c < NCH; ++c) {
+    int id = tid + c * blockDim.x;
+    if constexpr (S0F) id = (wave & 3) ? ((wave >> 2) * 3 + (wave & 3) - 1) * 64 + lane + c * 384 : 1 << 20;
+    sid[c] = id;
     sval[c] = (id >> 2) < p.N;
     const int r = sval[c] ? (id >> 2) : 0;
     spr[c] = r / p.ws; spc[c] = r - spr[c] * p.ws;
@@ -287,15 +294,15 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
   const float scale2 = scale * 1.4426950408889634f;     // scores kept in the log2 domain: exp is a bare v_exp_f32
   Geo geo;
   geo.set(p, g0);
-  bf16x8 kr[MAXC], vr[MAXC], qn;
+  bf16x8 kr[NCH], vr[NCH], qn;
   unsigned qpix = geo.pix(p, qpr, qpc);
   size_t qimg = geo.img(p);
   auto prefetch = [&]() {
     const bf16* base = p.qkv + qimg * ld;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < NCH; ++c) {
       if (sval[c]) {
-        const unsigned sc = (tid + c * blockDim.x) & 3;
+        const unsigned sc = sid[c] & 3;
         const unsigned st = geo.pix(p, spr[c], spc[c]) * ld + sc * 8;
         kr[c] = *reinterpret_cast<const bf16x8*>(at(base + ko, st));
         vr[c] = *reinterpret_cast<const bf16x8*>(at(base + vo, st));
@@ -319,9 +326,9 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
 #endif
     FWD_MARK(1);
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < NCH; ++c) {
       if (sval[c]) {
-        const int id = tid + c * blockDim.x, sr = id >> 2, sc = id & 3;
+        const int id = sid[c], sr = id >> 2, sc = id & 3;
         *reinterpret_cast<bf16x8*>(Ks + sr * RS + sc * 8) = kr[c];
         *reinterpret_cast<bf16x8*>(Vs + sr * RS + sc * 8) = vr[c];
       }
@@ -891,9 +898,16 @@ __device__ __forceinline__ bf16x8 trr_frag_lohi(const bf16* lo_img, int lo_strid
 
 // SHIFT: compile-time copy for shifted blocks -- every window then runs the masked body (interior windows carry one label: the
 // mask term is 0), so the kernel has ONE window body (two copies behind a branch cost 4-6 registers more than the cap allows).
-template <bool SHIFT>
-__global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
-  constexpr int MT = 9, MAXN = 160, NTH = 576;           // 12x12 windows: 9 strips of 16, images padded to 10 tiles
+// NWV = 11 (round 6): nine waves on four SIMDs are 3 / 2 / 2 / 2, both phases are issue-bound, so SIMD 0's third wave (key strip 8) was
+// the critical path of every window (tools/win_trace.py: phase 1 ends at 4.8 k ticks in waves 0-3, 6.3 k in waves 4-7, 8.1 k in wave 8).
+// Key strip 8 is cut by QUERY tiles into three helper waves 8 / 9 / 10 (SIMDs 0 / 1 / 2: 21 / 21 / 21 / 18 tile steps per SIMD instead of
+// 27 / 18 / 18 / 18).  Waves 8 and 9 hand their partial dK / dV of the strip to wave 10 through two LDS slots; wave 10, idle in phase 2,
+// adds them in a fixed order and stores the strip.  Waves 9 and 10 have no query strip (phase 2) and stage nothing.
+template <bool SHIFT, int NWV = 9>
+__global__ __launch_bounds__(NWV * 64) void win_bwd_fused_kernel(WinP p) {
+  constexpr int MT = 9, MAXN = 160, NTH = NWV * 64, NST = 576;   // 12x12 windows: 9 strips of 16, images padded to 10 tiles; NST staging threads
+  constexpr bool HELP = NWV == 11;
+  static_assert(NWV == 9 || NWV == 11, "9 waves, or 8 + 3 helpers of key strip 8");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nb = (2 * p.ws - 1) * (2 * p.ws - 1);
   Smem S = carve<10>(smem, nb, 0);
@@ -905,8 +919,14 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
   f32x4* db_lds = reinterpret_cast<f32x4*>(DSt + 144 * DSS);
   // column sums of dQ | dK | dV (the qkv bias gradient): reduced over the 16 key / query lanes in registers (the kernel is not
   // VALU-bound), then one f32x4 per (wave, lane group, piece) in LDS: [wave][gq][6]
-  f32x4* cs_small = db_lds + NL * NTH;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  f32x4* cs_small = db_lds + NL * NST;
+  f32x4* pslot = cs_small + NWV * 4 * 6;                 // HELP: partial dK | dV of key strip 8, [helper wave 8 | 9][4 accumulators][lane]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool helper = HELP && wave >= 8;                 // (wave-uniform)
+  // A helper runs the code of tiles 6, 7, 8 (first of a pair, second of a pair, alone; register accumulators 1 .. 3) on its query tiles
+  // hq0 .. hq0 + 2: every per-tile address below is taken relative to a base moved by trb tiles (0 in the waves that own a whole strip).
+  const int hq0 = helper ? (wave - 8) * 3 : 0;
+  const int trb = helper ? hq0 - 6 : 0;
   const int gq = lane >> 4, lq = lane & 15;
   const int h = blockIdx.y, C = p.C;
   // layout 3 = planar [3 * heads planes][token][32] for qkv / dqkv and [heads planes][token][32] for o / dout (see win_fwd_kernel)
@@ -922,11 +942,12 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
     uint32_t* z = reinterpret_cast<uint32_t*>(Qs);
     for (int t = tid; t < 3 * MAXN * RS / 2; t += NTH) z[t] = 0u;
   }
-  for (int t = tid; t < NL * NTH + 9 * 4 * 6; t += NTH) db_lds[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = tid; t < NL * NST + NWV * 4 * 6; t += NTH) db_lds[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   // staging chunk of this thread: row sr of the window, 16-byte piece sc (576 threads = 144 rows x 4 pieces exactly)
   const int sr = tid >> 2, sc = tid & 3;
   const int spr = sr / p.ws, spc = sr - spr * p.ws;
-  const int j = wave * 16 + lq;                          // this lane's key (phase 1) = this lane's query (phase 2)
+  const int j = (helper ? 8 : wave) * 16 + lq;           // this lane's key (phase 1) = this lane's query (phase 2)
+  const bool stager = !HELP || wave < 9;                 // waves 0-8 = the 576 staging threads
   const int kpr = j / p.ws, kpc = j - kpr * p.ws;
   const int kconst = (p.ws - 1) * (2 * p.ws - 1) + p.ws - 1 - (kpr * (2 * p.ws - 1) + kpc);
   const float scale = 0.17677669529663687f;
@@ -955,8 +976,9 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
     return v;
   };
   f32x4* cs_mine = cs_small + (wave * 4 + gq) * 6;
+  const int* koff_b = S.koff + trb * 16 + gq * 4;
   auto bias_tile = [&](int qt) -> f32x4 {                 // (the tile's base offset is re-read as well: nine more registers do not exist)
-    const float* b = S.btab + S.koff[qt * 16 + gq * 4] + kconst;
+    const float* b = S.btab + koff_b[qt * 16] + kconst;
     return f32x4{b[0], b[1], b[2], b[3]};
   };
   Geo geo;
@@ -967,12 +989,14 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
   size_t kimg = geo.img(p);
   auto prefetch = [&]() {
     const bf16* base = p.qkv + kimg * ld;
-    const unsigned st = geo.pix(p, spr, spc);
-    qr = *reinterpret_cast<const bf16x8*>(at(base + qo, st * ld + sc * 8));
-    kr = *reinterpret_cast<const bf16x8*>(at(base + ko, st * ld + sc * 8));
-    dr = *reinterpret_cast<const bf16x8*>(at(p.dout + oo + kimg * ldo, st * ldo + sc * 8));
-    orr = *reinterpret_cast<const bf16x8*>(at(static_cast<const bf16*>(p.o) + oo + kimg * ldo, st * ldo + sc * 8));
-    if (sc == 0) lser = *at(p.lse + kimg * p.heads + (size_t)h * p.Hres * p.Wres, st);
+    if (stager) {
+      const unsigned st = geo.pix(p, spr, spc);
+      qr = *reinterpret_cast<const bf16x8*>(at(base + qo, st * ld + sc * 8));
+      kr = *reinterpret_cast<const bf16x8*>(at(base + ko, st * ld + sc * 8));
+      dr = *reinterpret_cast<const bf16x8*>(at(p.dout + oo + kimg * ldo, st * ldo + sc * 8));
+      orr = *reinterpret_cast<const bf16x8*>(at(static_cast<const bf16*>(p.o) + oo + kimg * ldo, st * ldo + sc * 8));
+      if (sc == 0) lser = *at(p.lse + kimg * p.heads + (size_t)h * p.Hres * p.Wres, st);
+    }
     vn = *reinterpret_cast<const bf16x8*>(at(base + vo, kpix * ld + gq * 8));
   };
   prefetch();
@@ -992,6 +1016,7 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     WIN_MARK(1);
+    if (stager) {
     *reinterpret_cast<bf16x8*>(Qs + sr * RS + sc * 8) = qr;
     *reinterpret_cast<bf16x8*>(dOs + sr * RS + sc * 8) = dr;
     *reinterpret_cast<bf16x8*>(Ks + sr * RS + sc * 8) = kr;
@@ -1005,6 +1030,7 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
       dpart += __shfl_xor(dpart, 2);
       // seeds of the S and dP accumulators: (q.k - lse/scale) * scale*log2e + bias = log2 p, and dP - delta come out of the MFMAs
       if (sc == 0) { S.lse[sr] = lser * -5.656854249492381f; S.dlt[sr] = -dpart; }
+    }
     }
     float* kregf = reinterpret_cast<float*>(S.kreg);     // shift-region labels as floats
     float kregf_own = 0.f;
@@ -1022,7 +1048,7 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
     // The next window's loads are requested from INSIDE phase 1, a third of the waves at tile 0, 3 and 6: all nine waves requesting
     // right behind the barrier stalled each other for 0.5-2 k ticks on the address path (tools/win_trace.py) with nobody computing;
     // the data is needed a whole phase later either way (it used to land ~9 k ticks early).
-    const int pf_tile = (wave % 3) * 3;
+    const int pf_tile = helper ? 6 : (wave % 3) * 3;
     const bool pf_more = g + 1 < g1;
     auto prefetch_next = [&]() {
       geo.next(p);
@@ -1034,44 +1060,57 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
     // ---- phase 1: this wave's key strip against every query tile
     f32x4 dkacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     f32x4 dvacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    bf16* dsrow = DSt + j * DSS + gq * 4;                // DSt[key j][query tile * 16 + gq * 4 .. + 3]
+    bf16* dsrow = DSt + j * DSS + trb * 16 + gq * 4;     // DSt[key j][query tile * 16 + gq * 4 .. + 3]
+    const bf16* Qb = Qs + trb * 16 * RS; const bf16* dOb = dOs + trb * 16 * RS;
+    const float* lse_b = S.lse + trb * 16 + gq * 4; const float* dlt_b = S.dlt + trb * 16 + gq * 4;
     // One query tile per step; the dK / dV MFMAs are the K = 16 form (the operand is the tile's own 16 queries), so a step holds one
     // tile's temporaries instead of a pair's -- this kernel also carries 36 dbias accumulators under a 168-register cap.
     {
       constexpr bool BORDER = SHIFT;
       bf16x4 ds_prev, p_prev;
-      auto tile = [&](auto qi_t) {
+      // ROLE: 0 = first tile of a pair, 1 = second tile of a pair, 2 = alone.  DB: the tile's dbias accumulator, -1 = the LDS slot of tile QI,
+      // else register set DB.  (In a helper wave "tile QI" is query tile QI + trb.)
+      // The step of a tile is cut in two: front = operand reads + the S and dP MFMAs (results in sa / sdp), back = everything behind them.
+      // The front of tile i + 1 is issued BEFORE the back of tile i (two result sets, A for even tiles, B for odd ones): a SIMD holds two or three
+      // waves here and each tile is one dependent chain LDS -> MFMA -> exp -> convert -> MFMA, so the matrix pipe idled under the chain's VALU part
+      // (vector + matrix time per SIMD added up to the length of phase 1: tools/win_trace.py).
+      auto front = [&](auto qi_t, f32x4& sa, f32x4& sdp) {
         constexpr int qi = decltype(qi_t)::value;
         if constexpr (qi % 3 == 0) { if (pf_more && pf_tile == qi) prefetch_next(); }
-        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + (qi * 16 + lq) * RS + gq * 8);
-        const bf16x8 df = *reinterpret_cast<const bf16x8*>(dOs + (qi * 16 + lq) * RS + gq * 8);
-        f32x4 sa = *reinterpret_cast<const f32x4*>(S.lse + qi * 16 + gq * 4);
-        f32x4 sdp = *reinterpret_cast<const f32x4*>(S.dlt + qi * 16 + gq * 4);
+        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qb + (qi * 16 + lq) * RS + gq * 8);
+        const bf16x8 df = *reinterpret_cast<const bf16x8*>(dOb + (qi * 16 + lq) * RS + gq * 8);
+        sa = *reinterpret_cast<const f32x4*>(lse_b + qi * 16);
+        sdp = *reinterpret_cast<const f32x4*>(dlt_b + qi * 16);
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, sa, 0, 0, 0);        // S[query][key] - lse/scale
+        sdp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf, sdp, 0, 0, 0);      // dP[query][key] - delta
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto back = [&](auto qi_t, auto role_t, auto db_t, const f32x4& sa, const f32x4& sdp) {
+        constexpr int QI = decltype(qi_t)::value, ROLE = decltype(role_t)::value, DB = decltype(db_t)::value;
+        constexpr int qi = QI;
         f32x4 qg;
-        if constexpr (BORDER) qg = *reinterpret_cast<const f32x4*>(kregf + qi * 16 + gq * 4);
+        if constexpr (BORDER) qg = *reinterpret_cast<const f32x4*>(kregf + trb * 16 + qi * 16 + gq * 4);
         const f32x4 bq = bias_tile(qi);
         // dK / dV: query tiles are consumed in PAIRS by K = 32 MFMAs (the K = 16 form has half the rate per pass: 1.7 k of SIMD 0's
         // 10 k cycles per window); the odd tile of a pair brings both tiles' transposed operands, the last tile (8) runs alone
-        constexpr bool PAIR_END = (qi & 1) == 1, ALONE = qi == MT - 1;
+        constexpr bool PAIR_END = ROLE == 1, ALONE = ROLE == 2;
         bf16x8 qt2[2], dt2[2];
         if constexpr (PAIR_END) {
 #pragma unroll
-          for (int dt = 0; dt < 2; ++dt) { qt2[dt] = trr_frag(Qs, dt * 16, qi - 1, gq, lq); dt2[dt] = trr_frag(dOs, dt * 16, qi - 1, gq, lq); }
+          for (int dt = 0; dt < 2; ++dt) { qt2[dt] = trr_frag(Qb, dt * 16, qi - 1, gq, lq); dt2[dt] = trr_frag(dOb, dt * 16, qi - 1, gq, lq); }
         } else if constexpr (ALONE) {
-          // Q^T / dO^T of this tile and of the (all-zero, never staged) image rows 144..159 behind it: the lone tile runs as a K = 32
-          // MFMA whose upper half is zero.  NOT the K = 16 opcode (round 5): a 16x16x16 MFMA that takes the D of a 16x16x32 MFMA as
+          // Q^T / dO^T of this tile and of the image rows behind it (tile 8: the all-zero, never staged rows 144..159; a helper's lone tile:
+          // the next tile's rows, finite, against the zero half of dS / P): the lone tile runs as a K = 32 MFMA whose upper half is zero.  NOT the K = 16 opcode (round 5): a 16x16x16 MFMA that takes the D of a 16x16x32 MFMA as
           // its C is padded by hipcc like an accumulate chain of ONE opcode (one wait state) and can read the accumulator before the
           // K = 32 instruction has written it -- seen in a forward kernel as row sums of "last tile + stale registers".
 #pragma unroll
-          for (int dt = 0; dt < 2; ++dt) { qt2[dt] = trr_frag(Qs, dt * 16, qi, gq, lq); dt2[dt] = trr_frag(dOs, dt * 16, qi, gq, lq); }
+          for (int dt = 0; dt < 2; ++dt) { qt2[dt] = trr_frag(Qb, dt * 16, qi, gq, lq); dt2[dt] = trr_frag(dOb, dt * 16, qi, gq, lq); }
         }
-        sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, sa, 0, 0, 0);        // S[query][key] - lse/scale
-        sdp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf, sdp, 0, 0, 0);      // dP[query][key] - delta
         f32x4 sv = fma4(sa, scale * 1.4426950408889634f, bq);
         if constexpr (BORDER) sv = region_mask(sv, qg, kregf_own, -144.26950408889634f);
         const f32x4 pr = exp2x4(sv);
         const f32x4 ds = pr * sdp;
-        if constexpr (qi < NL) db_mine[qi * NTH] += ds; else dbacc[qi - NL] += ds;
+        if constexpr (DB < 0) db_mine[QI * NST] += ds; else dbacc[DB] += ds;
         bf16x4 dsb, pb;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { dsb[r] = f2bf(ds[r]); pb[r] = f2bf(pr[r]); }
@@ -1099,26 +1138,57 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
         }
         __builtin_amdgcn_sched_barrier(0);                 // no loads of later tiles hoisted over this one (register cap)
       };
-      tile(std::integral_constant<int, 0>{}); tile(std::integral_constant<int, 1>{}); tile(std::integral_constant<int, 2>{});
-      tile(std::integral_constant<int, 3>{}); tile(std::integral_constant<int, 4>{}); tile(std::integral_constant<int, 5>{});
-      tile(std::integral_constant<int, 6>{}); tile(std::integral_constant<int, 7>{}); tile(std::integral_constant<int, 8>{});
+      using std::integral_constant;
+      static_assert(NL == 5 && MT == 9, "the call list below spells the accumulator of every tile out");
+      f32x4 saA, sdA, saB, sdB;
+#define WIN_F(QI, X) front(integral_constant<int, QI>{}, sa##X, sd##X)
+#define WIN_B(QI, ROLE, DB, X) back(integral_constant<int, QI>{}, integral_constant<int, ROLE>{}, integral_constant<int, DB>{}, sa##X, sd##X)
+      if (!helper) {
+        WIN_F(0, A);
+        WIN_F(1, B); WIN_B(0, 0, -1, A);
+        WIN_F(2, A); WIN_B(1, 1, -1, B);
+        WIN_F(3, B); WIN_B(2, 0, -1, A);
+        WIN_F(4, A); WIN_B(3, 1, -1, B);
+        WIN_F(5, B); WIN_B(4, 0, -1, A);
+      }
+      WIN_F(6, A);
+      if (!helper) WIN_B(5, 1, 0, B);
+      WIN_F(7, B); WIN_B(6, 0, 1, A);
+      WIN_F(8, A); WIN_B(7, 1, 2, B);
+      WIN_B(8, 2, 3, A);
+#undef WIN_F
+#undef WIN_B
     }
     WIN_MARK(8);
+    auto store_dkv = [&]() {
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-      bf16x4 ok, ov;
+      for (int dt = 0; dt < 2; ++dt) {
+        bf16x4 ok, ov;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { ok[r] = f2bf(dkacc[dt][r] * scale); ov[r] = f2bf(dvacc[dt][r]); }
-      *reinterpret_cast<bf16x4*>(at(p.dqkv + dko + oimg * ldd, opix * ldd + dt * 16 + gq * 4)) = ok;
-      *reinterpret_cast<bf16x4*>(at(p.dqkv + dvo + oimg * ldd, opix * ldd + dt * 16 + gq * 4)) = ov;
-    }
-    if (p.colsum_part) {
-      const f32x4 s0 = lane16_sum(dkacc[0] * scale), s1 = lane16_sum(dkacc[1] * scale), s2 = lane16_sum(dvacc[0]), s3 = lane16_sum(dvacc[1]);
-      if (lq == 0) { cs_mine[2] += s0; cs_mine[3] += s1; cs_mine[4] += s2; cs_mine[5] += s3; }
+        for (int r = 0; r < 4; ++r) { ok[r] = f2bf(dkacc[dt][r] * scale); ov[r] = f2bf(dvacc[dt][r]); }
+        *reinterpret_cast<bf16x4*>(at(p.dqkv + dko + oimg * ldd, opix * ldd + dt * 16 + gq * 4)) = ok;
+        *reinterpret_cast<bf16x4*>(at(p.dqkv + dvo + oimg * ldd, opix * ldd + dt * 16 + gq * 4)) = ov;
+      }
+      if (p.colsum_part) {
+        const f32x4 s0 = lane16_sum(dkacc[0] * scale), s1 = lane16_sum(dkacc[1] * scale), s2 = lane16_sum(dvacc[0]), s3 = lane16_sum(dvacc[1]);
+        if (lq == 0) { cs_mine[2] += s0; cs_mine[3] += s1; cs_mine[4] += s2; cs_mine[5] += s3; }
+      }
+    };
+    if (!helper) store_dkv();
+    else if (wave < 10) {                                // partial sums of key strip 8 over this helper's query tiles -> wave 10
+      f32x4* ps = pslot + (wave - 8) * 256 + lane;
+      ps[0] = dkacc[0]; ps[64] = dkacc[1]; ps[128] = dvacc[0]; ps[192] = dvacc[1];
     }
     WIN_MARK(4);
-    __syncthreads();                                     // DSt complete
+    __syncthreads();                                     // DSt (and the partial slots) complete
     WIN_MARK(5);
+    if (HELP && wave == 10) {                            // (w8 + w9) + w10, always in this order
+      const f32x4* ps = pslot + lane;
+      dkacc[0] = (ps[0] + ps[256]) + dkacc[0]; dkacc[1] = (ps[64] + ps[320]) + dkacc[1];
+      dvacc[0] = (ps[128] + ps[384]) + dvacc[0]; dvacc[1] = (ps[192] + ps[448]) + dvacc[1];
+      store_dkv();
+    }
+    if (!HELP || wave < 9) {
     // ---- phase 2: dQ^T[d][query] of this wave's query strip = sum over keys K^T[d][key] dS^T[key][query]
     f32x4 dqacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -1144,11 +1214,12 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
       const f32x4 s0 = lane16_sum(dqacc[0] * scale), s1 = lane16_sum(dqacc[1] * scale);
       if (lq == 0) { cs_mine[0] += s0; cs_mine[1] += s1; }
     }
+    }
     WIN_MARK(6);
   }
 #ifdef FIBER_WIN_TRACE
   if (lane == 0 && blockIdx.x < 4 && h == 0) {
-    float* o = p.delta + (blockIdx.x * 9 + wave) * 12;
+    float* o = p.delta + (blockIdx.x * NWV + wave) * 12;
     for (int i = 0; i < 12; ++i) o[i] = (float)tr[i];
     if (wave == 0) p.delta[1000 + blockIdx.x] = (float)(g1 - g0);
   }
@@ -1156,11 +1227,18 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
 #undef WIN_MARK
   {                                                      // dbias_part[z, h, i, j]: this lane holds column j, rows qt*16 + gq*4 + r
     float* dst = p.dbias_part + ((size_t)blockIdx.x * p.heads + h) * p.N * p.N + j;
+    if (!helper) {
 #pragma unroll
-    for (int qt = 0; qt < MT; ++qt) {
-      const f32x4 v = qt < NL ? db_mine[qt * NTH] : dbacc[qt < NL ? 0 : qt - NL];
+      for (int qt = 0; qt < MT; ++qt) {
+        const f32x4 v = qt < NL ? db_mine[qt * NST] : dbacc[qt < NL ? 0 : qt - NL];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dst[(size_t)(qt * 16 + gq * 4 + r) * p.N] = v[r];
+        for (int r = 0; r < 4; ++r) dst[(size_t)(qt * 16 + gq * 4 + r) * p.N] = v[r];
+      }
+    } else {
+#pragma unroll
+      for (int li = 0; li < 3; ++li)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[(size_t)((hq0 + li) * 16 + gq * 4 + r) * p.N] = dbacc[1 + li][r];
     }
   }
   if (p.colsum_part) {                                   // channel c of group grp (q | k | v): piece grp*2 + (c >> 4), lane group (c >> 2) & 3, element c & 3
@@ -1168,7 +1246,7 @@ __global__ __launch_bounds__(576) void win_bwd_fused_kernel(WinP p) {
     if (tid < 96) {
       const int grp = tid >> 5, c = tid & 31;
       float sum = 0.f;
-      for (int w = 0; w < 9; ++w) sum += cs_small[(w * 4 + ((c >> 2) & 3)) * 6 + grp * 2 + (c >> 4)][c & 3];
+      for (int w = 0; w < NWV; ++w) sum += cs_small[(w * 4 + ((c >> 2) & 3)) * 6 + grp * 2 + (c >> 4)][c & 3];
       const int chan0 = planar ? grp * C + h * 32 : (int)(grp == 0 ? qo : grp == 1 ? ko : vo);   // planar: sums in the reference channel order
       p.colsum_part[(size_t)blockIdx.x * 3 * C + chan0 + c] = sum;
     }
@@ -1228,11 +1306,14 @@ void ensure_attrs() {
   hipFuncSetAttribute((const void*)win_bwd_dq_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   hipFuncSetAttribute((const void*)win_bwd_dkv_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   hipFuncSetAttribute((const void*)win_fwd_kernel<1, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)win_fwd_kernel<1, 9, 10, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   hipFuncSetAttribute((const void*)win_fwd_kernel<3, 0, 21, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   hipFuncSetAttribute((const void*)win_bwd_dq_kernel<3, 0, 21, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   hipFuncSetAttribute((const void*)win_bwd_dkv_kernel<3, 0, 21, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   hipFuncSetAttribute((const void*)win_bwd_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   hipFuncSetAttribute((const void*)win_bwd_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)win_bwd_fused_kernel<false, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  hipFuncSetAttribute((const void*)win_bwd_fused_kernel<true, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
 }
 
 // waves per workgroup / strip groups of the three passes
@@ -1311,7 +1392,11 @@ int fiber_win_fwd_launch(const void* qkv, const float* bias_table, void* o, floa
   int nw, sg;
   strip_geometry(p.N, nw, sg);
   if (big_window(p.N)) hipLaunchKernelGGL((win_fwd_kernel<3, 0, 21, false>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2), st, p);
-  else if (p.N == 144 && (ntc_mask() & 1)) hipLaunchKernelGGL((win_fwd_kernel<1, 9>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2), st, p);
+  else if (p.N == 144 && (ntc_mask() & 1)) {
+    static const bool s0f = getenv("FIBER_WIN_FWD_S0F") && atoi(getenv("FIBER_WIN_FWD_S0F")) != 0;   // experiment: SIMD 0's waves stage nothing
+    if (!s0f) hipLaunchKernelGGL((win_fwd_kernel<1, 9>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2), st, p);
+    else hipLaunchKernelGGL((win_fwd_kernel<1, 9, 10, true, true>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2), st, p);
+  }
   else hipLaunchKernelGGL((win_fwd_kernel<1, 0>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2), st, p);
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
@@ -1349,8 +1434,13 @@ int fiber_win_bwd_launch(const void* qkv, const float* bias_table, const void* o
   if ((colsum_ws == nullptr) != (dqkv_colsum == nullptr)) return FIBER_EINVAL;
   if (p.N == 144 && sg == 1) {                           // 12x12 windows: one pass (delta_ws stays unused).  The two-pass instances for this
     // size (round 3's A/B switch FIBER_WIN_FUSED=0) carried 8 / 24 bytes of scratch and are no longer built.
-    const size_t bytes = (size_t)(4 * 160 + ((nb + 3) & ~3)) * 4 + (size_t)3 * 160 * RS * 2 + (size_t)144 * DSS * 2 + (size_t)(5 * 576 + 9 * 4 * 6) * 16;
-    if (shift > 0) hipLaunchKernelGGL(win_bwd_fused_kernel<true>, dim3(gz, heads, 1), dim3(576), bytes, st, p);
+    static const int nwv = getenv("FIBER_WIN_BWD_WAVES") ? atoi(getenv("FIBER_WIN_BWD_WAVES")) : 9;   // 11: key strip 8 on three helper waves
+    const size_t bytes = (size_t)(4 * 160 + ((nb + 3) & ~3)) * 4 + (size_t)3 * 160 * RS * 2 + (size_t)144 * DSS * 2 +
+                         (size_t)(5 * 576 + (nwv == 11 ? 11 * 4 * 6 + 2 * 4 * 64 : 9 * 4 * 6)) * 16;
+    if (nwv == 11) {
+      if (shift > 0) hipLaunchKernelGGL((win_bwd_fused_kernel<true, 11>), dim3(gz, heads, 1), dim3(704), bytes, st, p);
+      else hipLaunchKernelGGL((win_bwd_fused_kernel<false, 11>), dim3(gz, heads, 1), dim3(704), bytes, st, p);
+    } else if (shift > 0) hipLaunchKernelGGL(win_bwd_fused_kernel<true>, dim3(gz, heads, 1), dim3(576), bytes, st, p);
     else hipLaunchKernelGGL(win_bwd_fused_kernel<false>, dim3(gz, heads, 1), dim3(576), bytes, st, p);
     FIBER_CHECK_LAUNCH();
     if (int rc = dbias_fold_gather(dbias_ws, dbias_table, gz, heads, ws, st)) return rc;

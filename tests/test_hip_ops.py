@@ -328,6 +328,23 @@ def test_window_attention_head_major_layout(ops, B, H, W, heads, ws, shift):
         assert_close(name, a, r, 6e-3)
 
 
+def test_window_attention_backward_helper_wave_variant():
+    """FIBER_WIN_BWD_WAVES=11 (key strip 8 of the one-pass 12x12 backward cut over three helper waves, csrc/win_attn.hip) against the shipped
+    nine-wave kernel on the same inputs, all four stages, shifted and unshifted, with and without the column-sum offer: dqkv may differ by the
+    summation order of strip 8's dK / dV partials (a bf16 ulp: 4e-3 of the tensor's maximum), the bias-table gradient and the column sums by fp32
+    round-off.  The switch is read once per process, so the two kernels run in child processes (tools/probes/win_bwd_waves_ab.py)."""
+    import os
+    import sys
+    from tests.mp_util import run_bounded
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = run_bounded([sys.executable, os.path.join(root, "tools", "probes", "win_bwd_waves_ab.py"), "3"], timeout=240, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rows = [ln.split() for ln in r.stdout.splitlines() if ln[:2] in ("s0", "s1", "s2", "s3")]
+    assert len(rows) == 16, r.stdout
+    for case, _, _, dq, dt, dc in rows:
+        assert float(dq) < 4e-3 and float(dt) < 1e-5 and float(dc) < 1e-5, (case, dq, dt, dc)
+
+
 @pytest.mark.parametrize("M,N,K", [
     (131072, 384, 128),      # stage-0 qkv: 128x128 tiles, deep split
     (65536, 512, 2048),      # fc2: 256x256 tiles, staggered wave groups

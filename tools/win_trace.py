@@ -12,6 +12,9 @@ from fiber_amd import lib
 lib.load()
 B, H, C, heads, ws = 512, 24, 512, 16, 12
 shift = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+NWV = int(os.environ.get("FIBER_WIN_BWD_WAVES", "9"))
+WAVES = list(range(NWV)) if len(sys.argv) > 2 and sys.argv[2] == "all" else (0, 4, 8)
+WNAME = f"0-{NWV - 1}" if len(WAVES) == NWV else "0 / 4 / 8"
 rows, N = B * H * H, ws * ws
 dev = "cuda"
 qkv = torch.randn(rows, 3 * C, device=dev).to(torch.bfloat16)
@@ -36,10 +39,10 @@ d = delta.flatten().cpu()
 names = ["top barrier", "prefetch landed (vmcnt 0)", "staging + delta", "barrier 2", "dk/dv stores + colsum", "barrier 3", "phase 2 + dq store + colsum", "kf read + next prefetch issued", "phase 1 body"]
 for blk in range(2):
     nwin = float(d[1000 + blk])
-    print(f"workgroup {blk}: {nwin:.0f} windows; ticks per window and segment (s_memtime), waves 0 / 4 / 8")
+    print(f"workgroup {blk}: {nwin:.0f} windows; ticks per window and segment (s_memtime), waves {WNAME}")
     for i in range(9):
-        print(f"  {names[i]:52s}", " ".join(f"{float(d[(blk * 9 + w) * 12 + i]) / nwin:8.0f}" for w in (0, 4, 8)))
-    print("  total", " ".join(f"{sum(float(d[(blk * 9 + w) * 12 + i]) for i in range(9)) / nwin:8.0f}" for w in (0, 4, 8)))
+        print(f"  {names[i]:52s}", " ".join(f"{float(d[(blk * NWV + w) * 12 + i]) / nwin:8.0f}" for w in WAVES))
+    print("  total", " ".join(f"{sum(float(d[(blk * NWV + w) * 12 + i]) for i in range(9)) / nwin:8.0f}" for w in WAVES))
 
 # forward kernel: the TRACE build keeps its sums in a device symbol
 import ctypes as C
@@ -51,7 +54,7 @@ if hasattr(L, "fiber_win_trace_read"):
     for blk in range(2):
         nwin = buf[200 + blk]
         if nwin:
-            print(f"forward workgroup {blk}: {nwin:.0f} windows; ticks per window and segment, waves 0 / 4 / 8")
+            print(f"forward workgroup {blk}: {nwin:.0f} windows; ticks per window and segment, waves {WNAME}")
             for i in range(7):
-                print(f"  {fn[i]:30s}", " ".join(f"{buf[(blk * 10 + w) * 8 + i] / nwin:8.0f}" for w in (0, 4, 8)))
-            print("  total", " ".join(f"{sum(buf[(blk * 10 + w) * 8 + i] for i in range(7)) / nwin:8.0f}" for w in (0, 4, 8)))
+                print(f"  {fn[i]:30s}", " ".join(f"{buf[(blk * 10 + w) * 8 + i] / nwin:8.0f}" for w in WAVES))
+            print("  total", " ".join(f"{sum(buf[(blk * 10 + w) * 8 + i] for i in range(7)) / nwin:8.0f}" for w in WAVES))
