@@ -152,3 +152,66 @@ extern "C" int fiber_transpose_multi_bf16(const void* table, int ndesc, int ntil
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Row-permuted bf16 working copies of fp32 weights (the head-major qkv projections of the window-attention blocks, ops._LinearQKVHeadMajor:
+// rows reordered to [heads][3][32]) in ONE launch after the optimizer step: dst[n][:] = bf16(src[perm[n]][:]), its transpose
+// dst_t[:][n] for the dX GEMM, and the permuted fp32 bias.  Before, each of the 24 projections was refreshed by five ATen launches
+// (index, cast, index, clone, strided copy) per step.
+namespace {
+
+struct PermDesc { const float* src; const int* perm; bf16* dst; bf16* dst_t; const float* bias; float* bias_dst; int N, K, tile0, tiles_k; };   // 64 bytes
+
+__global__ __launch_bounds__(256) void rowperm_cast_multi_kernel(const PermDesc* __restrict__ table, int ndesc) {
+  __shared__ bf16 tile[64][72];
+  int lo = 0, hi = ndesc - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PermDesc d = table[lo];
+  const int t = blockIdx.x - d.tile0;
+  const int n0 = (t / d.tiles_k) * 64, k0 = (t % d.tiles_k) * 64;
+  const int r = threadIdx.x >> 3, c = threadIdx.x & 7;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int n = n0 + r + h * 32, k = k0 + c * 8;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = f2bf(0.f);
+    if (n < d.N && k < d.K) {                            // K % 8 == 0
+      const float4* sp = reinterpret_cast<const float4*>(d.src + (size_t)d.perm[n] * d.K + k);
+      const float4 a = sp[0], b = sp[1];
+      v[0] = f2bf(a.x); v[1] = f2bf(a.y); v[2] = f2bf(a.z); v[3] = f2bf(a.w);
+      v[4] = f2bf(b.x); v[5] = f2bf(b.y); v[6] = f2bf(b.z); v[7] = f2bf(b.w);
+      *reinterpret_cast<bf16x8*>(d.dst + (size_t)n * d.K + k) = v;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tile[r + h * 32][c * 8 + e] = v[e];
+  }
+  if (k0 == 0 && d.bias && threadIdx.x < 64 && n0 + (int)threadIdx.x < d.N) d.bias_dst[n0 + threadIdx.x] = d.bias[d.perm[n0 + threadIdx.x]];
+  __syncthreads();
+  if (d.dst_t) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = k0 + r + h * 32, n = n0 + c * 8;
+      if (k < d.K && n < d.N) {                          // N % 8 == 0
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = tile[c * 8 + e][r + h * 32];
+        *reinterpret_cast<bf16x8*>(d.dst_t + (size_t)k * d.N + n) = v;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// table: device array of ndesc 64-byte records {const float* src [N,K]; const int32* perm [N]; bf16* dst [N,K]; bf16* dst_t [K,N] or null;
+// const float* bias [N] or null; float* bias_dst [N]; int32 N, K, tile0, tiles_k}, tiles as in fiber_transpose_multi_bf16.  N % 8 == K % 8 == 0.
+extern "C" int fiber_rowperm_cast_multi_bf16(const void* table, int ndesc, int ntiles, hipStream_t stream) {
+  if (ndesc <= 0 || ntiles <= 0) return FIBER_OK;
+  hipLaunchKernelGGL(rowperm_cast_multi_kernel, dim3((unsigned)ntiles), dim3(256), 0, stream, (const PermDesc*)table, ndesc);
+  FIBER_CHECK_LAUNCH();
+  return FIBER_OK;
+}

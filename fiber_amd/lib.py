@@ -56,6 +56,7 @@ SIGNATURES = {
     "fiber_resize_bicubic_norm_u8": [P, I, P, P, P, I, I, P, P],
     "fiber_mlm_mask_i64": [P, P, P, L, U64, C.c_uint, I, I, I, I],
     "fiber_transpose_multi_bf16": [P, I, I],
+    "fiber_rowperm_cast_multi_bf16": [P, I, I],
     "fiber_dcn_gather_bf16": [P, P, P, P, I, I, I, I, I, I, I, I, I, I],
     "fiber_dcn_scatter_bf16": [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I],
     "fiber_dcn_dx_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I],

@@ -140,6 +140,46 @@ def refresh_transposed_copies():
                 _wcache[key] = (_stamp(w), wt, ref)
 
 
+_hm_table = {}                       # device -> (members, device table, tiles)
+_HM_REFRESH = os.environ.get("FIBER_HM_REFRESH", "1") != "0"      # 0: the lazy ATen refresh in the next forward (A/B)
+
+
+def refresh_head_major_copies():
+    """Rewrite every cached head-major qkv working copy (permuted bf16 weight, its transpose, permuted fp32 bias: _LinearQKVHeadMajor) from the
+    fp32 parameters in ONE launch and mark it current.  Called by FiberAdamW.step() after the parameter update, like refresh_transposed_copies();
+    copies the optimizer did not touch are rewritten too (same values)."""
+    if not _HM_REFRESH:
+        return
+    by_dev = {}
+    for key, (stamp, val, ref) in list(_wcache.items()):
+        if not (isinstance(key, tuple) and key[0] == "HM"):
+            continue
+        w = ref()
+        b = val[3]() if len(val) > 3 else None
+        if w is None or b is None or not val[0].is_cuda or w.dtype != torch.float32 or b.dtype != torch.float32 or not w.is_contiguous():
+            continue
+        if (w.shape[0] % 8) or (w.shape[1] % 8):
+            continue
+        by_dev.setdefault(w.device, []).append((key, w, b, val, ref))
+    for dev, items in by_dev.items():
+        members = tuple((w.data_ptr(), b.data_ptr(), v[0].data_ptr(), v[1].data_ptr(), v[2].data_ptr()) for _, w, b, v, _ in items)
+        ent = _hm_table.get(dev)
+        if ent is None or ent[0] != members:
+            rows, tile0 = [], 0
+            for _, w, b, v, _ in items:
+                N, K = w.shape
+                tk = -(-K // 64)
+                pm = _qkv_perm32(K, v[4], dev)
+                rows.append((w.data_ptr(), pm.data_ptr(), v[0].data_ptr(), v[2].data_ptr(), b.data_ptr(), v[1].data_ptr(), N | (K << 32), tile0 | (tk << 32)))
+                tile0 += -(-N // 64) * tk
+            ent = (members, torch.tensor(rows, dtype=torch.int64).to(dev), tile0)
+            _hm_table[dev] = ent
+        with torch.cuda.device(dev):
+            lib.call("fiber_rowperm_cast_multi_bf16", lib.ptr(ent[1]), len(items), ent[2])
+        for key, w, b, v, ref in items:
+            _wcache[key] = ((_stamp(w), _stamp(b)), v, ref)
+
+
 def bf16_copy_if_cached(w):
     """The cached bf16 working copy of `w` (whatever its state), or None -- for the fused optimizer, which rewrites it."""
     hit = _cache_get(id(w), w)
@@ -165,6 +205,7 @@ def cast_bf16(w):
 def clear_weight_cache():
     _wcache.clear()
     _packs.clear()
+    _hm_table.clear()
 
 
 def _rows(x):
@@ -1106,8 +1147,9 @@ class _LinearQKVHeadMajor(torch.autograd.Function):
         hit = _cache_get(key, weight)
         if hit is None or hit[0] != (_stamp(weight), _stamp(bias)):
             wp = weight.detach()[perm].to(BF16).contiguous()
-            _cache_put(key, (_stamp(weight), _stamp(bias)), (wp, bias.detach()[perm].contiguous(), wp.t().contiguous()), weight)
-        wp, bp, _ = _wcache[key][1]
+            _cache_put(key, (_stamp(weight), _stamp(bias)), (wp, bias.detach()[perm].contiguous(), wp.t().contiguous(), weakref.ref(bias), heads), weight)
+            _hm_table.clear()                                # (new storage: the one-launch refresh rebuilds its descriptor table)
+        wp, bp = _wcache[key][1][:2]
         y, _ = gemm_nt(x2, wp, bp)
         ctx.save_for_backward(x2, weight)
         ctx.shp, ctx.heads = shp, heads
@@ -1119,7 +1161,7 @@ class _LinearQKVHeadMajor(torch.autograd.Function):
         dy2 = _c(dy).view(-1, weight.shape[0])
         hint = _take_colsum(dy2)
         perm, inv = _qkv_perm(weight.shape[1], ctx.heads, dy.device)
-        wp, _, wpt = _wcache[("HM", id(weight))][1]
+        wp, _, wpt = _wcache[("HM", id(weight))][1][:3]
         dx = gemm_nt(dy2, wpt)[0].view(ctx.shp)
         if _TN_ROWMAP:                                      # row r' of the head-major gradient is written at row perm[r'] by the kernel
             pmap = _qkv_perm32(weight.shape[1], ctx.heads, dy.device)

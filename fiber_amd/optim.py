@@ -173,4 +173,5 @@ class FiberAdamW(torch.optim.Optimizer):
             bumped = True
         if bumped:
             ops.refresh_transposed_copies()            # every W^T working copy in one launch (233 strided copies per step before)
+            ops.refresh_head_major_copies()            # ... and the permuted qkv copies of the window blocks (120 ATen launches per step before)
         return loss

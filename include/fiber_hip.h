@@ -205,6 +205,12 @@ int fiber_adamw_multi_f32(const long long* table, const long long* numel, const 
  * records {const bf16* src [N,K]; bf16* dst [K,N]; int32 N, K, tile0, tiles_k}; tile0 ascending from 0, a weight owns
  * ceil(N/64)*ceil(K/64) tiles, tiles_k = ceil(K/64); ntiles = the total.  N % 8 == K % 8 == 0. */
 int fiber_transpose_multi_bf16(const void* table, int ndesc, int ntiles, fiber_stream_t stream);
+/* Row-permuted bf16 working copies (+ their transposes, + the permuted fp32 bias) of fp32 weights in one launch after the optimizer step:
+ * the head-major qkv projections of the window-attention blocks (ops._LinearQKVHeadMajor; the permutation is this implementation's, the
+ * weights are WindowAttention.qkv, swin_transformer.py:197).  table: device array of ndesc 64-byte records {const float* src [N,K];
+ * const int32* perm [N]; bf16* dst [N,K]; bf16* dst_t [K,N] or null; const float* bias [N] or null; float* bias_dst [N]; int32 N, K, tile0,
+ * tiles_k}: dst[n] = bf16(src[perm[n]]), dst_t = dst^T, bias_dst[n] = bias[perm[n]]; tiles as in fiber_transpose_multi_bf16. */
+int fiber_rowperm_cast_multi_bf16(const void* table, int ndesc, int ntiles, fiber_stream_t stream);
 /* On-device input pipeline.
  * fiber_resize_bicubic_norm_u8 replaces transforms/transform.py:10-17 `albef_transform`: torchvision Resize((S,S), BICUBIC) on a
  * PIL RGB image (= Pillow ImagingResample: anti-aliased separable bicubic, 22-bit fixed-point coefficients, 8-bit rounding after

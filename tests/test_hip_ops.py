@@ -813,6 +813,36 @@ def test_transposed_weight_copies_refreshed_in_one_launch():
             assert torch.equal(ops_mod.bf16_weight(w), w.detach().to(BF))
 
 
+def test_head_major_qkv_copies_refreshed_in_one_launch():
+    """FiberAdamW.step() rewrites the permuted working copies of every head-major qkv projection (bf16 weight rows in [heads][3][32] order, their
+    transpose, the permuted fp32 bias) with fiber_rowperm_cast_multi_bf16: same storage as before the step, contents = what the lazy ATen path
+    would build from the updated parameters, stamps current (the lazy path is not taken again)."""
+    from fiber_amd import ops as ops_mod
+    from fiber_amd.optim import FiberAdamW
+    torch.manual_seed(0)
+    cfgs = [(128, 4), (256, 8), (64, 2), (512, 16)]
+    lins = [torch.nn.Linear(C, 3 * C).to(DEV) for C, _ in cfgs]
+    for m in lins:
+        m.bias.data.normal_(0, 0.1)
+    opt = FiberAdamW([p for m in lins for p in m.parameters()], lr=1e-2, weight_decay=0.01)
+    xs = [torch.randn(2, 16, C, device=DEV).to(BF).requires_grad_(True) for C, _ in cfgs]
+    for it in range(3):
+        opt.zero_grad(set_to_none=True)
+        loss = sum(ops_mod.linear_qkv_head_major(x, m.weight, m.bias, h).float().square().mean() for x, m, (_, h) in zip(xs, lins, cfgs))
+        loss.backward()
+        ptrs = [[t.data_ptr() for t in ops_mod._wcache[("HM", id(m.weight))][1][:3]] for m in lins]
+        opt.step()
+        for m, (C, h), p0 in zip(lins, cfgs, ptrs):
+            hit = ops_mod._cache_get(("HM", id(m.weight)), m.weight)
+            assert hit is not None and hit[0] == (ops_mod._stamp(m.weight), ops_mod._stamp(m.bias)), "head-major copies not marked current after the step"
+            wp, bp, wpt = hit[1][:3]
+            assert [wp.data_ptr(), bp.data_ptr(), wpt.data_ptr()] == p0
+            perm = ops_mod._qkv_perm(C, h, m.weight.device)[0]
+            assert torch.equal(wp, m.weight.detach()[perm].to(BF))
+            assert torch.equal(wpt, m.weight.detach()[perm].to(BF).t().contiguous())
+            assert torch.equal(bp, m.bias.detach()[perm])
+
+
 @pytest.mark.parametrize("B,S,L,hid,kvdim", [(3, 40, 144, 768, 1024), (2, 12, 36, 64, 128)])
 def test_packed_projections_and_packed_mha(ops, B, S, L, hid, kvdim):
     """ops.linear_packed + ops.mha_qkv_packed / mha_kv_packed (q | k | v of RobertaSelfAttention and key | value of t2i as ONE GEMM,

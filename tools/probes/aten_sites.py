@@ -41,24 +41,34 @@ def step():
 for _ in range(3):
     step()
 torch.cuda.synchronize()
-from torch.profiler import ProfilerActivity, profile
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-    step()
-    torch.cuda.synchronize()
+
+# Which Python line issues each ATen call?  torch.profiler's with_stack comes back empty on this build, so the calls are counted by a
+# TorchDispatchMode (it follows autograd into its worker thread) with the innermost fiber_amd / bench frame of the Python stack; ops that
+# launch no kernel (views, metadata) are dropped by name.
+import traceback
+from torch.utils._python_dispatch import TorchDispatchMode
+NO_KERNEL = ("view", "reshape", "expand", "permute", "transpose", "t.default", "slice", "select", "unsqueeze", "squeeze", "as_strided", "detach", "alias",
+             "empty", "_unsafe_view", "unbind", "split", "narrow", "size", "stride", "numel", "is_", "_local_scalar", "lift_fresh", "resize", "set_", "chunk",
+             "_to_copy.default@same", "new_empty", "record_stream", "storage_offset", "sym_", "prim", "unfold", "diagonal", "movedim", "flatten", "contiguous")
 sites = collections.Counter()
-kern = collections.Counter()
-for ev in prof.events():
-    if not ev.name.startswith("aten::") or ev.device_time_total <= 0 or not getattr(ev, "kernels", None):
-        continue
-    if not ev.kernels:
-        continue
-    frame = "?"
-    for fr in (ev.stack or []):
-        if "fiber_amd" in fr or "bench.py" in fr or "aten_sites" in fr:
-            frame = fr.split("/root/repo/")[-1] if "/root/repo/" in fr else fr
-            break
-    sites[(ev.name, frame)] += len(ev.kernels)
-    kern[ev.name] += len(ev.kernels)
-print("ATen ops with device kernels in one step:", sum(kern.values()))
-for (name, frame), c in sites.most_common(60):
-    print(f"{c:5d}  {name:28s} {frame[:150]}")
+
+
+class Census(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func)
+        if not any(k in name for k in NO_KERNEL):
+            frame = "?"
+            for fr in reversed(traceback.extract_stack(limit=40)):
+                if ("fiber_amd" in fr.filename or fr.filename.endswith("bench.py")) and "probes" not in fr.filename:
+                    frame = f"{fr.filename.split('/root/repo/')[-1].split('repo/')[-1]}:{fr.lineno} {fr.name}"
+                    break
+            sites[(name, frame)] += 1
+        return func(*args, **(kwargs or {}))
+
+
+with Census():
+    step()
+torch.cuda.synchronize()
+print(f"ATen calls (views / metadata dropped) in one step at B = {B}: {sum(sites.values())}")
+for (name, frame), n in sites.most_common(70):
+    print(f"{n:5d}  {name:36s} {frame}")
