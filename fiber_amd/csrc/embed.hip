@@ -161,18 +161,28 @@ __global__ __launch_bounds__(256) void roberta_embed_bwd_kernel(const bf16* __re
   }
 }
 
-// img fp32 [B,3,H,W] -> cols bf16 [B*(H/4)*(W/4), 64]; column = c*16 + kh*4 + kw for c<3, zeros for 48..63
-__global__ __launch_bounds__(256) void im2col4_kernel(const float* __restrict__ img, bf16* __restrict__ cols, int B, int H, int W) {
+// img fp32 [B,3,H,W] -> cols bf16 [B*(H/4)*(W/4), 64]; column = c*16 + kh*4 + kw for c<3, zeros for 48..63.
+// PAIR: the 2B-sample batch of the one-pass MLM + ITM step, [img ; where(sel, img, alt)] (objectives.py:56-61 builds the ITM half with a
+// python loop over samples; compute_mlm_itm_fused concatenates the halves), gathered straight from the two sources: sample b < B reads
+// img[b], sample B + b reads sel[b] ? img[b] : alt[b] -- no torch.where / torch.cat pass over the fp32 images (3.2 GB of traffic at B = 256).
+template <bool PAIR>
+__global__ __launch_bounds__(256) void im2col4_kernel(const float* __restrict__ img, const float* __restrict__ alt, const unsigned char* __restrict__ sel,
+                                                      bf16* __restrict__ cols, int B, int H, int W) {
   const int Hp = H >> 2, Wp = W >> 2;
-  const size_t total = (size_t)B * Hp * Wp * 16;             // 16 groups of 4 columns per patch
+  const size_t total = (size_t)(PAIR ? 2 * B : B) * Hp * Wp * 16;   // 16 groups of 4 columns per patch
   for (size_t idx = blockIdx.x * (size_t)256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
     const int grp = idx & 15;
     const size_t patch = idx >> 4;
-    const int j = patch % Wp, i = (patch / Wp) % Hp, b = patch / ((size_t)Wp * Hp);
+    const int j = patch % Wp, i = (patch / Wp) % Hp;
+    int b = patch / ((size_t)Wp * Hp);
+    const float* src = img;
+    if constexpr (PAIR) {
+      if (b >= B) { b -= B; if (!sel[b]) src = alt; }
+    }
     bf16x4 o;
     if (grp < 12) {
       const int c = grp >> 2, kh = grp & 3;
-      const float4 v = *reinterpret_cast<const float4*>(img + (((size_t)b * 3 + c) * H + i * 4 + kh) * W + j * 4);
+      const float4 v = *reinterpret_cast<const float4*>(src + (((size_t)b * 3 + c) * H + i * 4 + kh) * W + j * 4);
       o[0] = f2bf(v.x); o[1] = f2bf(v.y); o[2] = f2bf(v.z); o[3] = f2bf(v.w);
     } else {
       o[0] = o[1] = o[2] = o[3] = f2bf(0.f);
@@ -220,7 +230,19 @@ extern "C" int fiber_im2col_patch4(const float* img, void* cols, int B, int H, i
   if ((H & 3) || (W & 3)) return FIBER_EINVAL;
   const size_t total = (size_t)B * (H / 4) * (W / 4) * 16;
   size_t g = (total + 255) / 256;
-  hipLaunchKernelGGL(im2col4_kernel, dim3((int)(g > 4096 ? 4096 : g)), dim3(256), 0, stream, img, (bf16*)cols, B, H, W);
+  hipLaunchKernelGGL(im2col4_kernel<false>, dim3((int)(g > 4096 ? 4096 : g)), dim3(256), 0, stream, img, nullptr, nullptr, (bf16*)cols, B, H, W);
+  FIBER_CHECK_LAUNCH();
+  return FIBER_OK;
+}
+
+// img, alt fp32 [B,3,H,W]; sel uint8 [B] -> cols bf16 [2B*(H/4)*(W/4), 64] of the batch [img ; where(sel, img, alt)]
+extern "C" int fiber_im2col_patch4_pair(const float* img, const float* alt, const unsigned char* sel, void* cols, int B, int H, int W,
+                                        hipStream_t stream) {
+  if ((H & 3) || (W & 3)) return FIBER_EINVAL;
+  if (B <= 0) return FIBER_OK;
+  const size_t total = (size_t)2 * B * (H / 4) * (W / 4) * 16;
+  size_t g = (total + 255) / 256;
+  hipLaunchKernelGGL(im2col4_kernel<true>, dim3((int)(g > 4096 ? 4096 : g)), dim3(256), 0, stream, img, alt, sel, (bf16*)cols, B, H, W);
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;
 }

@@ -40,6 +40,7 @@ SIGNATURES = {
     "fiber_roberta_embed_fwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, U64, P],
     "fiber_roberta_embed_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, U64, P],
     "fiber_im2col_patch4": [P, P, I, I, I],
+    "fiber_im2col_patch4_pair": [P, P, P, P, I, I, I],
     "fiber_gelu_bwd_bf16": [P, P, P, L],
     "fiber_gelu_bwd_colsum_bf16": [P, P, P, P, P, I, I],
     "fiber_scale_add_bf16": [P, P, P, F, P, L],

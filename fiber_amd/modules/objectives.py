@@ -101,10 +101,10 @@ def compute_mlm_itm_fused(pl_module, batch, itm_labels=None):
         itm_labels = itm_labels[torch.randperm(itm_labels.size(0))]
     else:
         itm_labels = itm_labels.to(pl_module.device).float()
-    sel = itm_labels.view(-1, 1, 1, 1) == 1
     true_img, false_img = batch["image"][0], batch["false_image_0"][0]
     fused = {
-        "image": [torch.cat([true_img, torch.where(sel, true_img, false_img)], 0)],
+        # [true ; where(label == 1, true, false)] as its two sources: the patch embedding gathers from them (ops.ImagePair)
+        "image": [ops.ImagePair(true_img, false_img, itm_labels == 1)],
         "text_ids": torch.cat([batch["text_ids_mlm"], batch["text_ids"]], 0),
         "text_labels": torch.cat([batch["text_labels_mlm"], batch["text_labels"]], 0),
         "text_masks": torch.cat([batch["text_masks"], batch["text_masks"]], 0),

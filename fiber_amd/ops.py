@@ -1681,17 +1681,43 @@ def roberta_embed(ids, word, pos_tab, type_tab, gamma, beta, pad=1, eps=1e-5, p_
     return _RobertaEmbed.apply(ids, word, pos_tab, type_tab, gamma, beta, pad, eps, p, next_seed() if p > 0 else 0)
 
 
+class ImagePair:
+    """The image batch of the one-pass MLM + ITM step, [img ; where(sel, img, alt)] (objectives.compute_mlm_itm_fused), as its two sources:
+    the patch embedding gathers its im2col rows from them (fiber_im2col_patch4_pair), so neither the `where` nor the `cat` pass over the fp32
+    images runs.  `tensor()` builds the batch for any other consumer."""
+
+    def __init__(self, img, alt, sel):
+        assert img.shape == alt.shape and sel.numel() == img.shape[0]
+        self.img, self.alt, self.sel = img, alt, sel.reshape(-1).to(torch.bool)
+        self.shape = torch.Size((2 * img.shape[0],) + tuple(img.shape[1:]))
+        self.device, self.dtype, self.is_cuda = img.device, img.dtype, img.is_cuda
+
+    def size(self, d=None):
+        return self.shape if d is None else self.shape[d]
+
+    def tensor(self):
+        return torch.cat([self.img, torch.where(self.sel.view(-1, 1, 1, 1), self.img, self.alt)], 0)
+
+
 class _PatchEmbedProj(torch.autograd.Function):
     """Conv2d(3->C, k=4, s=4) + bias as im2col + MFMA GEMM (no input gradient: the image is data)."""
 
     @staticmethod
-    def forward(ctx, img, weight, bias):
-        B, _, H, W = img.shape
+    def forward(ctx, img, weight, bias, pair=None):
         Cout = weight.shape[0]
-        img = _c(img.float())
-        rows = B * (H // 4) * (W // 4)
-        cols = torch.empty((rows, 64), dtype=BF16, device=img.device)
-        lib.call("fiber_im2col_patch4", lib.ptr(img), lib.ptr(cols), B, H, W)
+        if pair is not None:
+            B, _, H, W = pair.shape
+            rows = B * (H // 4) * (W // 4)
+            a, b, sel = _c(pair.img.float()), _c(pair.alt.float()), pair.sel.to(torch.uint8)
+            cols = torch.empty((rows, 64), dtype=BF16, device=a.device)
+            lib.call("fiber_im2col_patch4_pair", lib.ptr(a), lib.ptr(b), lib.ptr(sel), lib.ptr(cols), B // 2, H, W)
+            img = a
+        else:
+            B, _, H, W = img.shape
+            img = _c(img.float())
+            rows = B * (H // 4) * (W // 4)
+            cols = torch.empty((rows, 64), dtype=BF16, device=img.device)
+            lib.call("fiber_im2col_patch4", lib.ptr(img), lib.ptr(cols), B, H, W)
         key = ("pe", id(weight))
         hit = _cache_get(key, weight)
         if hit is None or hit[0] != _stamp(weight):
@@ -1713,10 +1739,14 @@ class _PatchEmbedProj(torch.autograd.Function):
             out.view(w_.shape[0], 48).copy_(w_[:, :48])
             return out, b_
         dw, db = wgrad(dy2, cols, want_bias=True, post=crop)
-        return None, dw, db
+        return None, dw, db, None
 
 
 def patch_embed_proj(img, weight, bias):
+    if isinstance(img, ImagePair):
+        if img.is_cuda:
+            return _PatchEmbedProj.apply(None, weight, bias, img)
+        img = img.tensor()
     return _PatchEmbedProj.apply(img, weight, bias)
 
 

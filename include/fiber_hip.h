@@ -148,6 +148,10 @@ int fiber_roberta_embed_bwd(const void* dy, const int64_t* ids, const int* pos, 
 
 /* timm PatchEmbed Conv2d(3->C,k=4,s=4) as im2col (K=48 ordered [c][kh][kw], zero padded to 64) feeding fiber_gemm_nt_bf16 */
 int fiber_im2col_patch4(const float* img, void* cols, int B, int H, int W, fiber_stream_t stream);
+/* ... of the 2B-sample batch [img ; where(sel, img, alt)] that the one-pass MLM + ITM step feeds the backbone (objectives.py:56-61 draws
+ * the ITM images, :17-75 are the two passes), gathered from the two fp32 sources [B,3,H,W]; sel uint8 [B]. cols bf16 [2B*(H/4)*(W/4), 64]. */
+int fiber_im2col_patch4_pair(const float* img, const float* alt, const unsigned char* sel, void* cols, int B, int H, int W,
+                             fiber_stream_t stream);
 
 /* element-wise / reduction helpers (n % 8 == 0) */
 int fiber_gelu_bwd_bf16(const void* dgelu, const void* h_pre, void* dh, long n, fiber_stream_t stream);

@@ -592,6 +592,28 @@ def test_patch_embed(ops, B, img, dim):
     assert_close("db", b.grad, br.grad, 4e-3)
 
 
+@pytest.mark.parametrize("B,img,dim", [(5, 32, 32), (3, 384, 128)])
+def test_patch_embed_of_an_image_pair_is_the_patch_embed_of_the_concatenated_batch(ops, B, img, dim):
+    """ops.ImagePair (the [true ; where(label, true, false)] image batch of the one-pass MLM + ITM step, gathered from its two sources by
+    fiber_im2col_patch4_pair) against ops.patch_embed_proj on the batch built with torch.where / torch.cat: bitwise the same output and gradients."""
+    a, alt = rnd(B, 3, img, img).to(DEV), rnd(B, 3, img, img, seed=3).to(DEV)
+    sel = torch.tensor([i % 3 != 1 for i in range(B)], device=DEV)
+    w, b = rnd(dim, 3, 4, 4, std=0.1).to(DEV).requires_grad_(True), rnd(dim, seed=1, std=0.1).to(DEV).requires_grad_(True)
+    pair = ops.ImagePair(a, alt, sel)
+    assert tuple(pair.shape) == (2 * B, 3, img, img)
+    ref_batch = torch.cat([a, torch.where(sel.view(-1, 1, 1, 1), a, alt)], 0)
+    assert torch.equal(pair.tensor(), ref_batch)
+    g = bf(rnd(2 * B, (img // 4) ** 2, dim, seed=2))
+    outs = []
+    for x in (pair, ref_batch):
+        w.grad = b.grad = None
+        y = ops.patch_embed_proj(x, w, b)
+        y.backward(g)
+        outs.append((y.detach().clone(), w.grad.clone(), b.grad.clone()))
+    for name, p_, r_ in zip(("y", "dw", "db"), outs[0], outs[1]):
+        assert torch.equal(p_, r_), name
+
+
 def test_elementwise(ops):
     a, b = bf(rnd(4, 100, 64)).requires_grad_(True), bf(rnd(4, 100, 64, seed=1)).requires_grad_(True)
     alpha = torch.tensor([0.37], device=DEV, requires_grad=True)
