@@ -51,7 +51,8 @@ SIGNATURES = {
     "fiber_droppath_scale_f32": [P, I, F, U64, P],
     "fiber_rowscale_add_bf16": [P, P, P, P, L, L],
     "fiber_rowscale_colsum_bf16": [P, P, P, P, P, I, I, I],
-    "fiber_ce_fwd_bf16": [P, P, P, P, I, I, L],
+    "fiber_ce_fwd_bf16": [P, P, P, P, P, I, I, L],
+    "fiber_colsum_labelled_bf16": [P, P, P, P, I, I, L],
     "fiber_ce_bwd_bf16": [P, P, P, P, P, I, I, L],
     "fiber_adamw_multi_f32": [P, P, P, I, F, F, F, F, F, I, P],
     "fiber_resize_bicubic_norm_u8": [P, I, P, P, P, I, I, P, P],
@@ -63,7 +64,7 @@ SIGNATURES = {
     "fiber_dcn_dx_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I],
 }
 # host-side helpers without a stream argument
-PLAIN = {"fiber_layernorm_bwd_grid": [I], "fiber_window_attn_bwd_slices": [I, I], "fiber_window_attn_colsum_rows": [I, I, I], "fiber_colsum_slabs": [I, I], "fiber_gemm_row_tile": [I, I, I], "fiber_gemm_tn_splits": [I, I, I],
+PLAIN = {"fiber_layernorm_bwd_grid": [I], "fiber_window_attn_bwd_slices": [I, I], "fiber_window_attn_colsum_rows": [I, I, I], "fiber_colsum_slabs": [I, I], "fiber_colsum_labelled_slabs": [I], "fiber_gemm_row_tile": [I, I, I], "fiber_gemm_tn_splits": [I, I, I],
          "fiber_adamw_chunk": [], "fiber_resample_ksize": [I, I], "fiber_dcn_dx_workspace": [I, I, I, I, I, I, I]}
 
 PLAIN_LONG = {"fiber_dcn_dx_workspace"}          # helpers returning a 64-bit count

@@ -60,9 +60,13 @@ class Accuracy(_Running):
 
     def __call__(self, logits, target):
         with torch.no_grad():
-            preds = logits.detach().argmax(dim=-1)
-            tgt = target.detach().to(preds.device)
+            tgt = target.detach().to(logits.device)
             valid = tgt != -100
+            handed = getattr(logits, "_fiber_argmax", None)     # ops.cross_entropy left the arg max of its labelled rows on the logits it was given
+            if (handed is not None and handed[2] == -100 and handed[0].numel() == tgt.numel() and handed[1].data_ptr() == tgt.data_ptr()):
+                preds = handed[0].view(tgt.shape).long()        # (-1 on ignored rows: never equal to a target the metric counts)
+            else:
+                preds = logits.detach().argmax(dim=-1)
             correct = ((preds == tgt) & valid).sum().float()
             total = valid.sum().float()
             self._update(correct, total)

@@ -7,7 +7,7 @@ import torch.nn.functional as F
 from .. import ops
 
 
-def _mlm_ce(logits, labels, head=None):
+def _mlm_ce(logits, labels, head=None, owner=None):
     """F.cross_entropy(logits, labels, ignore_index=-100) (objectives.py:24-28) on the HIP kernel for bf16 device logits.
 
     The 50265-way logits are bf16 (2 B instead of 8 MB per sample of HBM traffic); log-sum-exp averages their rounding away,
@@ -15,7 +15,10 @@ def _mlm_ce(logits, labels, head=None):
     token -- the dominant term of the loss-curve gap to the fp32 reference (tests/test_hip_modules.py, 50-step curve).  With
     `head` (the MLMHead, after its forward) the label logit is recomputed in fp32 from the head's hidden state -- a gathered
     dot product per token -- and substituted into the loss VALUE; gradients are unchanged (they are the same function)."""
-    loss = ops.cross_entropy(logits.to(torch.bfloat16), labels, -100)
+    x16 = logits.to(torch.bfloat16)
+    loss = ops.cross_entropy(x16, labels, -100)
+    if owner is not None and getattr(x16, "_fiber_argmax", None) is not None:
+        owner._fiber_argmax = x16._fiber_argmax              # the arg max of the labelled rows rides on the logits the metric will be given
     if head is not None and head.last_hidden is not None:
         with torch.no_grad():
             h = head.last_hidden.reshape(-1, head.last_hidden.shape[-1])
@@ -46,9 +49,9 @@ def _mlm_head(pl_module, text_feats, labels):
             feats = text_feats.reshape(-1, text_feats.shape[-1]).index_select(0, keep)
             lab = flat.index_select(0, keep)
             logits = pl_module.mlm_score(feats)
-            return _mlm_ce(logits, lab, pl_module.mlm_score), logits, lab
+            return _mlm_ce(logits, lab, pl_module.mlm_score, owner=logits), logits, lab
     logits = pl_module.mlm_score(text_feats)
-    return _mlm_ce(logits.view(-1, V), flat, pl_module.mlm_score), logits, labels
+    return _mlm_ce(logits.view(-1, V), flat, pl_module.mlm_score, owner=logits), logits, labels
 
 
 def compute_mlm(pl_module, batch):

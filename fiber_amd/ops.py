@@ -8,6 +8,7 @@ dX = dY.W on the NT kernel (transposed bf16 working copy of W), dW = dY^T.X (+ t
 Nothing here runs on the CPU: tensors must live on a HIP device.
 """
 import math
+import threading
 import weakref
 
 import torch
@@ -380,8 +381,34 @@ class _LibLinear(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 dw = torch.matmul(dy2.t(), x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy2.sum(0)
+            hint = _take_labelled_rows(dy2)
+            if hint is not None:                             # dlogits of _CrossEntropy: its ignored rows are zero, only the labelled ones are read
+                lab, ignore = hint
+                M, N = dy2.shape
+                slabs = lib.plain("fiber_colsum_labelled_slabs", M)
+                db32 = torch.empty(N, dtype=torch.float32, device=dy2.device)
+                ws = torch.empty(slabs * N, dtype=torch.float32, device=dy2.device) if slabs > 1 else None
+                lib.call("fiber_colsum_labelled_bf16", lib.ptr(dy2), lib.ptr(lab), lib.ptr(db32), lib.ptr(ws), M, N, ignore)
+                db = db32.to(dy2.dtype)                      # (what dy2.sum(0) returns: fp32 accumulation, one rounding)
+            else:
+                db = dy2.sum(0)
         return dx, dw, db
+
+
+# _CrossEntropy.backward -> the linear that produced the logits: "the rows of this gradient whose label is the ignore index are zero".
+_rows_tls = threading.local()
+
+
+def _offer_labelled_rows(dx, labels, ignore):
+    _rows_tls.slot = (dx.data_ptr(), tuple(dx.shape), labels, ignore)
+
+
+def _take_labelled_rows(t2d):
+    h = getattr(_rows_tls, "slot", None)
+    _rows_tls.slot = None
+    if h is not None and t2d.is_cuda and t2d.dtype == BF16 and t2d.is_contiguous() and h[0] == t2d.data_ptr() and h[1] == tuple(t2d.shape):
+        return h[2], h[3]
+    return None
 
 
 class _CrossEntropy(torch.autograd.Function):
@@ -395,7 +422,10 @@ class _CrossEntropy(torch.autograd.Function):
         lab = labels.contiguous()
         loss = torch.empty(rows, dtype=torch.float32, device=x.device)
         lse = torch.empty_like(loss)
-        lib.call("fiber_ce_fwd_bf16", lib.ptr(x), lib.ptr(lab), lib.ptr(loss), lib.ptr(lse), rows, V, int(ignore_index))
+        pred = torch.empty(rows, dtype=torch.int32, device=x.device)
+        lib.call("fiber_ce_fwd_bf16", lib.ptr(x), lib.ptr(lab), lib.ptr(loss), lib.ptr(lse), lib.ptr(pred), rows, V, int(ignore_index))
+        # arg max of the labelled rows (-1 on the others), for the accuracy metric: handed over on the logits object (fiber_utils.Accuracy)
+        logits._fiber_argmax = (pred, lab, int(ignore_index))
         nvalid = (lab != ignore_index).sum().clamp(min=1).float()
         ctx.save_for_backward(x, lab, lse, nvalid)
         ctx.ignore = int(ignore_index)
@@ -408,6 +438,7 @@ class _CrossEntropy(torch.autograd.Function):
         dx = torch.empty_like(x)
         lib.call("fiber_ce_bwd_bf16", lib.ptr(x), lib.ptr(lab), lib.ptr(lse), lib.ptr(scale), lib.ptr(dx), x.shape[0], x.shape[1],
                  ctx.ignore)
+        _offer_labelled_rows(dx, lab, ctx.ignore)
         return dx, None, None
 
 

@@ -190,10 +190,17 @@ int fiber_rowscale_colsum_bf16(const void* x, const float* scale, void* y, float
 /* Cross-entropy over the vocabulary for bf16 logits (caller side: compute_mlm's F.cross_entropy(..., ignore_index=-100),
  * objectives.py:24-28).  fwd: loss[r] = logsumexp(x[r,:]) - x[r, labels[r]] (0 on ignored rows), lse saved; bwd: dlogits =
  * (softmax - onehot) * scale[0] with scale a device scalar (upstream gradient / number of valid rows). */
-int fiber_ce_fwd_bf16(const void* logits, const long long* labels, float* loss, float* lse, int rows, int V,
+int fiber_ce_fwd_bf16(const void* logits, const long long* labels, float* loss, float* lse, int* pred, int rows, int V,
                       long long ignore_index, fiber_stream_t stream);
 int fiber_ce_bwd_bf16(const void* logits, const long long* labels, const float* lse, const float* scale, void* dlogits, int rows,
                       int V, long long ignore_index, fiber_stream_t stream);
+/* pred (nullable, int32 [rows]) of fiber_ce_fwd_bf16: arg max of every labelled row, smallest index among equal maxima as torch.argmax has
+ * it, -1 on ignored rows -- the MLM accuracy of the step (gadgets/my_metrics.py:5-28 via fiber_utils.py) without an argmax pass over all rows.
+ * fiber_colsum_labelled_bf16: the decoder's bias gradient, column sums of dlogits over the labelled rows only (fiber_ce_bwd_bf16 wrote zeros into
+ * the others; heads.py:47-62 MLMHead.bias); workspace fp32 [fiber_colsum_labelled_slabs(rows) * V]. */
+int fiber_colsum_labelled_slabs(int rows);
+int fiber_colsum_labelled_bf16(const void* x, const long long* labels, float* out, float* workspace, int rows, int V,
+                               long long ignore_index, fiber_stream_t stream);
 
 /* AdamW step of one parameter group in one launch (caller side of the path: transformers 4.6.0 AdamW(correct_bias=True) as
  * configured by fiber_utils.set_schedule, fiber_utils.py:248-252), also refreshing the bf16 working copies of the weights.

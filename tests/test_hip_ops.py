@@ -811,6 +811,40 @@ def test_cross_entropy_bf16(ops, rows, V):
     assert float(x.grad[lab == -100].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("rows,V", [(64, 50265), (600, 1000), (5000, 777)])
+def test_cross_entropy_hands_over_argmax_and_labelled_rows(ops, rows, V):
+    """Two by-products of the cross-entropy kernels for the MLM head (csrc/loss.hip): (1) the arg max of every labelled row -- coarse bf16 logits
+    with many exact ties, so the smallest-index rule of torch.argmax is exercised -- as fiber_utils.Accuracy consumes it; (2) the decoder's bias
+    gradient as column sums over the labelled rows only, against dlogits.float().sum(0), through ops.lib_linear's backward."""
+    from fiber_amd.modules.fiber_utils import Accuracy
+    g = torch.Generator().manual_seed(3)
+    h = bf(torch.randn(rows, 48, generator=g))
+    w = (torch.randn(V, 48, generator=g) * 0.3).to(DEV).to(BF).requires_grad_(True)
+    b = (torch.randn(V, generator=g) * 0.1).to(DEV).to(BF).requires_grad_(True)
+    lab = torch.randint(0, V, (rows,), generator=g)
+    lab[torch.rand(rows, generator=g) < 0.8] = -100
+    lab[0] = 3
+    lab = lab.to(DEV)
+    logits = ops.lib_linear(h, w, b)
+    logits.data.copy_((logits.detach().float() * 2).round() / 2)          # half-integer logits: ties in almost every row
+    loss = ops.cross_entropy(logits, lab)
+    pred, lab_seen, ignore = logits._fiber_argmax
+    valid = lab != -100
+    want = logits.detach().argmax(-1)
+    assert torch.equal(pred[valid].long(), want[valid]) and bool((pred[~valid] == -1).all())
+    ties = (logits.detach()[valid] == logits.detach()[valid].max(-1, keepdim=True).values).sum(-1)
+    assert int((ties > 1).sum()) > 0, "the case is meant to contain ties"
+    acc = Accuracy()(logits, lab)
+    logits2 = logits.detach().clone()                                       # (no hand-over on this object: the metric's own argmax)
+    assert float(acc) == float(Accuracy()(logits2, lab))
+    loss.backward()
+    x2 = logits.detach().requires_grad_(True)
+    ops.cross_entropy(x2, lab).backward()
+    want_db = x2.grad.float().sum(0)
+    assert float(x2.grad[~valid].abs().max()) == 0.0
+    assert_close("db", b.grad, want_db, 4e-3)
+
+
 def test_transposed_weight_copies_refreshed_in_one_launch():
     """FiberAdamW.step() rewrites every cached W^T working copy with one multi-tensor transpose: same storage as before the
     step, contents = transpose of the updated bf16 copy, and the lazy path is not taken again (stamps current)."""
