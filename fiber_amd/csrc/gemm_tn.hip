@@ -46,7 +46,6 @@ struct TnArgs {
   const float* row_mask;   // optional fp32 [M / rows_per_sample]: rows of samples whose entry is 0 do not contribute
   int rows_per_sample;     // (a multiple of the K-tile depth: a K tile never straddles two samples)
   float scale;             // the result (and the bias sums) are multiplied by this
-  const int* row_map;      // optional int32 [N]: output row n (and bias entry n) is written at row_map[n] (a permutation)
 };
 
 __device__ __attribute__((aligned(16))) unsigned g_tn_zeros[128];   // 512 zero bytes: the source of dY rows past M
@@ -275,7 +274,7 @@ __global__ __launch_bounds__(TS * 2) void gemm_tn_kernel(TnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int n = nb + (r & 3) + 8 * (r >> 2);
-          if (n < a.N) outp[(size_t)(a.row_map ? a.row_map[n] : n) * a.K + kk] = acc[t][u][r] * a.scale;
+          if (n < a.N) outp[(size_t)n * a.K + kk] = acc[t][u][r] * a.scale;
         }
       }
     }
@@ -283,12 +282,14 @@ __global__ __launch_bounds__(TS * 2) void gemm_tn_kernel(TnArgs a) {
     float* csp = a.cs + (size_t)s * a.N;
     const float v = (csa + __shfl_xor(csa, 32)) * a.scale;
     const int n = n0 + wa * WTA + wb * 32 + (lane & 31);
-    if (lane < 32 && n < a.N) csp[a.row_map ? a.row_map[n] : n] = v;
+    if (lane < 32 && n < a.N) csp[n] = v;
   }
 }
 
 // out[i] = sum_s slab[s][i] over the N*K tile elements (float4) and, optionally, the N column sums
-__device__ __forceinline__ void tn_fold_item(const float* ws, const float* ws_cs, float* out, float* cs, int S, long nk4, int N, long i) {
+// row_map (nullable): element (n, k) of the sum is written at row row_map[n] (a float4 never straddles rows: K % 8 == 0), bias entry n at row_map[n]
+__device__ __forceinline__ void tn_fold_item(const float* ws, const float* ws_cs, float* out, float* cs, int S, long nk4, int N, long i,
+                                             const int* row_map = nullptr) {
   if (i < nk4) {
     const float4* p = reinterpret_cast<const float4*>(ws) + i;
     float4 t = p[0];
@@ -311,17 +312,23 @@ __device__ __forceinline__ void tn_fold_item(const float* ws, const float* ws_cs
       const float4 v = p[(long)s * nk4];
       t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
     }
-    reinterpret_cast<float4*>(out)[i] = t;
+    long o = i;
+    if (row_map) {
+      const long k4 = nk4 / N;                             // float4s per row
+      const long n = i / k4;
+      o = (long)row_map[n] * k4 + (i - n * k4);
+    }
+    reinterpret_cast<float4*>(out)[o] = t;
   } else if (cs != nullptr && i - nk4 < N) {
     const int n = (int)(i - nk4);
     float t = 0.f;
     for (int s = 0; s < S; ++s) t += ws_cs[(long)s * N + n];
-    cs[n] = t;
+    cs[row_map ? row_map[n] : n] = t;
   }
 }
 
-__global__ __launch_bounds__(256) void tn_fold_kernel(const float* ws, const float* ws_cs, float* out, float* cs, int S, long nk4, int N) {
-  tn_fold_item(ws, ws_cs, out, cs, S, nk4, N, (long)blockIdx.x * 256 + threadIdx.x);
+__global__ __launch_bounds__(256) void tn_fold_kernel(const float* ws, const float* ws_cs, float* out, float* cs, int S, long nk4, int N, const int* row_map) {
+  tn_fold_item(ws, ws_cs, out, cs, S, nk4, N, (long)blockIdx.x * 256 + threadIdx.x, row_map);
 }
 
 // The folds of MANY weight gradients in one launch (ops.py defers them to the end of the backward pass: 187 launches of ~14 us per
@@ -383,23 +390,28 @@ static int tn_launch(const void* dY, const void* X, float* dW, float* dbias, flo
   if ((N & 7) || (K & 7) || (lddy & 7) || (ldx & 7)) return FIBER_EINVAL;
   if (row_mask && (rows_per_sample <= 0 || (rows_per_sample & 63))) return FIBER_EINVAL;
   const TnPlan p = tn_plan(M, N, K);
-  if (p.S > 1 && !workspace) return FIBER_EINVAL;
+  // The row permutation is applied by the fold (one index per float4 of the result), never by the GEMM's epilogue: a `row_map ? row_map[n] : n`
+  // in front of each of its 128 stores per lane cost EVERY weight gradient of the step 2.8 % (profiles/r06_kernel_diff_vs_r05.log).  A
+  // permuted result therefore always goes through the workspace, as ONE slab when the reduction is not split.
+  const bool via_ws = p.S > 1 || (row_map != nullptr && fold);
+  if (via_ws && !workspace) return FIBER_EINVAL;
+  if (row_map && !fold) return FIBER_EINVAL;
   TnArgs a;
   a.A = (const bf16*)dY; a.B = (const bf16*)X;
-  a.out = p.S > 1 ? workspace : dW;
-  a.cs = dbias ? (p.S > 1 ? workspace + (size_t)p.S * N * K : dbias) : nullptr;
+  a.out = via_ws ? workspace : dW;
+  a.cs = dbias ? (via_ws ? workspace + (size_t)p.S * N * K : dbias) : nullptr;
   a.M = M; a.N = N; a.K = K; a.lda = lddy; a.ldb = ldx;
   a.S = p.S; a.tiles_n = p.tiles_n; a.tiles_k = p.tiles_k; a.kt_per_split = p.kt_per_split; a.nk_total = p.nk_total;
-  a.row_mask = row_mask; a.rows_per_sample = rows_per_sample; a.scale = scale; a.row_map = row_map;
+  a.row_mask = row_mask; a.rows_per_sample = rows_per_sample; a.scale = scale;
   const unsigned grid = (unsigned)(p.tiles_n * p.tiles_k * p.S);
   if (p.ts == 256) hipLaunchKernelGGL((gemm_tn_kernel<256, 64, 2, true>), dim3(grid), dim3(512), 0, stream, a);
   else hipLaunchKernelGGL((gemm_tn_kernel<128, 32, 4, false>), dim3(grid), dim3(256), 0, stream, a);
   FIBER_CHECK_LAUNCH();
-  if (p.S > 1 && fold) {
+  if (via_ws && fold) {
     const long nk4 = (long)N * K / 4;
     const long total = nk4 + (dbias ? N : 0);
     hipLaunchKernelGGL(tn_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, workspace,
-                       workspace + (size_t)p.S * N * K, dW, dbias, p.S, nk4, N);
+                       workspace + (size_t)p.S * N * K, dW, dbias, p.S, nk4, N, row_map);
     FIBER_CHECK_LAUNCH();
   }
   return FIBER_OK;

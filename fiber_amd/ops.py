@@ -594,7 +594,7 @@ def wgrad(dh, x2, want_bias=False, row_mask=None, scale=1.0, post=None, row_map=
     dw = torch.empty((N, K), dtype=torch.float32, device=dh.device)
     db = torch.empty(N, dtype=torch.float32, device=dh.device) if want_bias else None
     S = lib.plain("fiber_gemm_tn_splits", M, N, K)
-    ws = torch.empty(S * (N * K + N), dtype=torch.float32, device=dh.device) if S > 1 else None
+    ws = torch.empty(S * (N * K + N), dtype=torch.float32, device=dh.device) if (S > 1 or row_map is not None) else None   # (the row map is applied by the fold)
     rps = (M // row_mask.numel()) if row_mask is not None else 0
     args = (lib.ptr(dh), lib.ptr(x2), lib.ptr(dw), lib.ptr(db), lib.ptr(ws), M, N, K, dh.stride(0), x2.stride(0), lib.ptr(row_mask), rps,
             float(scale))

@@ -50,7 +50,8 @@ int fiber_gemm_tn_bf16(const void* dY, const void* X, float* dW, float* dbias, f
 int fiber_gemm_tn_slabs_bf16(const void* dY, const void* X, float* dW, float* dbias, float* workspace, int M, int N, int K, int lddy,
                        int ldx, const float* row_mask, int rows_per_sample, float scale, fiber_stream_t stream);
 /* fiber_gemm_tn_bf16 with its output rows permuted on the way out: row n of dW (entry n of dbias) is written at row_map[n] (int32 [N], a
- * permutation) -- the gradient of a weight whose working copy has its rows in another order (the head-major qkv projection). */
+ * permutation) -- the gradient of a weight whose working copy has its rows in another order (the head-major qkv projection).  The
+ * permutation is applied by the fold of the M splits, so `workspace` is needed for every S: max(S, 1) * (N*K + N) floats. */
 int fiber_gemm_tn_rowmap_bf16(const void* dY, const void* X, float* dW, float* dbias, float* workspace, int M, int N, int K, int lddy,
                               int ldx, const float* row_mask, int rows_per_sample, float scale, const int* row_map,
                               fiber_stream_t stream);
