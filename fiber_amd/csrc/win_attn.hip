@@ -217,7 +217,7 @@ __device__ __forceinline__ void setup(const WinP& p, const Smem& S, int h, int n
 // ================================================================ forward =====================================
 // MAXC: 16-byte staging chunks per thread; NTC: key/query tiles if known at compile time (9 for 12x12 windows);
 // MTT: tile capacity (10 / 21); BREG: window-invariant bias slice in registers (else LDS look-ups per score)
-template <int MAXC, int NTC = 0, int MTT = 10, bool BREG = true, bool S0FREE = false>
+template <int MAXC, int NTC = 0, int MTT = 10, bool BREG = true>
 __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) {
   WIN_DIMS(MTT);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -240,18 +240,14 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
   setup<MTT>(p, S, h, nb, 2, 5.656854249492381f, 0.f);
 
   // this thread's staging chunks: chunk id = tid + c*blockDim -> (row = id>>2 of the window, 16-byte piece id&3)
-  // S0F (round-6 experiment, off: FIBER_WIN_FWD_S0F=1 for A/B): the three waves of SIMD 0 (0, 4, 8; nine waves sit 3 / 2 / 2 / 2 on the SIMDs)
-  // stage nothing, the 576 chunks go to the six waves of SIMDs 1-3.  Bit-identical, 0-1 % faster (tools/probes/win_fwd_ab.py): the forward is
-  // not bound by SIMD 0's issue slots, whatever the per-wave s_memtime trace suggests.
-  constexpr bool S0F = MAXC == 1 && NTC == 9 && S0FREE;
-  constexpr int NCH = S0F ? 2 : MAXC;
-  int spr[NCH], spc[NCH], sid[NCH];
-  bool sval[NCH];
+  // (Round-6 experiment, removed: the three waves of SIMD 0 -- nine waves sit 3 / 2 / 2 / 2 on the SIMDs -- staging nothing, their chunks given to
+  // the six waves of SIMDs 1-3: bit-identical, 0-1 % faster at 12 more registers, profiles/r06_win_fwd_s0f_ab.log.  The forward is not bound by
+  // SIMD 0's issue slots, whatever the per-wave s_memtime trace suggests.)
+  int spr[MAXC], spc[MAXC];
+  bool sval[MAXC];
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    int id = tid + c * blockDim.x;
-    if constexpr (S0F) id = (wave & 3) ? ((wave >> 2) * 3 + (wave & 3) - 1) * 64 + lane + c * 384 : 1 << 20;
-    sid[c] = id;
+  for (int c = 0; c < MAXC; ++c) {
+    const int id = tid + c * blockDim.x;
     sval[c] = (id >> 2) < p.N;
     const int r = sval[c] ? (id >> 2) : 0;
     spr[c] = r / p.ws; spc[c] = r - spr[c] * p.ws;
@@ -294,15 +290,15 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
   const float scale2 = scale * 1.4426950408889634f;     // scores kept in the log2 domain: exp is a bare v_exp_f32
   Geo geo;
   geo.set(p, g0);
-  bf16x8 kr[NCH], vr[NCH], qn;
+  bf16x8 kr[MAXC], vr[MAXC], qn;
   unsigned qpix = geo.pix(p, qpr, qpc);
   size_t qimg = geo.img(p);
   auto prefetch = [&]() {
     const bf16* base = p.qkv + qimg * ld;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
+    for (int c = 0; c < MAXC; ++c) {
       if (sval[c]) {
-        const unsigned sc = sid[c] & 3;
+        const unsigned sc = (tid + c * blockDim.x) & 3;
         const unsigned st = geo.pix(p, spr[c], spc[c]) * ld + sc * 8;
         kr[c] = *reinterpret_cast<const bf16x8*>(at(base + ko, st));
         vr[c] = *reinterpret_cast<const bf16x8*>(at(base + vo, st));
@@ -326,9 +322,9 @@ __global__ __launch_bounds__(MAXC == 1 ? 640 : 448) void win_fwd_kernel(WinP p) 
 #endif
     FWD_MARK(1);
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
+    for (int c = 0; c < MAXC; ++c) {
       if (sval[c]) {
-        const int id = sid[c], sr = id >> 2, sc = id & 3;
+        const int id = tid + c * blockDim.x, sr = id >> 2, sc = id & 3;
         *reinterpret_cast<bf16x8*>(Ks + sr * RS + sc * 8) = kr[c];
         *reinterpret_cast<bf16x8*>(Vs + sr * RS + sc * 8) = vr[c];
       }
@@ -1306,7 +1302,6 @@ void ensure_attrs() {
   hipFuncSetAttribute((const void*)win_bwd_dq_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   hipFuncSetAttribute((const void*)win_bwd_dkv_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   hipFuncSetAttribute((const void*)win_fwd_kernel<1, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-  hipFuncSetAttribute((const void*)win_fwd_kernel<1, 9, 10, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   hipFuncSetAttribute((const void*)win_fwd_kernel<3, 0, 21, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   hipFuncSetAttribute((const void*)win_bwd_dq_kernel<3, 0, 21, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   hipFuncSetAttribute((const void*)win_bwd_dkv_kernel<3, 0, 21, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
@@ -1392,11 +1387,7 @@ int fiber_win_fwd_launch(const void* qkv, const float* bias_table, void* o, floa
   int nw, sg;
   strip_geometry(p.N, nw, sg);
   if (big_window(p.N)) hipLaunchKernelGGL((win_fwd_kernel<3, 0, 21, false>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes<21>(nb, 2), st, p);
-  else if (p.N == 144 && (ntc_mask() & 1)) {
-    static const bool s0f = getenv("FIBER_WIN_FWD_S0F") && atoi(getenv("FIBER_WIN_FWD_S0F")) != 0;   // experiment: SIMD 0's waves stage nothing
-    if (!s0f) hipLaunchKernelGGL((win_fwd_kernel<1, 9>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2), st, p);
-    else hipLaunchKernelGGL((win_fwd_kernel<1, 9, 10, true, true>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2), st, p);
-  }
+  else if (p.N == 144 && (ntc_mask() & 1)) hipLaunchKernelGGL((win_fwd_kernel<1, 9>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2), st, p);
   else hipLaunchKernelGGL((win_fwd_kernel<1, 0>), dim3(cdiv(p.G, p.gpb), heads, sg), dim3(64 * nw), smem_bytes<10>(nb, 2), st, p);
   FIBER_CHECK_LAUNCH();
   return FIBER_OK;

@@ -1,4 +1,4 @@
-"""A/B of a window-attention forward switch read once per process (default FIBER_WIN_FWD_S0F = 0 / 1): us per call at the four Swin-B stages of
+"""A/B of a window-attention forward switch read once per process (any switch of the forward; the round-6 FIBER_WIN_FWD_S0F experiment this was written for is removed): us per call at the four Swin-B stages of
 512 images 384^2, outputs compared.    python tools/probes/win_fwd_ab.py [images] [ENV_NAME] [value_a] [value_b]"""
 import os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
