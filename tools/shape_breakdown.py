@@ -42,7 +42,7 @@ def gemm_row(name, sc):
             by += 2 * M * N
             kind = "gelu'*aux" + ("+droppath" if rps else "")
         return 2.0 * M * N * K, by, f"NT {kind}", (M, N, K)
-    if name == "fiber_gemm_tn_bf16":
+    if name in ("fiber_gemm_tn_bf16", "fiber_gemm_tn_rowmap_bf16"):
         M, N, K, lddy, ldx, rps, scale = sc
         return 2.0 * M * N * K, 2 * M * (N + K) + 4 * N * K, "TN wgrad" + ("+droppath" if rps else ""), (M, N, K)
     return None
