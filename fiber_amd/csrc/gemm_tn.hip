@@ -287,52 +287,81 @@ __global__ __launch_bounds__(TS * 2) void gemm_tn_kernel(TnArgs a) {
 }
 
 // out[i] = sum_s slab[s][i] over the N*K tile elements (float4) and, optionally, the N column sums
+// out = sum over the S slabs, element by element.  A workgroup owns CW = 256 / QL float4 columns of the result and cuts the slabs over QL thread
+// rows: thread (q, c) adds slabs q, q + QL, ... of column c (four requested before the first add), the QL partial sums meet in LDS and are added
+// in the order 0 .. QL - 1 -- a fixed order, the same in the one-result and the many-results launch.  (Round 6: one thread per float4 walking all S
+// slabs ran at 2.2-3.9 TB/s out of the Infinity Cache, 0.7 TB/s at the stage-0 shapes with 170 slabs and 48 workgroups; 187 folds a step.)
 // row_map (nullable): element (n, k) of the sum is written at row row_map[n] (a float4 never straddles rows: K % 8 == 0), bias entry n at row_map[n]
-__device__ __forceinline__ void tn_fold_item(const float* ws, const float* ws_cs, float* out, float* cs, int S, long nk4, int N, long i,
-                                             const int* row_map = nullptr) {
-  if (i < nk4) {
-    const float4* p = reinterpret_cast<const float4*>(ws) + i;
-    float4 t = p[0];
-    int s = 1;
-    for (; s + 8 <= S; s += 8) {                          // eight slabs requested before the first add (same summation order)
-      float4 v[8];
+__host__ __device__ inline int tn_fold_ql(int S) { return S >= 64 ? 16 : S >= 16 ? 8 : 4; }
+__host__ __device__ inline long tn_fold_nblocks(int S, long nk4, int N, bool has_cs) {
+  const int cw = 256 / tn_fold_ql(S);
+  return (nk4 + cw - 1) / cw + (has_cs ? (N + cw - 1) / cw : 0);
+}
+template <int QL>
+__device__ __forceinline__ void tn_fold_block(const float* ws, const float* ws_cs, float* out, float* cs, int S, long nk4, int N, long blk,
+                                              const int* row_map) {
+  constexpr int CW = 256 / QL;
+  __shared__ float4 part[QL][CW];
+  const int c = threadIdx.x % CW, q = threadIdx.x / CW;
+  const long nmain = (nk4 + CW - 1) / CW;
+  if (blk < nmain) {
+    const long i = blk * CW + c;
+    float4 t = {0.f, 0.f, 0.f, 0.f};
+    if (i < nk4) {
+      const float4* p = reinterpret_cast<const float4*>(ws) + i;
+      int s = q;
+      for (; s + 3 * QL < S; s += 4 * QL) {
+        float4 v[4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = p[(long)(s + u) * nk4];
+        for (int u = 0; u < 4; ++u) v[u] = p[(long)(s + u * QL) * nk4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { t.x += v[u].x; t.y += v[u].y; t.z += v[u].z; t.w += v[u].w; }
+        for (int u = 0; u < 4; ++u) { t.x += v[u].x; t.y += v[u].y; t.z += v[u].z; t.w += v[u].w; }
+      }
+      for (; s < S; s += QL) {
+        const float4 v = p[(long)s * nk4];
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+      }
     }
-    for (; s + 4 <= S; s += 4) {
-      float4 v[4];
+    part[q][c] = t;
+    __syncthreads();
+    if (q == 0 && i < nk4) {
+      float4 r = part[0][c];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = p[(long)(s + u) * nk4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { t.x += v[u].x; t.y += v[u].y; t.z += v[u].z; t.w += v[u].w; }
+      for (int k = 1; k < QL; ++k) { const float4 v = part[k][c]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+      long o = i;
+      if (row_map) {
+        const long k4 = nk4 / N;                           // float4s per row
+        const long n = i / k4;
+        o = (long)row_map[n] * k4 + (i - n * k4);
+      }
+      reinterpret_cast<float4*>(out)[o] = r;
     }
-    for (; s < S; ++s) {
-      const float4 v = p[(long)s * nk4];
-      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
-    }
-    long o = i;
-    if (row_map) {
-      const long k4 = nk4 / N;                             // float4s per row
-      const long n = i / k4;
-      o = (long)row_map[n] * k4 + (i - n * k4);
-    }
-    reinterpret_cast<float4*>(out)[o] = t;
-  } else if (cs != nullptr && i - nk4 < N) {
-    const int n = (int)(i - nk4);
+  } else if (cs != nullptr) {                              // the bias sums: CW entries per workgroup, the same cut over the slabs
+    const long n = (blk - nmain) * CW + c;
     float t = 0.f;
-    for (int s = 0; s < S; ++s) t += ws_cs[(long)s * N + n];
-    cs[row_map ? row_map[n] : n] = t;
+    if (n < N)
+      for (int s = q; s < S; s += QL) t += ws_cs[(long)s * N + n];
+    float* pf = reinterpret_cast<float*>(&part[0][0]);
+    pf[q * CW + c] = t;
+    __syncthreads();
+    if (q == 0 && n < N) {
+      float r = pf[c];
+#pragma unroll
+      for (int k = 1; k < QL; ++k) r += pf[k * CW + c];
+      cs[row_map ? row_map[n] : n] = r;
+    }
   }
 }
 
 __global__ __launch_bounds__(256) void tn_fold_kernel(const float* ws, const float* ws_cs, float* out, float* cs, int S, long nk4, int N, const int* row_map) {
-  tn_fold_item(ws, ws_cs, out, cs, S, nk4, N, (long)blockIdx.x * 256 + threadIdx.x, row_map);
+  const int ql = tn_fold_ql(S);
+  if (ql == 16) tn_fold_block<16>(ws, ws_cs, out, cs, S, nk4, N, blockIdx.x, row_map);
+  else if (ql == 8) tn_fold_block<8>(ws, ws_cs, out, cs, S, nk4, N, blockIdx.x, row_map);
+  else tn_fold_block<4>(ws, ws_cs, out, cs, S, nk4, N, blockIdx.x, row_map);
 }
 
-// The folds of MANY weight gradients in one launch (ops.py defers them to the end of the backward pass: 187 launches of ~14 us per
-// step at the bench batch, more than the folds' own bytes cost).  Same per-element summation order as tn_fold_kernel: same bits.
+// The folds of MANY weight gradients in one launch (ops.py can defer them to the end of the backward pass; measured slower than the immediate
+// folds, profiles/r06_summary.md section 3).  Same per-element summation order as tn_fold_kernel: same bits.
 struct FoldDesc { const float* ws; float* out; float* cs; int S, N, nk4, block0; };   // 40 bytes (cs: NULL = no bias sums)
 
 __global__ __launch_bounds__(256) void tn_fold_multi_kernel(const FoldDesc* __restrict__ table, int ndesc) {
@@ -342,8 +371,11 @@ __global__ __launch_bounds__(256) void tn_fold_multi_kernel(const FoldDesc* __re
     if (table[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const FoldDesc d = table[lo];
-  const long i = (long)(blockIdx.x - d.block0) * 256 + threadIdx.x;
-  tn_fold_item(d.ws, d.ws + (size_t)d.S * d.nk4 * 4, d.out, d.cs, d.S, d.nk4, d.N, i);
+  const long blk = (long)blockIdx.x - d.block0;
+  const int ql = tn_fold_ql(d.S);
+  if (ql == 16) tn_fold_block<16>(d.ws, d.ws + (size_t)d.S * d.nk4 * 4, d.out, d.cs, d.S, d.nk4, d.N, blk, nullptr);
+  else if (ql == 8) tn_fold_block<8>(d.ws, d.ws + (size_t)d.S * d.nk4 * 4, d.out, d.cs, d.S, d.nk4, d.N, blk, nullptr);
+  else tn_fold_block<4>(d.ws, d.ws + (size_t)d.S * d.nk4 * 4, d.out, d.cs, d.S, d.nk4, d.N, blk, nullptr);
 }
 
 struct TnPlan { int ts, bkm, tiles_n, tiles_k, S, kt_per_split, nk_total; };
@@ -409,8 +441,7 @@ static int tn_launch(const void* dY, const void* X, float* dW, float* dbias, flo
   FIBER_CHECK_LAUNCH();
   if (via_ws && fold) {
     const long nk4 = (long)N * K / 4;
-    const long total = nk4 + (dbias ? N : 0);
-    hipLaunchKernelGGL(tn_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, workspace,
+    hipLaunchKernelGGL(tn_fold_kernel, dim3((unsigned)tn_fold_nblocks(p.S, nk4, N, dbias != nullptr)), dim3(256), 0, stream, workspace,
                        workspace + (size_t)p.S * N * K, dW, dbias, p.S, nk4, N, row_map);
     FIBER_CHECK_LAUNCH();
   }
@@ -432,7 +463,8 @@ extern "C" int fiber_gemm_tn_slabs_bf16(const void* dY, const void* X, float* dW
 }
 
 // table: device array of ndesc 40-byte records {ws, out, cs (8-byte pointers; cs NULL = no bias sums), int32 S, N, nk4 = N*K/4, block0},
-// block0 ascending from 0, blocks of a record = ceil((nk4 + (cs ? N : 0)) / 256); nblocks = their total.
+// block0 ascending from 0, blocks of a record = fiber_tn_fold_blocks(S, N, K, cs != NULL); nblocks = their total.
+extern "C" int fiber_tn_fold_blocks(int S, int N, int K, int has_cs) { return (int)tn_fold_nblocks(S, (long)N * K / 4, N, has_cs != 0); }
 extern "C" int fiber_tn_fold_multi(const void* table, int ndesc, int nblocks, hipStream_t stream) {
   if (ndesc <= 0 || nblocks <= 0) return FIBER_OK;
   hipLaunchKernelGGL(tn_fold_multi_kernel, dim3((unsigned)nblocks), dim3(256), 0, stream, (const FoldDesc*)table, ndesc);

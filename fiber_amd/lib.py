@@ -64,7 +64,7 @@ SIGNATURES = {
     "fiber_dcn_dx_bf16": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I],
 }
 # host-side helpers without a stream argument
-PLAIN = {"fiber_layernorm_bwd_grid": [I], "fiber_window_attn_bwd_slices": [I, I], "fiber_window_attn_colsum_rows": [I, I, I], "fiber_colsum_slabs": [I, I], "fiber_colsum_labelled_slabs": [I], "fiber_gemm_row_tile": [I, I, I], "fiber_gemm_tn_splits": [I, I, I],
+PLAIN = {"fiber_layernorm_bwd_grid": [I], "fiber_window_attn_bwd_slices": [I, I], "fiber_window_attn_colsum_rows": [I, I, I], "fiber_colsum_slabs": [I, I], "fiber_tn_fold_blocks": [I, I, I, I], "fiber_colsum_labelled_slabs": [I], "fiber_gemm_row_tile": [I, I, I], "fiber_gemm_tn_splits": [I, I, I],
          "fiber_adamw_chunk": [], "fiber_resample_ksize": [I, I], "fiber_dcn_dx_workspace": [I, I, I, I, I, I, I]}
 
 PLAIN_LONG = {"fiber_dcn_dx_workspace"}          # helpers returning a 64-bit count

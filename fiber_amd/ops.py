@@ -572,7 +572,7 @@ def flush_folds():
                     ws.record_stream(cur)
                 nk4 = N * K // 4
                 rows.append((ws.data_ptr(), dwp, dbp, S | (N << 32), nk4 | (block0 << 32)))
-                block0 += -(-(nk4 + (N if dbp else 0)) // 256)
+                block0 += lib.plain("fiber_tn_fold_blocks", S, N, K, 1 if dbp else 0)
             table = torch.tensor(rows, dtype=torch.int64).to(dev)      # (blocking: the host staging tensor dies with this statement)
             lib.call("fiber_tn_fold_multi", lib.ptr(table), len(rows), block0)
         items.clear()

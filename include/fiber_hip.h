@@ -57,7 +57,8 @@ int fiber_gemm_tn_rowmap_bf16(const void* dY, const void* X, float* dW, float* d
                               fiber_stream_t stream);
 /* Folds the slabs of MANY such GEMMs in one launch (ops.py defers them to the end of the backward pass).  table: device array of ndesc
  * 40-byte records {const float* ws; float* dW; float* dbias (NULL = none); int32 S, N, nk4 = N*K/4, block0}, block0 ascending from 0, a
- * record owns ceil((nk4 + (dbias ? N : 0)) / 256) blocks; nblocks = their total.  Same summation order as fiber_gemm_tn_bf16's fold. */
+ * record owns fiber_tn_fold_blocks(S, N, K, dbias != NULL) blocks; nblocks = their total.  Same summation order as fiber_gemm_tn_bf16's fold. */
+int fiber_tn_fold_blocks(int S, int N, int K, int has_dbias);
 int fiber_tn_fold_multi(const void* table, int ndesc, int nblocks, fiber_stream_t stream);
 
 /* nn.LayerNorm over the last dim (C%8==0, C<=4096); saves mean/rstd.  replaces swin_transformer.py:362,391,244; roberta.py:485,422 */
