@@ -157,10 +157,7 @@ __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
   z = z ^ (z >> 31);
   return (uint32_t)(z >> 32);
 }
-// keep with probability (1-p):  thresh = p * 2^32
-__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
-  return hash_u32(seed, idx) >= thresh;
-}
+// (hash_u32 keys the MLM collate and the DropPath draw -- both pinned by the oracle, oracle/image_ref.py; one draw per token / sample.)
 
 // Attention-probability dropout: keep decision of score (row, key) -- row = ((sample * heads + head) * Lq + query) -- of a launch keyed by
 // seed32.  Three 32-bit multiplies per score (two when the row or the key term is lane-constant and hoisted) instead of the three 64-bit
@@ -171,6 +168,15 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t x) {
   return x;
 }
 __device__ __forceinline__ uint32_t drop_seed32(uint64_t seed) { return (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B1u); }
+// Element-wise (hidden-state) dropout: keep element idx with probability 1 - p, thresh = p * 2^32.  Round 6: the same 32-bit mix as the attention
+// dropout -- hash_u32's three 64-bit multiplies are twelve quarter-rate VALU multiplies per ELEMENT, which made the text stack's residual adds
+// (stream_add: 31-MB tensors) VALU-bound at 58 us a call.  A vector's elements share drop_base(seed, index of its first element): one multiply per
+// vector, two (fmix32) per element.  drop_keep_e(drop_base(seed, b), e, t) == drop_keep(seed, b + e, t) for vectors that do not straddle 2^32.
+__device__ __forceinline__ uint32_t drop_base(uint64_t seed, uint64_t base) {
+  return drop_seed32(seed) + (uint32_t)base * 0x9E3779B1u + (uint32_t)(base >> 32) * 0x7FEB352Du;
+}
+__device__ __forceinline__ bool drop_keep_e(uint32_t h0, int e, uint32_t thresh) { return fmix32(h0 + (uint32_t)e * 0x9E3779B1u) >= thresh; }
+__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t thresh) { return fmix32(drop_base(seed, idx)) >= thresh; }
 __device__ __forceinline__ bool drop_keep_rk(uint32_t seed32, uint32_t row, uint32_t key, uint32_t thresh) {
   return fmix32(seed32 + row * 0x9E3779B1u + key * 0x7FEB352Du) >= thresh;
 }

@@ -203,8 +203,9 @@ __global__ __launch_bounds__(256) void dropout_kernel(const bf16* __restrict__ x
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
     const bf16x8 v = reinterpret_cast<const bf16x8*>(x)[i];
     bf16x8 o;
+    const uint32_t h0 = drop_base(seed, i * 8);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = drop_keep(seed, i * 8 + e, thresh) ? f2bf(bf2f(v[e]) * inv_keep) : f2bf(0.f);
+    for (int e = 0; e < 8; ++e) o[e] = drop_keep_e(h0, e, thresh) ? f2bf(bf2f(v[e]) * inv_keep) : f2bf(0.f);
     reinterpret_cast<bf16x8*>(y)[i] = o;
   }
 }
@@ -270,15 +271,17 @@ __global__ __launch_bounds__(256) void stream_add_kernel(StreamAddArgs p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = bf2f(av[e]);
     if (p.thresh_a) {
+      const uint32_t ha = drop_base(sa, i * 8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = drop_keep(sa, i * 8 + e, p.thresh_a) ? v[e] * p.inv_keep_a : 0.f;
+      for (int e = 0; e < 8; ++e) v[e] = drop_keep_e(ha, e, p.thresh_a) ? v[e] * p.inv_keep_a : 0.f;
     }
     if (p.b) {
       const bf16x8 bv = reinterpret_cast<const bf16x8*>(p.b)[i];
+      const uint32_t hb = drop_base(sb, i * 8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float t = bf2f(bv[e]);
-        if (p.thresh_b) t = drop_keep(sb, i * 8 + e, p.thresh_b) ? t * p.inv_keep_b : 0.f;
+        if (p.thresh_b) t = drop_keep_e(hb, e, p.thresh_b) ? t * p.inv_keep_b : 0.f;
         v[e] += al * t;
       }
     }
@@ -346,13 +349,14 @@ __global__ __launch_bounds__(256) void stream_add_bwd_kernel(StreamAddBwdArgs p)
       const float rs = rss[u];
       const bf16x8 dv = dvs[u];
       float g[8];
+      const uint32_t ha = drop_base(sa, i * 8), hb = drop_base(sb, i * 8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) g[e] = rs * bf2f(dv[e]);
       if (p.da) {
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          o[e] = f2bf(p.thresh_a ? (drop_keep(sa, i * 8 + e, p.thresh_a) ? g[e] * p.inv_keep_a : 0.f) : g[e]);
+          o[e] = f2bf(p.thresh_a ? (drop_keep_e(ha, e, p.thresh_a) ? g[e] * p.inv_keep_a : 0.f) : g[e]);
         reinterpret_cast<bf16x8*>(p.da)[i] = o;
       }
       if (p.db) {
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(256) void stream_add_bwd_kernel(StreamAddBwdArgs p)
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float m = p.thresh_b ? (drop_keep(sb, i * 8 + e, p.thresh_b) ? p.inv_keep_b : 0.f) : 1.f;
+          const float m = p.thresh_b ? (drop_keep_e(hb, e, p.thresh_b) ? p.inv_keep_b : 0.f) : 1.f;
           o[e] = f2bf(al * m * g[e]);
           if (p.dalpha) acc += g[e] * m * bf2f(bv[e]);
         }

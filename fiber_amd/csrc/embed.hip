@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void roberta_embed_fwd_kernel(const int64_t* _
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float r = (v[i][e] - mu) * rs * gg[e] + be[e];
-          if (p_drop > 0.f) r = drop_keep(seed, row * C + vi * 4 + e, thresh) ? r * inv_keep : 0.f;
+          if (p_drop > 0.f) r = drop_keep_e(drop_base(seed, (size_t)row * C + vi * 4), e, thresh) ? r * inv_keep : 0.f;
           o[e] = f2bf(r);
         }
         *reinterpret_cast<bf16x4*>(y + row * C + vi * 4) = o;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void roberta_embed_bwd_kernel(const bf16* __re
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float d = bf2f(d4[e]);
-          if (p_drop > 0.f) d = drop_keep(seed, (size_t)row * C + vi * 4 + e, thresh) ? d * inv_keep : 0.f;
+          if (p_drop > 0.f) d = drop_keep_e(drop_base(seed, (size_t)row * C + vi * 4), e, thresh) ? d * inv_keep : 0.f;
           xh[i][e] = (x[e] - mu) * rs;
           dg[i][e] = d * gg[e];
           s1 += dg[i][e];

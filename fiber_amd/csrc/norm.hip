@@ -328,7 +328,13 @@ template <bool MERGE, bool X32>
 int launch_fwd(const void* x, const float* g, const float* b, bf16* y, float* y32, float* mean, float* rstd, int rows, int C,
                float eps, MergeMap mm, hipStream_t st) {
   const int need = cdiv(rows, 4 * rows_per_wave(C));
-  const int grid = need < 4096 ? need : 4096;
+  // A wave loads gamma / beta (2 x 4 B per column) once and then walks its rows: with one iteration per wave -- every tensor below ~130 k rows at
+  // the 4096-workgroup cap -- that preload is more bytes than the wave's rows (text stack, 20480 x 768: 8 KB of parameters for 3 KB of rows).
+  // Four iterations per wave: 34 -> 22 us there, 86 -> 68 us at 73728 x 1024; the large tensors sit at the cap either way
+  // (tools/probes/ln_small_bench.py; FIBER_LN_FWD_DIV=1 restores one iteration).
+  static const int div = getenv("FIBER_LN_FWD_DIV") ? atoi(getenv("FIBER_LN_FWD_DIV")) : 4;
+  const int want = cdiv(need, div < 1 ? 1 : div);
+  const int grid = want < 4096 ? want : 4096;
 #define FWD(LPR, NV, UU, ...) hipLaunchKernelGGL((ln_fwd_kernel<LPR, NV, MERGE, X32, UU>), dim3(grid), dim3(256), 0, st, __VA_ARGS__)
   LN_DISPATCH(FWD, LN_UF, (LN_UF > 1 ? 2 : 1), x, g, b, y, y32, mean, rstd, rows, C, eps, mm);
 #undef FWD
@@ -353,7 +359,7 @@ int launch_bwd(const bf16* dy, const void* x, const float* g, const float* mean,
 
 // Number of workgroups the backward uses for `rows` rows: the caller sizes the fp32 workspace as grid*8*C floats.
 extern "C" int fiber_layernorm_bwd_grid(int rows) {
-  int g = cdiv(rows, 4 * 16);
+  int g = cdiv(rows, 4 * 16);                            // (8 or 4 rows per wave: 32 -> 27 -> ~22 us at the text stack's 20480 x 768, nothing above: kept)
   return g < 1 ? 1 : (g > 1024 ? 1024 : g);
 }
 
