@@ -18,6 +18,8 @@ from . import fiber_utils, heads, objectives, roberta, swin_transformer
 from .roberta import RobertaModel
 from .swin_helpers import swin_adapt_position_encoding
 
+_FORK_IMAGE = os.environ.get("FIBER_FORK_IMAGE", "1") != "0"      # A/B switch: 0 = autograd's own fan-in add for the image tokens of a fused step
+
 
 @torch.no_grad()
 def concat_all_gather(tensor):
@@ -265,16 +267,19 @@ class FIBERTransformerSS(LightningModule):
                 text_embeds.record_stream(main)
                 ext.record_stream(main)
                 side = None
+            # The image tokens feed the text layer's t2i keys / values AND the image block: the block reads an alias handed out by that projection,
+            # whose dX GEMM then adds the block's input gradient in its epilogue (no autograd fan-in pass over [B*L, C]: ops._LinearPacked).
+            sink = [] if (_FORK_IMAGE and self.training and torch.is_grad_enabled()) else None
             if side is None:                                 # same call order as the two-stream form below: the dropout /
-                new_text = layer(text_embeds, ext, encoder_hidden_states=image_embeds, **kw)[0]   # DropPath key counters
-                return blk(image_embeds, text_embeds, ext), new_text                       # do not depend on the mode
+                new_text = layer(text_embeds, ext, encoder_hidden_states=image_embeds, image_alias_sink=sink, **kw)[0]   # DropPath key counters
+                return blk(sink[0] if sink else image_embeds, text_embeds, ext), new_text  # do not depend on the mode
             main.wait_stream(side)                           # text tokens of the previous step (produced on `side`)
             side.wait_stream(main)                           # image tokens of the previous step (produced on `main`)
             text_embeds.record_stream(main)
             image_embeds.record_stream(side)
             with torch.cuda.stream(side):
-                new_text = layer(text_embeds, ext, encoder_hidden_states=image_embeds, **kw)[0]
-            return blk(image_embeds, text_embeds, ext), new_text
+                new_text = layer(text_embeds, ext, encoder_hidden_states=image_embeds, image_alias_sink=sink, **kw)[0]
+            return blk(sink[0] if sink else image_embeds, text_embeds, ext), new_text
 
         num_pre_block = 8 + num_pre_text
         for blk_cnt, blk in enumerate(vit.layers[2].blocks):

@@ -60,7 +60,7 @@ class RobertaSelfAttention(nn.Module):
         self.value = nn.Linear(kv, self.all_head_size)
         self.dropout = nn.Dropout(config.attention_probs_dropout_prob)
 
-    def forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None):
+    def forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None, kv_alias_sink=None):
         B, S, _ = hidden_states.shape
         C, scale = self.all_head_size, 1.0 / math.sqrt(self.attention_head_size)
         p = self.dropout.p if self.training else 0.0
@@ -74,7 +74,9 @@ class RobertaSelfAttention(nn.Module):
             # t2i: keys / values from the image tokens as one GEMM; roberta.py:276: the cross-attention mask is None
             q = ops.linear(hidden_states, self.query.weight, self.query.bias).view(B * S, C)
             Lk = encoder_hidden_states.shape[1]
-            kv = ops.linear_packed(encoder_hidden_states, [(self.key.weight, self.key.bias), (self.value.weight, self.value.bias)])
+            # (kv_alias_sink: the caller wants an alias of the image tokens for their other consumer, see ops._LinearPacked)
+            kv = ops.linear_packed(encoder_hidden_states, [(self.key.weight, self.key.bias), (self.value.weight, self.value.bias)],
+                                   fork_sink=kv_alias_sink)
             o = ops.mha_kv_packed(q, kv.view(B * Lk, 2 * C), None, B, self.num_attention_heads, scale, p, seed)
         return o.view(B, S, C)
 
@@ -155,7 +157,7 @@ class RobertaLayer(nn.Module):
         self.output = RobertaOutput(config)
         self.alpha_t2i = nn.Parameter(torch.Tensor([0]))
 
-    def forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None, last_norm=True):
+    def forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None, last_norm=True, image_alias_sink=None):
         ln = self.attention.output.LayerNorm
         if encoder_hidden_states is None:
             a = self.attention(hidden_states, attention_mask, residual=hidden_states)      # dense(attn) + h fused
@@ -163,7 +165,7 @@ class RobertaLayer(nn.Module):
             assert hasattr(self, "crossattention_t2i"), "layer built without cross-attention"
             a = self.attention(hidden_states, attention_mask)
             ca = self.crossattention_t2i
-            c = ca.self(a, None, encoder_hidden_states)
+            c = ca.self(a, None, encoder_hidden_states, kv_alias_sink=image_alias_sink)
             c = ops.linear(c, ca.output.dense.weight, ca.output.dense.bias)
             # hidden + (a + alpha_t2i * dropout(c)) in one pass (roberta.py:474-485: RobertaSelfOutput's dropout, the gate, the residual)
             a = ops.stream_add(hidden_states, a, b=c, alpha=self.alpha_t2i, p_b=ca.output.dropout.p, training=self.training)
