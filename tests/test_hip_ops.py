@@ -899,6 +899,34 @@ def test_head_major_qkv_copies_refreshed_in_one_launch():
             assert torch.equal(bp, m.bias.detach()[perm])
 
 
+@pytest.mark.parametrize("B,L,C,N", [(3, 144, 512, 768), (2, 37, 64, 24)])
+def test_packed_projection_fork_adds_the_other_consumers_gradient_in_its_dgrad(ops, B, L, C, N):
+    """ops.linear_packed(..., fork_sink=[]) hands out an alias of its input for the input's OTHER consumer; that consumer's gradient then reaches
+    the node itself and is added by the dX GEMM's residual epilogue.  Against the unforked graph (autograd's own fan-in add): the same outputs,
+    the same weight gradients, the input gradient equal up to one bf16 rounding (sum rounded once instead of twice)."""
+    x0 = bf(rnd(B, L, C))
+    w = [rnd(N, C, seed=s_, std=C ** -0.5).to(DEV).requires_grad_(True) for s_ in (1, 2)]
+    b = [rnd(N, seed=s_ + 5, std=0.1).to(DEV).requires_grad_(True) for s_ in (1, 2)]
+    g1, g2 = bf(rnd(B, L, 2 * N, seed=9)), bf(rnd(B, L, C, seed=10))
+    res = []
+    for fork in (False, True):
+        x = x0.clone().requires_grad_(True)
+        for t in w + b:
+            t.grad = None
+        sink = [] if fork else None
+        y = ops.linear_packed(x, [(w[0], b[0]), (w[1], b[1])], fork_sink=sink)
+        assert (len(sink) == 1 and sink[0].data_ptr() == x.data_ptr()) if fork else True
+        other = (sink[0] if fork else x) * 0.5                     # the other consumer
+        torch.autograd.backward([y, other], [g1, g2])
+        res.append((y.detach().clone(), x.grad.clone(), [t.grad.clone() for t in w + b]))
+    assert torch.equal(res[0][0], res[1][0])
+    for a_, r_ in zip(res[1][2], res[0][2]):
+        assert torch.equal(a_, r_)
+    want = (g1.float().view(-1, 2 * N) @ torch.cat([w[0], w[1]]).detach().to(BF).float()).view(B, L, C) + 0.5 * g2.float()
+    assert_close("dx forked", res[1][1], want, 4e-3)
+    assert_close("dx plain", res[0][1], want, 6e-3)
+
+
 @pytest.mark.parametrize("B,S,L,hid,kvdim", [(3, 40, 144, 768, 1024), (2, 12, 36, 64, 128)])
 def test_packed_projections_and_packed_mha(ops, B, S, L, hid, kvdim):
     """ops.linear_packed + ops.mha_qkv_packed / mha_kv_packed (q | k | v of RobertaSelfAttention and key | value of t2i as ONE GEMM,
