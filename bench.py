@@ -398,6 +398,9 @@ def main():
     import torch.distributed as dist
     from fiber_amd import parallel
     backend = os.environ.get("FIBER_DIST_BACKEND", "nccl")                    # RCCL; "gloo" only for 1-GPU wiring tests
+    # the group timeout bounds the rendezvous too: eight ranks paging torch in on a fresh box may arrive a minute or two apart
+    # (the tests pin 120 s through the environment; a benchmark run gets the room)
+    os.environ.setdefault("FIBER_DIST_TIMEOUT", "600")
     parallel.init_distributed(backend)
     ranks = dist.get_world_size() if dist.is_initialized() else 1
     assert ranks == args.gpus == world, f"process group has {ranks} ranks, --gpus {args.gpus}, WORLD_SIZE {world}"
