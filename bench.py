@@ -136,6 +136,26 @@ def _cpu_run(threads, budget_s, batch, legs, warm=2, timed=5):
     return res
 
 
+def launches_per_step(batch, budget_s=150.0):
+    """Device launches of one steady-state step (kernels of this library, ATen, the BLAS library; copy / fill commands), counted by
+    tools/probes/launch_count.py with torch.profiler in a CHILD process under a deadline (killed by PID): a profiler that misbehaves cannot
+    take the bench line with it.  The launch structure does not depend on the batch; the child uses a small one to stay short."""
+    import subprocess
+    torch.cuda.empty_cache()
+    proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "probes", "launch_count.py"), str(batch)],
+                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    try:
+        out, _ = proc.communicate(timeout=budget_s)
+    except subprocess.TimeoutExpired:
+        proc.kill()                                           # the exact child we started
+        proc.communicate()
+        return {"error": f"launch count did not finish in {budget_s:.0f} s"}
+    for line in reversed(out.splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    return {"error": f"launch count child exited with {proc.returncode}"}
+
+
 def cpu_baseline(budget_s=280.0, batch=2):
     """The oracle (CPU restatement of the reference path, fp32 PyTorch) timed on this host's cores, the legs BASELINE.md section 4b
     names (2 warm-ups, median of 5 each), every child process under a hard wall-clock budget (killed by PID at the deadline) so that
@@ -580,6 +600,7 @@ def main():
                                  "frac_of_mfma_peak": round(b / sec * flop_img / 1e12 / PEAK_BF16_TFLOPS, 4)}
             res["extra"] = {"batch_sweep": sweep, "batch_sweep_note": "per-GPU batches of SURVEY.md 8d (8 = coarse_grained/README.md:35), "
                             "same process after torch.cuda.empty_cache(), 8 warm-up + 10 timed eager steps each, wall clock around a device synchronise"}
+            res["extra"]["launches_per_step"] = launches_per_step(32)
         if world == 1 and not args.no_cpu_baseline and args.task == "mlm_itm":
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
