@@ -179,3 +179,16 @@ def test_bench_self_spawns_two_ranks_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["global_batch"] == 16
     assert len(d["step_ms"]["per_rank_mean"]) == 2
+
+
+def test_bench_counts_the_launches_of_a_step_in_a_child_process():
+    """`extra.launches_per_step` of the bench line: tools/probes/launch_count.py (torch.profiler, device activity) in a child under a deadline.
+    Round 6 counts 1493 kernels + 12 copy commands per steady-state step, 1292 of the kernels from libfiber_hip.so (the review's bar: <= 1700)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    d = bench.launches_per_step(8, budget_s=200.0)
+    assert "error" not in d, d
+    assert 1000 < d["kernels"] + d["copy_or_fill_commands"] <= 1700, d
+    assert d["of_which_fiber_hip"] > 0.8 * d["kernels"], d
